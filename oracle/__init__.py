@@ -1,0 +1,194 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package, and only as the checker.  The product package ``gloc3d_amd`` never imports it.
+
+``libgloc_oracle.so``  -- this repo's C restatement (oracle/knn_oracle.c, oracle/reg_oracle.c)
+``_ref/libgloc_ref.so`` -- the reference's own vendored nanoflann behind a C harness
+                           (oracle/ref_harness.cpp); built only where /root/reference exists.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgloc_oracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libgloc_ref.so")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class RegParams(C.Structure):
+    _fields_ = [
+        ("ransac_iters", C.c_uint32),
+        ("inlier_thresh", C.c_float),
+        ("min_inlier_ratio", C.c_float),
+        ("icp_iters", C.c_uint32),
+        ("max_corr_dist", C.c_float),
+        ("seed", C.c_uint64),
+    ]
+
+
+def build(ref=True, quiet=True):
+    """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
+    out = subprocess.DEVNULL if quiet else None
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"], stdout=out)
+    if ref and os.path.exists("/root/reference/registration/nanoflann.hpp"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"], stdout=out)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build(ref=False)
+        L = C.CDLL(LIB_PATH)
+        L.oracle_l2_eval.restype = C.c_float
+        L.oracle_l2_eval.argtypes = [_f32p, _f32p, C.c_size_t]
+        L.oracle_knn_search.argtypes = [_f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t,
+                                        C.c_size_t, C.c_size_t, C.c_size_t, _u64p, _f32p]
+        L.oracle_knn_search_mt.argtypes = L.oracle_knn_search.argtypes + [C.c_int]
+        L.oracle_transform_points.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        L.oracle_nn3.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _u32p, _f32p]
+        L.oracle_nn3_grid.argtypes = L.oracle_nn3.argtypes
+        L.oracle_kabsch_from_cov.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p]
+        L.oracle_ransac_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+        L.oracle_ransac_hypothesis.restype = C.c_int
+        L.oracle_ransac_hypothesis.argtypes = [_f32p, _f32p, _u32p, C.c_uint32, C.c_uint64,
+                                               C.c_uint32, C.c_uint32, _f32p, _f32p]
+        L.oracle_count_inliers.restype = C.c_uint32
+        L.oracle_count_inliers.argtypes = [_f32p, _f32p, _u32p, C.c_uint32, _f32p, _f32p, C.c_float]
+        L.oracle_reg_one.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_void_p,
+                                     C.POINTER(RegParams), C.c_uint32, _f32p,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.oracle_pose_error.argtypes = [_f32p, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.oracle_rng_key.restype = C.c_uint64
+        L.oracle_rng_key.argtypes = [C.c_uint64, C.c_uint64]
+        L.oracle_rng_draw.restype = C.c_uint64
+        L.oracle_rng_draw.argtypes = [C.c_uint64, C.c_uint64]
+        L.oracle_rng_gauss.restype = C.c_float
+        L.oracle_rng_gauss.argtypes = [C.c_uint64, C.c_uint64]
+        L.oracle_synth_iid.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, _f32p]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def ref():
+    """The reference's vendored nanoflann (oracle/_ref); raises if it was never built."""
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libgloc_ref.so not built (needs /root/reference)")
+        R = C.CDLL(REF_PATH)
+        R.ref_knn_build.restype = C.c_void_p
+        R.ref_knn_build.argtypes = [_f32p, C.c_size_t, C.c_size_t]
+        R.ref_knn_query.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, _u64p, _f32p]
+        R.ref_knn_free.argtypes = [C.c_void_p]
+        R.ref_nn3_build.restype = C.c_void_p
+        R.ref_nn3_build.argtypes = [_f32p, C.c_size_t]
+        R.ref_nn3_query.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u32p, _f32p]
+        R.ref_nn3_free.argtypes = [C.c_void_p]
+        _ref = R
+    return _ref
+
+
+# ---- convenience wrappers ------------------------------------------------------------------
+
+def knn_search(db, queries, k, first_row=0, last_row=None, threads=1):
+    db = np.ascontiguousarray(db, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32).reshape(-1, db.shape[1])
+    n, dim = db.shape
+    nq = queries.shape[0]
+    if last_row is None:
+        last_row = n
+    idx = np.empty((nq, k), np.uint64)
+    d2 = np.empty((nq, k), np.float32)
+    if threads > 1:
+        lib().oracle_knn_search_mt(db, n, dim, queries, nq, k, first_row, last_row, idx, d2, threads)
+    else:
+        lib().oracle_knn_search(db, n, dim, queries, nq, k, first_row, last_row, idx, d2)
+    return idx, d2
+
+
+def ref_knn_search(db, queries, k):
+    db = np.ascontiguousarray(db, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32).reshape(-1, db.shape[1])
+    n, dim = db.shape
+    nq = queries.shape[0]
+    R = ref()
+    h = R.ref_knn_build(db, n, dim)
+    idx = np.empty((nq, k), np.uint64)
+    d2 = np.empty((nq, k), np.float32)
+    R.ref_knn_query(h, queries, nq, k, idx, d2)
+    R.ref_knn_free(h)
+    return idx, d2
+
+
+def nn3(src, tgt, grid=False):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+    tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
+    idx = np.empty(src.shape[0], np.uint32)
+    d2 = np.empty(src.shape[0], np.float32)
+    f = lib().oracle_nn3_grid if grid else lib().oracle_nn3
+    f(src, src.shape[0], tgt, tgt.shape[0], idx, d2)
+    return idx, d2
+
+
+def ref_nn3(src, tgt):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+    tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
+    R = ref()
+    h = R.ref_nn3_build(tgt, tgt.shape[0])
+    idx = np.empty(src.shape[0], np.uint32)
+    d2 = np.empty(src.shape[0], np.float32)
+    R.ref_nn3_query(h, src, src.shape[0], idx, d2)
+    R.ref_nn3_free(h)
+    return idx, d2
+
+
+def transform_points(T, xyz):
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    lib().oracle_transform_points(T, xyz, xyz.shape[0], out)
+    return out
+
+
+def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
+            min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+    tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
+    prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed)
+    T = np.empty(16, np.float32)
+    rmse, inl, hyp, ok = C.c_float(), C.c_uint32(), C.c_uint32(), C.c_int()
+    if init_T is not None:
+        it = np.ascontiguousarray(init_T, np.float32).reshape(16)
+        itp = it.ctypes.data_as(C.c_void_p)
+    else:
+        itp = None
+    lib().oracle_reg_one(src, src.shape[0], tgt, tgt.shape[0], itp, C.byref(prm), cand_id, T,
+                         C.byref(rmse), C.byref(inl), C.byref(hyp), C.byref(ok))
+    return dict(T=T.reshape(4, 4), rmse=rmse.value, inliers=inl.value, best_hyp=hyp.value,
+                ok=bool(ok.value))
+
+
+def pose_error(T_gt, T_est):
+    a = np.ascontiguousarray(T_gt, np.float32).reshape(16)
+    b = np.ascontiguousarray(T_est, np.float32).reshape(16)
+    er, ep = C.c_float(), C.c_float()
+    lib().oracle_pose_error(a, b, C.byref(er), C.byref(ep))
+    return er.value, ep.value

@@ -1,0 +1,123 @@
+/*
+ * gloc_oracle.h -- CPU restatement of the GLoc3D place-retrieval + registration hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker.  The product (gloc3d_amd/, include/) never links, imports or falls back to it.
+ *
+ * Parity status
+ *   - descriptor kNN (oracle_knn_*): PINNED.  Checked bit-for-bit (indices and d2 bit patterns)
+ *     against the reference's vendored nanoflann compiled from /root/reference (oracle/_ref, see
+ *     oracle/Makefile) and against the committed fixtures tests/golden/knn_*.npz.
+ *   - 3-D nearest neighbour (oracle_nn3_*): PINNED against the vendored nanoflann instantiated for
+ *     3-D points with L2_Simple_Adaptor (same harness).
+ *   - RANSAC-SVD and ICP (oracle_reg_*): PARITY UNPINNED.  The reference delegates this arithmetic
+ *     to PCL / OpenCV (absent from /root/reference, versions unpinned; call sites
+ *     registration/global_registration.cpp:237-248, registration/loop_detector.cpp:256-257) and
+ *     holds no test or fixture for it.  The semantics are those of SURVEY.md Appendix B; known-answer
+ *     tests use synthetic scan pairs with a constructed SE(3).
+ *
+ * All fp32 arithmetic here is compiled with -ffp-contract=off (see Makefile): the reference builds
+ * Release/C++14 with no arch flags (registration/CMakeLists.txt:5-7), i.e. no FMA contraction.
+ */
+#ifndef GLOC_ORACLE_H
+#define GLOC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- descriptor kNN ------------------------------------------------------------------------ */
+
+/* Squared L2 in the reference's accumulation order: groups of four, sequential over d, scalar
+ * tail.  Follows registration/nanoflann.hpp:453-487 (L2_Adaptor::evalMetric, worst_dist = -1). */
+float oracle_l2_eval(const float* a, const float* b, size_t dim);
+
+/* Exact top-k by exhaustive scan of rows [first_row, last_row) in index order, with the
+ * reference's result-set semantics (registration/nanoflann.hpp:200-235: sorted insertion, strict
+ * '>' so equal distances keep arrival order = ascending index here).  Mirrors
+ * KDTreeVectorOfVectorsAdaptor::query (registration/KDTreeVectorOfVectorsAdaptor.h:95-102) as
+ * called from registration/loop_detector.cpp:42-45 and :75-79.
+ * Unused slots (fewer than k rows) keep idx = UINT64_MAX, d2 = FLT_MAX. */
+void oracle_knn_search(const float* db, size_t n_rows, size_t dim, const float* queries, size_t nq,
+                       size_t k, size_t first_row, size_t last_row, uint64_t* out_idx,
+                       float* out_d2);
+
+/* Same, threaded over queries (cpu_baseline "all cores" leg). */
+void oracle_knn_search_mt(const float* db, size_t n_rows, size_t dim, const float* queries,
+                          size_t nq, size_t k, size_t first_row, size_t last_row,
+                          uint64_t* out_idx, float* out_d2, int n_threads);
+
+/* recall@{1,5,10,20}: first-hit semantics of registration/global_localization.cpp:221-268 and
+ * main.py:336-348.  pos_off has nq+1 entries (CSR).  Queries with no positives are skipped
+ * (global_localization.cpp:226).  Returns the number of valid queries. */
+size_t oracle_recall_at(const uint64_t* idx, size_t nq, size_t k, const uint64_t* pos,
+                        const size_t* pos_off, const int* k_values, size_t n_k, float* recalls);
+
+/* ---- 3-D registration ---------------------------------------------------------------------- */
+
+typedef struct oracle_reg_params {
+  uint32_t ransac_iters;    /* 3000: registration/loop_detector.cpp:257 */
+  float inlier_thresh;      /* 0.6 m = 3 * 0.2 m: loop_detector.cpp:257, loop_detector.h:116 */
+  float min_inlier_ratio;   /* ok iff inliers >= ratio * n_src (dense analogue of >=5 matches) */
+  uint32_t icp_iters;       /* 30: registration/global_registration.cpp:242 */
+  float max_corr_dist;      /* <=0: no rejection (PCL default) */
+  uint64_t seed;
+} oracle_reg_params;
+
+/* p' = R p + t in fp32, fixed order ((r0*x + r1*y) + r2*z) + t, no contraction. */
+void oracle_transform_points(const float* T16, const float* xyz, size_t n, float* out_xyz);
+
+/* Exact 1-NN by exhaustive scan: d2 = ((dx*dx) + dy*dy) + dz*dz (nanoflann L2_Simple order,
+ * registration/nanoflann.hpp:504-515), tie -> smallest target index. */
+void oracle_nn3(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                uint32_t* out_idx, float* out_d2);
+
+/* Same result via a uniform grid (used for full-size scans where the exhaustive scan takes
+ * minutes); validated against oracle_nn3 and the nanoflann 3-D harness in tests. */
+void oracle_nn3_grid(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                     uint32_t* out_idx, float* out_d2);
+
+/* Kabsch / Umeyama without scale from a 3x3 cross-covariance M = sum (p-pbar)(q-qbar)^T (fp64),
+ * R = V diag(1,1,det(V U^T)) U^T.  SVD by cyclic Jacobi on M^T M (only + - * / sqrt). */
+void oracle_kabsch_from_cov(const double M[9], const double pbar[3], const double qbar[3],
+                            double R[9], double t[3]);
+
+/* The counter RNG's k-th sample triple for (seed, candidate, hypothesis). */
+void oracle_ransac_sample(uint64_t seed, uint32_t cand, uint32_t hyp, uint32_t n, uint32_t out[3]);
+
+/* One hypothesis: returns 0 if the sample is degenerate (near-collinear), else fills R,t (fp32
+ * row-major 3x3 + 3). */
+int oracle_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint32_t* corr,
+                             uint32_t n, uint64_t seed, uint32_t cand, uint32_t hyp, float R[9],
+                             float t[3]);
+
+/* Inlier count of (R,t) over correspondences: ||R p + t - q|| < thr, compared as d2 < thr*thr. */
+uint32_t oracle_count_inliers(const float* src_xyz, const float* tgt_xyz, const uint32_t* corr,
+                              uint32_t n, const float R[9], const float t[3], float thr);
+
+/* Full per-candidate registration.  init_T may be NULL (identity).
+ * Outputs: T (row-major 4x4 f32, query->db), rmse, best inlier count, best hypothesis, ok. */
+void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                    const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                    float* out_T, float* out_rmse, uint32_t* out_inliers, uint32_t* out_best_hyp,
+                    int* out_ok);
+
+/* Accuracy metric of registration/global_localization.cpp:288-306 (err_rot in degrees with the
+ * 180-degree forgiveness, err_pos in metres). */
+void oracle_pose_error(const float* T_gt16, const float* T_est16, float* err_rot_deg,
+                       float* err_pos);
+
+/* ---- deterministic synthetic inputs (shared definition with gloc3d_amd/synth.py) ----------- */
+uint64_t oracle_rng_key(uint64_t seed, uint64_t stream);
+uint64_t oracle_rng_draw(uint64_t key, uint64_t ctr);
+float oracle_rng_gauss(uint64_t key, uint64_t ctr);
+void oracle_synth_iid(uint64_t seed, size_t first_row, size_t n_rows, size_t dim, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

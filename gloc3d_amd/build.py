@@ -1,0 +1,80 @@
+"""In-tree build of the HIP extension: gloc3d_amd/lib/libgloc3d.so (gfx950 only).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the GPU
+box with the snapshot.  `python -m gloc3d_amd.build` or `gloc3d_amd.build.build()`.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgloc3d.so")
+SOURCES = ["common.hip", "knn.hip", "reg.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the exact kernels must reproduce the reference's un-fused fp32 arithmetic
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(HERE, "..", "include", "gloc3d.h"))
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def build_cli(force=False, verbose=False):
+    """The drop-in command lines (registration/global_localization, global_registration)."""
+    build(force=force, verbose=verbose)
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    outs = []
+    for name in ("global_localization", "global_registration"):
+        src = os.path.join(CSRC, "cli", name + ".cpp")
+        if not os.path.exists(src):
+            continue
+        out = os.path.join(bindir, name)
+        deps = [src, LIB] + [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+        if force or _stale(out, deps):
+            cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "include"),
+                   "-I" + os.path.join(CSRC, "host"), src, "-o", out, "-L" + LIBDIR, "-lgloc3d",
+                   "-Wl,-rpath,$ORIGIN/../lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    build_cli(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,329 @@
+"""ctypes binding of the C ABI in include/gloc3d.h (gloc3d_amd/lib/libgloc3d.so).
+
+This is the same binding a reference-side maintainer would write.  It fails loudly
+when the HIP extension is missing or no gfx950 device is usable: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgloc3d.so")
+
+GLOC_OK = 0
+ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "GLOC_ERR_NODEVICE",
+             5: "GLOC_ERR_STATE"}
+ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
+KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
+REG_OPT_PROFILE = 1
+SIZE_MAX = C.c_size_t(-1).value
+
+
+class GlocError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class KnnStats(C.Structure):
+    _fields_ = [("searches_exact", C.c_uint64), ("searches_mfma", C.c_uint64),
+                ("queries_total", C.c_uint64), ("queries_fallback", C.c_uint64),
+                ("last_n_tile", C.c_uint32), ("last_k_split", C.c_uint32),
+                ("last_candidates", C.c_uint32)]
+
+
+class RegParams(C.Structure):
+    _fields_ = [("ransac_iters", C.c_uint32), ("inlier_thresh", C.c_float),
+                ("min_inlier_ratio", C.c_float), ("icp_iters", C.c_uint32),
+                ("max_corr_dist", C.c_float), ("seed", C.c_uint64)]
+
+
+# every symbol include/gloc3d.h declares: (name, restype, argtypes)
+_vp, _sz, _u64, _i, _u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32
+_PROTOS = [
+    ("gloc_last_error", C.c_char_p, []),
+    ("gloc_abi_version", _i, []),
+    ("gloc_device_count", _i, []),
+    ("gloc_knn_create", _i, [_i, _sz, C.POINTER(_vp)]),
+    ("gloc_knn_destroy", _i, [_vp]),
+    ("gloc_knn_set_stream", _i, [_vp, _vp]),
+    ("gloc_knn_synchronize", _i, [_vp]),
+    ("gloc_knn_set_option", _i, [_vp, _i, C.c_int64]),
+    ("gloc_knn_add", _i, [_vp, _vp, _sz]),
+    ("gloc_knn_add_device", _i, [_vp, _vp, _sz]),
+    ("gloc_knn_reserve", _i, [_vp, _sz]),
+    ("gloc_knn_clear", _i, [_vp]),
+    ("gloc_knn_size", _i, [_vp, C.POINTER(_sz)]),
+    ("gloc_knn_dim", _i, [_vp, C.POINTER(_sz)]),
+    ("gloc_knn_device_rows", _i, [_vp, C.POINTER(_vp)]),
+    ("gloc_knn_search", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    ("gloc_knn_search_device", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _u64, _vp, _vp]),
+    ("gloc_topk_merge_device", _i, [_i, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    ("gloc_knn_get_stats", _i, [_vp, C.POINTER(KnnStats)]),
+    ("gloc_knn_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("gloc_knn_profile_reset", _i, [_vp]),
+    ("gloc_reg_default_params", None, [C.POINTER(RegParams)]),
+    ("gloc_reg_create", _i, [_i, C.POINTER(_vp)]),
+    ("gloc_reg_destroy", _i, [_vp]),
+    ("gloc_reg_set_stream", _i, [_vp, _vp]),
+    ("gloc_reg_synchronize", _i, [_vp]),
+    ("gloc_reg_set_option", _i, [_vp, _i, C.c_int64]),
+    ("gloc_reg_scan_upload", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
+    ("gloc_reg_scan_count", _i, [_vp, C.POINTER(_sz)]),
+    ("gloc_reg_scan_clear", _i, [_vp]),
+    ("gloc_reg_batch", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp,
+                            C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
+    ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
+    ("gloc_reg_select_first_ok", _i, [_vp, _sz]),
+    ("gloc_reg_nn", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    ("gloc_reg_ransac_hypotheses", _i, [_vp, _vp, _vp, _vp, _sz, _u64, _u32, _u32, _vp, _vp, _vp,
+                                        C.c_float]),
+    ("gloc_reg_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("gloc_reg_profile_reset", _i, [_vp]),
+    ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz]),
+    ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _vp]),
+]
+EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
+
+_lib = None
+
+
+def lib():
+    """Load libgloc3d.so (no compute; safe without a GPU).  Raises if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m gloc3d_amd.build or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _PROTOS:
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != GLOC_OK:
+        raise GlocError(rc, lib().gloc_last_error().decode("utf-8", "replace"))
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class KnnIndex:
+    """Resident descriptor database + exact L2 top-k (the reference's InvKeyTree / IndexFlatL2)."""
+
+    def __init__(self, dim, device=0):
+        self._h = C.c_void_p()
+        self.dim = int(dim)
+        self.device = device
+        check(lib().gloc_knn_create(device, self.dim, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_knn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_size_t()
+        check(lib().gloc_knn_size(self._h, C.byref(n)))
+        return n.value
+
+    def set_option(self, option, value):
+        check(lib().gloc_knn_set_option(self._h, option, int(value)))
+
+    def set_stream(self, hip_stream):
+        check(lib().gloc_knn_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        check(lib().gloc_knn_synchronize(self._h))
+
+    def reserve(self, n):
+        check(lib().gloc_knn_reserve(self._h, n))
+
+    def clear(self):
+        check(lib().gloc_knn_clear(self._h))
+
+    def add(self, rows):
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, self.dim)
+        check(lib().gloc_knn_add(self._h, _np_ptr(rows), rows.shape[0]))
+
+    def add_device(self, dev_ptr, n):
+        check(lib().gloc_knn_add_device(self._h, C.c_void_p(dev_ptr), n))
+
+    def add_synthetic(self, kind, seed, first_row, n):
+        check(lib().gloc_knn_add_synthetic(self._h, kind, seed, first_row, n))
+
+    def device_rows(self):
+        p = C.c_void_p()
+        check(lib().gloc_knn_device_rows(self._h, C.byref(p)))
+        return p.value
+
+    def search(self, queries, k, first_row=0, last_row=None):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        idx = np.empty((nq, k), np.uint64)
+        d2 = np.empty((nq, k), np.float32)
+        last = SIZE_MAX if last_row is None else last_row
+        check(lib().gloc_knn_search(self._h, _np_ptr(q), nq, k, first_row, last, _np_ptr(idx),
+                                    _np_ptr(d2)))
+        return idx, d2
+
+    def search_device(self, q_ptr, nq, k, idx_ptr, d2_ptr, first_row=0, last_row=None,
+                      index_offset=0):
+        last = SIZE_MAX if last_row is None else last_row
+        check(lib().gloc_knn_search_device(self._h, C.c_void_p(q_ptr), nq, k, first_row, last,
+                                           index_offset, C.c_void_p(idx_ptr), C.c_void_p(d2_ptr)))
+
+    def stats(self):
+        s = KnnStats()
+        check(lib().gloc_knn_get_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in KnnStats._fields_}
+
+    def profile(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gloc_knn_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        check(lib().gloc_knn_profile_reset(self._h))
+
+
+def topk_merge_device(device, stream, idx_ptr, d2_ptr, n_lists, nq, k, out_idx_ptr, out_d2_ptr):
+    check(lib().gloc_topk_merge_device(device, C.c_void_p(stream or 0), C.c_void_p(idx_ptr),
+                                       C.c_void_p(d2_ptr), n_lists, nq, k,
+                                       C.c_void_p(out_idx_ptr), C.c_void_p(out_d2_ptr)))
+
+
+def synth_fill_device(device, stream, kind, seed, first_row, n, dim, out_ptr):
+    check(lib().gloc_synth_fill_device(device, C.c_void_p(stream or 0), kind, seed, first_row, n,
+                                       dim, C.c_void_p(out_ptr)))
+
+
+def default_reg_params(**over):
+    p = RegParams()
+    lib().gloc_reg_default_params(C.byref(p))
+    for k_, v in over.items():
+        setattr(p, k_, v)
+    return p
+
+
+class Registrar:
+    """Batched candidate registration (RANSAC-SVD + ICP) with a resident scan store."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self.device = device
+        check(lib().gloc_reg_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_reg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        check(lib().gloc_reg_set_option(self._h, option, int(value)))
+
+    def set_stream(self, hip_stream):
+        check(lib().gloc_reg_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        check(lib().gloc_reg_synchronize(self._h))
+
+    def scan_upload(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        assert pts.ndim == 2 and pts.shape[1] in (3, 4)
+        sid = C.c_uint32()
+        check(lib().gloc_reg_scan_upload(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1],
+                                         C.byref(sid)))
+        return sid.value
+
+    def scan_count(self):
+        n = C.c_size_t()
+        check(lib().gloc_reg_scan_count(self._h, C.byref(n)))
+        return n.value
+
+    def scan_clear(self):
+        check(lib().gloc_reg_scan_clear(self._h))
+
+    @staticmethod
+    def _outs(n):
+        return (np.empty((n, 4, 4), np.float32), np.empty(n, np.float32), np.empty(n, np.uint32),
+                np.empty(n, np.int32))
+
+    def batch(self, q_xyz, cands, init_T=None, params=None):
+        q = np.ascontiguousarray(q_xyz, np.float32).reshape(-1, 3)
+        cs = [np.ascontiguousarray(c, np.float32).reshape(-1, 3) for c in cands]
+        n = len(cs)
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in cs])
+        cnts = (C.c_size_t * n)(*[c.shape[0] for c in cs])
+        prm = params or default_reg_params()
+        it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(n, 16)
+        T, rmse, inl, ok = self._outs(n)
+        check(lib().gloc_reg_batch(self._h, _np_ptr(q), q.shape[0], ptrs, cnts, n,
+                                   None if it is None else _np_ptr(it), C.byref(prm), _np_ptr(T),
+                                   _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
+        return dict(T=T, rmse=rmse, inliers=inl, ok=ok.astype(bool))
+
+    def batch_ids(self, q_id, cand_ids, init_T=None, params=None):
+        ids = np.ascontiguousarray(cand_ids, np.uint32)
+        n = ids.shape[0]
+        prm = params or default_reg_params()
+        it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(n, 16)
+        T, rmse, inl, ok = self._outs(n)
+        check(lib().gloc_reg_batch_ids(self._h, int(q_id), _np_ptr(ids), n,
+                                       None if it is None else _np_ptr(it), C.byref(prm),
+                                       _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
+        return dict(T=T, rmse=rmse, inliers=inl, ok=ok.astype(bool))
+
+    def nn(self, src, tgt, T=None):
+        s = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
+        idx = np.empty(s.shape[0], np.uint32)
+        d2 = np.empty(s.shape[0], np.float32)
+        Tp = None if T is None else np.ascontiguousarray(T, np.float32).reshape(16)
+        check(lib().gloc_reg_nn(self._h, _np_ptr(s), s.shape[0], _np_ptr(t), t.shape[0],
+                                None if Tp is None else _np_ptr(Tp), _np_ptr(idx), _np_ptr(d2)))
+        return idx, d2
+
+    def ransac_hypotheses(self, src, tgt, corr, seed, cand, n_hyp, inlier_thresh):
+        s = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
+        c = np.ascontiguousarray(corr, np.uint32)
+        Rt = np.empty((n_hyp, 12), np.float32)
+        valid = np.empty(n_hyp, np.uint32)
+        inl = np.empty(n_hyp, np.uint32)
+        check(lib().gloc_reg_ransac_hypotheses(self._h, _np_ptr(s), _np_ptr(t), _np_ptr(c),
+                                               s.shape[0], seed, cand, n_hyp, _np_ptr(Rt),
+                                               _np_ptr(valid), _np_ptr(inl), inlier_thresh))
+        return Rt, valid, inl
+
+    def profile(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gloc_reg_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        check(lib().gloc_reg_profile_reset(self._h))
+
+
+def reg_select_first_ok(ok):
+    a = np.ascontiguousarray(ok, np.int32)
+    return lib().gloc_reg_select_first_ok(_np_ptr(a), a.shape[0])

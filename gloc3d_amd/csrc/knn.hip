@@ -1,0 +1,502 @@
+// knn.hip -- C ABI of the descriptor kNN (include/gloc3d.h) over the kernels in knn_kernels.hpp.
+// Replaces registration/loop_detector.cpp:34-45,66-79 (KD-tree build + query) and
+// main.py:317-324 (faiss.IndexFlatL2 add/search) of the reference.
+#include <algorithm>
+#include <cfloat>
+#include <new>
+
+#include "common.hpp"
+#include "knn_kernels.hpp"
+#include "synth_kernels.hpp"
+
+using namespace gloc;
+using namespace gloc::knn;
+
+struct gloc_knn {
+  int device = 0;
+  size_t dim = 0;
+  size_t n = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  DevBuf rows;      // n x dim fp32, row-major, dense
+  DevBuf norms;     // n fp32 (coarse form only)
+  DevBuf dn_max;    // 1 x uint32 (bits of the largest row norm)
+  DevBuf dist;      // exact: [nq][ld]; mfma: [splits][Qpad][ld]
+  DevBuf keys;      // select output [nq][K]
+  DevBuf keys2;     // rerank output [nq][k]
+  DevBuf qnorm;     // [nq]
+  DevBuf flags;     // [nq] int
+  DevBuf stage_q;   // host-API staging: queries
+  DevBuf stage_idx, stage_d2;
+  int* h_flags = nullptr;  // pinned
+  size_t h_flags_cap = 0;
+  int algo = GLOC_KNN_ALGO_AUTO;
+  int candidates = 32;
+  Profiler prof;
+  gloc_knn_stats stats{};
+};
+
+namespace {
+
+int ensure_rows(gloc_knn* h, size_t n_rows) {
+  GLOC_TRY(h->rows.ensure(n_rows * h->dim * sizeof(float), h->stream, true,
+                          h->n * h->dim * sizeof(float)));
+  GLOC_TRY(h->norms.ensure(n_rows * sizeof(float), h->stream, true, h->n * sizeof(float)));
+  if (!h->dn_max.p) {
+    GLOC_TRY(h->dn_max.ensure(sizeof(uint32_t), h->stream));
+    GLOC_HIP(hipMemsetAsync(h->dn_max.p, 0, sizeof(uint32_t), h->stream));
+  }
+  return GLOC_OK;
+}
+
+int update_norms(gloc_knn* h, size_t first, size_t count) {
+  if (!count) return GLOC_OK;
+  ProfScope ps(h->prof, "norms", h->stream);
+  const unsigned blocks = (unsigned)((count + 3) / 4);
+  hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                     h->rows.as<float>() + first * h->dim, count, (int)h->dim,
+                     h->norms.as<float>() + first, h->dn_max.as<uint32_t>());
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+// ---- exact path ------------------------------------------------------------------------------
+int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n_range,
+                      size_t ld) {
+  ProfScope ps(h->prof, "dist_exact", h->stream);
+  const int QT = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  const int qgroups = (nq + QT - 1) / QT;
+  // rows per wave: fill the chip with >= ~2048 waves when the window is small, up to 64/QT
+  int RW = 64 / QT;
+  while (RW > 4 && (long long)((n_range + RW - 1) / RW) * qgroups < 2048) RW >>= 1;
+  if (RW < 4) RW = 4;
+  const unsigned gx = (unsigned)((n_range + 4 * RW - 1) / (4 * RW));
+  dim3 grid(gx, (unsigned)qgroups), block(256);
+  float* dist = h->dist.as<float>();
+  const float* db = h->rows.as<float>();
+#define LAUNCH_EXACT(QT_)                                                                      \
+  hipLaunchKernelGGL(dist_exact_kernel<QT_>, grid, block, 0, h->stream, db, d_q, dist,         \
+                     (int)h->dim, first, n_range, nq, RW, ld)
+  switch (QT) {
+    case 8: LAUNCH_EXACT(8); break;
+    case 4: LAUNCH_EXACT(4); break;
+    case 2: LAUNCH_EXACT(2); break;
+    default: LAUNCH_EXACT(1); break;
+  }
+#undef LAUNCH_EXACT
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
+              uint64_t* d_keys_out) {
+  const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
+  GLOC_TRY(h->dist.ensure((size_t)nq * ld * sizeof(float), h->stream));
+  GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld));
+  {
+    ProfScope ps(h->prof, "select", h->stream);
+    hipLaunchKernelGGL(select_kernel<0>, dim3(nq), dim3(256), 0, h->stream, h->dist.as<float>(),
+                       ld, (size_t)0, 1, (const float*)nullptr, (const float*)nullptr, first,
+                       n_range, k, d_keys_out);
+    GLOC_HIP(hipGetLastError());
+  }
+  return GLOC_OK;
+}
+
+// ---- MFMA path -------------------------------------------------------------------------------
+struct MfmaPlan {
+  int WQ, NT, KS, BQ, BN;
+};
+
+MfmaPlan plan_mfma(int nq, int n_range, int dim) {
+  MfmaPlan best{};
+  double best_cost = 1e300;
+  const int WQ = nq <= 16 ? 1 : (nq <= 32 ? 2 : 4);
+  static const int NT4[] = {2, 3, 4, 5, 6, 8}, NT2[] = {2, 4}, NT1[] = {1, 2};
+  const int* nts = WQ == 4 ? NT4 : (WQ == 2 ? NT2 : NT1);
+  const int n_nts = WQ == 4 ? 6 : 2;
+  const int BQ = 16 * WQ;
+  const int qblocks = (nq + BQ - 1) / BQ;
+  for (int i = 0; i < n_nts; ++i) {
+    const int NT = nts[i], BN = 16 * NT * (4 / WQ);
+    const long long ntiles = (n_range + BN - 1) / BN;
+    for (int KS = 1; KS <= 16; KS <<= 1) {
+      if ((dim % (32 * KS)) != 0 && KS > 1) continue;
+      const int klen = (dim + KS - 1) / KS;
+      if (klen < 128 && KS > 1) continue;
+      const long long wgs = ntiles * qblocks * KS;
+      const long long rounds = (wgs + 255) / 256;
+      // per-WG time ~ klen * (MFMA issue for BN rows + staging of BQ+BN rows); + split overhead
+      const double per_wg = (double)klen * ((double)BN * 1.0 + (double)(BQ + BN) * 0.35);
+      const double cost = (double)rounds * per_wg + 4000.0 * KS + (wgs < 128 ? 1e5 : 0);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = MfmaPlan{WQ, NT, KS, BQ, BN};
+      }
+    }
+  }
+  return best;
+}
+
+template <int WQ, int NT>
+void launch_mfma_inst(gloc_knn* h, const MfmaPlan& p, const float* d_q, int nq, size_t first,
+                      int n_range, size_t ld, size_t strideP) {
+  dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ),
+            (unsigned)p.KS);
+  const int kps = (((int)h->dim + p.KS - 1) / p.KS + 31) & ~31;
+  hipLaunchKernelGGL((dist_mfma_kernel<WQ, NT>), grid, dim3(256), 0, h->stream,
+                     h->rows.as<float>(), d_q, h->dist.as<float>(), (int)h->dim, first, n_range,
+                     nq, kps, ld, strideP);
+}
+
+int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
+             uint64_t* d_keys_out) {
+  const MfmaPlan p = plan_mfma(nq, n_range, (int)h->dim);
+  const int KC = std::max(h->candidates, std::min(64, k + 12));
+  const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
+  const size_t qpad = (size_t)((nq + p.BQ - 1) / p.BQ) * p.BQ;
+  const size_t strideP = qpad * ld;
+  GLOC_TRY(h->dist.ensure((size_t)p.KS * strideP * sizeof(float), h->stream));
+  GLOC_TRY(h->qnorm.ensure((size_t)nq * sizeof(float), h->stream));
+  GLOC_TRY(h->keys.ensure((size_t)nq * KC * sizeof(uint64_t), h->stream));
+  GLOC_TRY(h->flags.ensure((size_t)nq * sizeof(int), h->stream));
+  {
+    ProfScope ps(h->prof, "norms", h->stream);
+    hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 3) / 4), dim3(256), 0, h->stream, d_q,
+                       (size_t)nq, (int)h->dim, h->qnorm.as<float>(), (uint32_t*)nullptr);
+    GLOC_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps(h->prof, "dist_mfma", h->stream);
+#define MF(WQ_, NT_)                                                        \
+  if (p.WQ == WQ_ && p.NT == NT_) {                                         \
+    launch_mfma_inst<WQ_, NT_>(h, p, d_q, nq, first, n_range, ld, strideP); \
+  } else
+    MF(4, 2) MF(4, 3) MF(4, 4) MF(4, 5) MF(4, 6) MF(4, 8) MF(2, 2) MF(2, 4) MF(1, 1) MF(1, 2) {
+      set_err("internal: no MFMA instance for WQ=%d NT=%d", p.WQ, p.NT);
+      return GLOC_ERR_STATE;
+    }
+#undef MF
+    GLOC_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps(h->prof, "select", h->stream);
+    hipLaunchKernelGGL(select_kernel<1>, dim3(nq), dim3(256), 0, h->stream, h->dist.as<float>(),
+                       ld, strideP, p.KS, h->qnorm.as<float>(), h->norms.as<float>(), first,
+                       n_range, KC, h->keys.as<uint64_t>());
+    GLOC_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps(h->prof, "rerank", h->stream);
+    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(64), 0, h->stream, h->rows.as<float>(), d_q,
+                       (int)h->dim, h->keys.as<uint64_t>(), KC, k, n_range,
+                       h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), d_keys_out,
+                       h->flags.as<int>());
+    GLOC_HIP(hipGetLastError());
+  }
+  h->stats.last_n_tile = (uint32_t)p.BN;
+  h->stats.last_k_split = (uint32_t)p.KS;
+  h->stats.last_candidates = (uint32_t)KC;
+  // completeness flags -> host; incomplete queries are redone on the exact path
+  if (h->h_flags_cap < (size_t)nq) {
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
+    h->h_flags = nullptr;
+    GLOC_HIP(hipHostMalloc((void**)&h->h_flags, sizeof(int) * (size_t)nq * 2));
+    h->h_flags_cap = (size_t)nq * 2;
+  }
+  GLOC_HIP(hipMemcpyAsync(h->h_flags, h->flags.p, sizeof(int) * (size_t)nq,
+                          hipMemcpyDeviceToHost, h->stream));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  for (int q = 0; q < nq; ++q) {
+    if (h->h_flags[q]) {
+      h->stats.queries_fallback++;
+      GLOC_TRY(run_exact(h, d_q + (size_t)q * h->dim, 1, k, first, n_range,
+                         d_keys_out + (size_t)q * k));
+    }
+  }
+  return GLOC_OK;
+}
+
+int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_t first_row,
+                       size_t last_row, uint64_t index_offset, uint64_t* d_idx, float* d_d2) {
+  GLOC_REQUIRE(h && d_q && d_idx && d_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(k >= 1 && k <= 256, GLOC_ERR_INVALID, "k = %zu outside [1,256]", k);
+  GLOC_REQUIRE(nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "nq = %zu outside [1,2^20]", nq);
+  GLOC_HIP(hipSetDevice(h->device));
+  if (last_row > h->n) last_row = h->n;
+  if (first_row > last_row) first_row = last_row;
+  const size_t range = last_row - first_row;
+  GLOC_REQUIRE(range < (1ull << 31), GLOC_ERR_INVALID, "row window too large");
+  GLOC_TRY(h->keys2.ensure(nq * k * sizeof(uint64_t), h->stream));
+  uint64_t* keys_out = h->keys2.as<uint64_t>();
+  if (range == 0) {
+    GLOC_HIP(hipMemsetAsync(keys_out, 0xFF, nq * k * sizeof(uint64_t), h->stream));
+  } else {
+    int algo = h->algo;
+    const bool mfma_ok = (h->dim % 4 == 0) && k <= 52 && range >= 64;
+    if (algo == GLOC_KNN_ALGO_AUTO) algo = (nq > 8 && mfma_ok) ? GLOC_KNN_ALGO_MFMA : GLOC_KNN_ALGO_EXACT;
+    if (algo == GLOC_KNN_ALGO_MFMA && !mfma_ok) algo = GLOC_KNN_ALGO_EXACT;
+    // process queries in blocks that bound the distance workspace (<= 2 GiB)
+    const size_t ld = (range + 63) & ~(size_t)63;
+    size_t qblk = (size_t)(2ull << 30) / (ld * sizeof(float) * 4);
+    qblk = std::min<size_t>(1024, std::max<size_t>(64, qblk / 64 * 64));
+    for (size_t q0 = 0; q0 < nq; q0 += qblk) {
+      const int cnt = (int)std::min(qblk, nq - q0);
+      if (algo == GLOC_KNN_ALGO_MFMA) {
+        h->stats.searches_mfma++;
+        GLOC_TRY(run_mfma(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range,
+                          keys_out + q0 * k));
+      } else {
+        h->stats.searches_exact++;
+        GLOC_TRY(run_exact(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range,
+                           keys_out + q0 * k));
+      }
+    }
+  }
+  h->stats.queries_total += nq;
+  {
+    ProfScope ps(h->prof, "finalize", h->stream);
+    const size_t total = nq * k;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       h->stream, keys_out, total, index_offset, d_idx, d_d2);
+    GLOC_HIP(hipGetLastError());
+  }
+  return GLOC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gloc_knn_create(int device, size_t dim, gloc_knn** out) {
+  GLOC_REQUIRE(out, GLOC_ERR_INVALID, "out is null");
+  *out = nullptr;
+  GLOC_REQUIRE(dim >= 1 && dim <= (1u << 20), GLOC_ERR_INVALID, "dim = %zu outside [1,2^20]", dim);
+  GLOC_TRY(select_device(device));
+  gloc_knn* h = new (std::nothrow) gloc_knn;
+  GLOC_REQUIRE(h, GLOC_ERR_NOMEM, "host allocation failed");
+  h->device = device;
+  h->dim = dim;
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete h;
+    return GLOC_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return GLOC_OK;
+}
+
+int gloc_knn_destroy(gloc_knn* h) {
+  if (!h) return GLOC_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->prof.destroy();
+  h->rows.release();
+  h->norms.release();
+  h->dn_max.release();
+  h->dist.release();
+  h->keys.release();
+  h->keys2.release();
+  h->qnorm.release();
+  h->flags.release();
+  h->stage_q.release();
+  h->stage_idx.release();
+  h->stage_d2.release();
+  if (h->h_flags) (void)hipHostFree(h->h_flags);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return GLOC_OK;
+}
+
+int gloc_knn_set_stream(gloc_knn* h, void* hip_stream) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return GLOC_OK;
+}
+
+int gloc_knn_synchronize(gloc_knn* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  return GLOC_OK;
+}
+
+int gloc_knn_set_option(gloc_knn* h, int option, int64_t value) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  switch (option) {
+    case GLOC_KNN_OPT_ALGO:
+      GLOC_REQUIRE(value >= 0 && value <= 2, GLOC_ERR_INVALID, "bad algorithm %lld", (long long)value);
+      h->algo = (int)value;
+      return GLOC_OK;
+    case GLOC_KNN_OPT_CANDIDATES:
+      GLOC_REQUIRE(value >= 1 && value <= 64, GLOC_ERR_INVALID, "candidates %lld outside [1,64]",
+                   (long long)value);
+      h->candidates = (int)value;
+      return GLOC_OK;
+    case GLOC_KNN_OPT_PROFILE:
+      h->prof.enabled = value != 0;
+      return GLOC_OK;
+    default:
+      set_err("unknown option %d", option);
+      return GLOC_ERR_INVALID;
+  }
+}
+
+int gloc_knn_reserve(gloc_knn* h, size_t n_rows) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  return ensure_rows(h, n_rows);
+}
+
+int gloc_knn_add(gloc_knn* h, const float* rows, size_t n) {
+  GLOC_REQUIRE(h && (rows || n == 0), GLOC_ERR_INVALID, "null argument");
+  if (n == 0) return GLOC_OK;
+  GLOC_REQUIRE(h->n + n < (1ull << 32) - 1, GLOC_ERR_INVALID, "database limited to 2^32-2 rows");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(ensure_rows(h, h->n + n));
+  GLOC_HIP(hipMemcpyAsync(h->rows.as<float>() + h->n * h->dim, rows, n * h->dim * sizeof(float),
+                          hipMemcpyHostToDevice, h->stream));
+  GLOC_TRY(update_norms(h, h->n, n));
+  GLOC_HIP(hipStreamSynchronize(h->stream));  // the caller may free `rows` on return
+  h->n += n;
+  return GLOC_OK;
+}
+
+int gloc_knn_add_device(gloc_knn* h, const float* d_rows, size_t n) {
+  GLOC_REQUIRE(h && (d_rows || n == 0), GLOC_ERR_INVALID, "null argument");
+  if (n == 0) return GLOC_OK;
+  GLOC_REQUIRE(h->n + n < (1ull << 32) - 1, GLOC_ERR_INVALID, "database limited to 2^32-2 rows");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(ensure_rows(h, h->n + n));
+  GLOC_HIP(hipMemcpyAsync(h->rows.as<float>() + h->n * h->dim, d_rows,
+                          n * h->dim * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  GLOC_TRY(update_norms(h, h->n, n));
+  h->n += n;
+  return GLOC_OK;
+}
+
+int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_REQUIRE(kind == 0 || kind == 1, GLOC_ERR_INVALID, "kind must be 0 (iid) or 1 (trajectory)");
+  if (n == 0) return GLOC_OK;
+  GLOC_REQUIRE(h->n + n < (1ull << 32) - 1, GLOC_ERR_INVALID, "database limited to 2^32-2 rows");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(ensure_rows(h, h->n + n));
+  gloc::synth::launch_fill(h->stream, kind, seed, first_row, n, h->dim,
+                           h->rows.as<float>() + h->n * h->dim);
+  GLOC_HIP(hipGetLastError());
+  GLOC_TRY(update_norms(h, h->n, n));
+  h->n += n;
+  return GLOC_OK;
+}
+
+int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed,
+                           uint64_t first_row, size_t n, size_t dim, float* d_out) {
+  GLOC_REQUIRE(d_out || n == 0, GLOC_ERR_INVALID, "null output");
+  GLOC_REQUIRE(kind == 0 || kind == 1, GLOC_ERR_INVALID, "kind must be 0 (iid) or 1 (trajectory)");
+  GLOC_TRY(select_device(device));
+  if (n == 0) return GLOC_OK;
+  gloc::synth::launch_fill((hipStream_t)hip_stream, kind, seed, first_row, n, dim, d_out);
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+int gloc_knn_clear(gloc_knn* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->n = 0;
+  if (h->dn_max.p) GLOC_HIP(hipMemsetAsync(h->dn_max.p, 0, sizeof(uint32_t), h->stream));
+  return GLOC_OK;
+}
+
+int gloc_knn_size(const gloc_knn* h, size_t* n_rows) {
+  GLOC_REQUIRE(h && n_rows, GLOC_ERR_INVALID, "null argument");
+  *n_rows = h->n;
+  return GLOC_OK;
+}
+
+int gloc_knn_dim(const gloc_knn* h, size_t* dim) {
+  GLOC_REQUIRE(h && dim, GLOC_ERR_INVALID, "null argument");
+  *dim = h->dim;
+  return GLOC_OK;
+}
+
+int gloc_knn_device_rows(const gloc_knn* h, const float** d_rows) {
+  GLOC_REQUIRE(h && d_rows, GLOC_ERR_INVALID, "null argument");
+  *d_rows = h->rows.as<float>();
+  return GLOC_OK;
+}
+
+int gloc_knn_search_device(gloc_knn* h, const float* d_queries, size_t nq, size_t k,
+                           size_t first_row, size_t last_row, uint64_t index_offset,
+                           uint64_t* d_out_idx, float* d_out_d2) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  return search_device_impl(h, d_queries, nq, k, first_row, last_row, index_offset, d_out_idx,
+                            d_out_d2);
+}
+
+int gloc_knn_search(gloc_knn* h, const float* queries, size_t nq, size_t k, size_t first_row,
+                    size_t last_row, uint64_t* out_idx, float* out_d2) {
+  GLOC_REQUIRE(h && queries && out_idx && out_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(k >= 1 && k <= 256, GLOC_ERR_INVALID, "k = %zu outside [1,256]", k);
+  GLOC_REQUIRE(nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "nq = %zu outside [1,2^20]", nq);
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(h->stage_q.ensure(nq * h->dim * sizeof(float), h->stream));
+  GLOC_TRY(h->stage_idx.ensure(nq * k * sizeof(uint64_t), h->stream));
+  GLOC_TRY(h->stage_d2.ensure(nq * k * sizeof(float), h->stream));
+  GLOC_HIP(hipMemcpyAsync(h->stage_q.p, queries, nq * h->dim * sizeof(float),
+                          hipMemcpyHostToDevice, h->stream));
+  GLOC_TRY(search_device_impl(h, h->stage_q.as<float>(), nq, k, first_row, last_row, 0,
+                              h->stage_idx.as<uint64_t>(), h->stage_d2.as<float>()));
+  GLOC_HIP(hipMemcpyAsync(out_idx, h->stage_idx.p, nq * k * sizeof(uint64_t),
+                          hipMemcpyDeviceToHost, h->stream));
+  GLOC_HIP(hipMemcpyAsync(out_d2, h->stage_d2.p, nq * k * sizeof(float), hipMemcpyDeviceToHost,
+                          h->stream));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  return GLOC_OK;
+}
+
+int gloc_topk_merge_device(int device, void* hip_stream, const uint64_t* d_idx, const float* d_d2,
+                           size_t n_lists, size_t nq, size_t k, uint64_t* d_out_idx,
+                           float* d_out_d2) {
+  GLOC_REQUIRE(d_idx && d_d2 && d_out_idx && d_out_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_lists >= 1 && k >= 1 && n_lists * k <= 1024, GLOC_ERR_INVALID,
+               "n_lists * k = %zu outside [1,1024]", n_lists * k);
+  GLOC_REQUIRE(nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "nq outside [1,2^20]");
+  GLOC_TRY(select_device(device));
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(64), 0, (hipStream_t)hip_stream, d_idx,
+                     d_d2, (int)n_lists, (int)nq, (int)k, d_out_idx, d_out_d2);
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+int gloc_knn_get_stats(const gloc_knn* h, gloc_knn_stats* out) {
+  GLOC_REQUIRE(h && out, GLOC_ERR_INVALID, "null argument");
+  *out = h->stats;
+  return GLOC_OK;
+}
+
+int gloc_knn_profile(gloc_knn* h, const char* kernel, double* total_ms, uint64_t* launches) {
+  GLOC_REQUIRE(h && kernel, GLOC_ERR_INVALID, "null argument");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(h->prof.collect(h->stream));
+  auto it = h->prof.fam.find(kernel);
+  if (total_ms) *total_ms = it == h->prof.fam.end() ? 0.0 : it->second.total_ms;
+  if (launches) *launches = it == h->prof.fam.end() ? 0 : it->second.launches;
+  return GLOC_OK;
+}
+
+int gloc_knn_profile_reset(gloc_knn* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->prof.reset();
+  return GLOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,478 @@
+// knn_kernels.hpp -- device kernels of the descriptor kNN (gfx950).  Included only by knn.hip.
+//
+// Pipeline (kernels K1/K1b/K2/K3):
+//   exact path : dist_exact -> select(k)                          -> finalize
+//   MFMA  path : row_norms(q) -> dist_mfma -> select(k') -> rerank -> finalize   (+ exact fallback)
+//
+// Bit-exactness contract: every distance that reaches the caller is computed by exact_pairs_wave(),
+// which reproduces nanoflann's L2_Adaptor::evalMetric (registration/nanoflann.hpp:453-487) --
+// groups of four differences, ((d0^2 + d1^2) + d2^2) + d3^2, added sequentially over d, scalar tail,
+// no FMA contraction (this translation unit is compiled with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gloc {
+namespace knn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(4))) f4u {  // float4 with 4-byte alignment (rows start at any dword)
+  float x, y, z, w;
+};
+
+constexpr uint64_t KEY_SENTINEL = ~0ull;
+
+// order-preserving float -> uint32 (handles the small negative values the MFMA form can produce)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t idx) {
+  return ((uint64_t)f2ord(d) << 32) | (uint64_t)idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: squared row norms (any summation order: they only feed the coarse MFMA form) + running max.
+// One wave per row.
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ rows, size_t n,
+                                                        int dim, float* __restrict__ out,
+                                                        uint32_t* __restrict__ max_bits) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* r = rows + row * (size_t)dim;
+  float s = 0.f;
+  for (int d = lane; d < dim; d += 64) s += r[d] * r[d];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    out[row] = s;
+    if (max_bits) atomicMax(max_bits, __float_as_uint(s));  // s >= 0: uint order == float order
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference-order distances for up to 64 (query,row) pairs per wave.
+//   phase 1 (lane <-> group of 4 dims, coalesced 1-KiB row reads): s_g = ((d0^2+d1^2)+d2^2)+d3^2
+//   phase 2 (lane <-> pair): acc += s_g for g ascending -- the reference's sequential chain.
+// The group sums cross lanes through a per-wave LDS tile S[64 pairs][68].
+// Pair p = qt * RW + r  (qt < QT queries, r < RW rows).  Row r is row_of(r).
+constexpr int S_PITCH = 68;  // floats; 272 B rows keep ds_read_b128 aligned and conflict-free
+
+template <int QT, class RowOf>
+__device__ __forceinline__ float exact_pairs_wave(const float* __restrict__ db,
+                                                  const float* __restrict__ q /* QT rows */,
+                                                  int dim, int RW, RowOf row_of, int n_valid_q,
+                                                  float* __restrict__ S /* [64][S_PITCH] */) {
+  const int lane = threadIdx.x & 63;
+  const int G = dim >> 2;
+  const int P = QT * RW;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < G; c0 += 64) {
+    const int g = c0 + lane;
+    const bool gv = g < G;
+    f4u qv[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (gv && t < n_valid_q)
+        qv[t] = *reinterpret_cast<const f4u*>(q + (size_t)t * dim + 4 * g);
+      else
+        qv[t] = f4u{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r0 = 0; r0 < RW; r0 += 4) {
+      f4u dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        const long long row = (r < RW) ? row_of(r) : -1;
+        if (gv && row >= 0)
+          dv[u] = *reinterpret_cast<const f4u*>(db + (size_t)row * dim + 4 * g);
+        else
+          dv[u] = f4u{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        if (r < RW) {
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            const float e0 = qv[t].x - dv[u].x;
+            const float e1 = qv[t].y - dv[u].y;
+            const float e2 = qv[t].z - dv[u].z;
+            const float e3 = qv[t].w - dv[u].w;
+            const float s = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA
+            S[(t * RW + r) * S_PITCH + lane] = s;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ng = (G - c0) < 64 ? (G - c0) : 64;
+    if (lane < P) {
+      const float* sp = S + lane * S_PITCH;
+      int i = 0;
+      for (; i + 4 <= ng; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + i);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+      }
+      for (; i < ng; ++i) acc += sp[i];
+    }
+    __syncthreads();
+  }
+  // scalar tail, dims 4G..dim-1 (nanoflann.hpp:480-485)
+  if ((dim & 3) && lane < P) {
+    const int t = lane / RW, r = lane % RW;
+    const long long row = row_of(r);
+    if (row >= 0 && t < n_valid_q) {
+      for (int d = 4 * G; d < dim; ++d) {
+        const float e = q[(size_t)t * dim + d] - db[(size_t)row * dim + d];
+        acc += e * e;
+      }
+    }
+  }
+  return acc;
+}
+
+// K1 (exact form): dist[q][j - first] for rows [first, first + n_range).
+// grid.x = row tiles (4 waves x RW rows), grid.y = query groups of QT.
+template <int QT>
+__global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict__ db,
+                                                         const float* __restrict__ queries,
+                                                         float* __restrict__ dist, int dim,
+                                                         size_t first_row, int n_range, int nq,
+                                                         int RW, size_t ld) {
+  __shared__ __attribute__((aligned(16))) float S_all[4 * 64 * S_PITCH];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* S = S_all + w * 64 * S_PITCH;
+  const int row0 = (blockIdx.x * 4 + w) * RW;  // relative to first_row
+  const int q0 = blockIdx.y * QT;
+  const int nvq = (nq - q0) < QT ? (nq - q0) : QT;
+  auto row_of = [&](int r) -> long long {
+    const int rr = row0 + r;
+    return rr < n_range ? (long long)(first_row + (size_t)rr) : -1;
+  };
+  const float acc =
+      exact_pairs_wave<QT>(db, queries + (size_t)q0 * dim, dim, RW, row_of, nvq, S);
+  if (lane < QT * RW) {
+    const int t = lane / RW, r = lane % RW;
+    if (t < nvq && row0 + r < n_range) dist[(size_t)(q0 + t) * ld + (size_t)(row0 + r)] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 (MFMA form): partial dot products P[split][q][j - first] = sum_{k in split} Q[q][k] D[j][k]
+// with v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  Work-group = 4 waves;
+// WQ waves along the queries (16 each), 4/WQ along the rows, NT 16-row tiles per wave.
+// LDS image per K-step of 32: [kq = k/4][row][4 floats], rows 0..BQ-1 queries, BQ.. db rows,
+// one 16-B slot of padding per kq plane (conflict-free ds_write_b128, <=2-way ds_read_b128).
+template <int WQ, int NT>
+__global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict__ db,
+                                                        const float* __restrict__ queries,
+                                                        float* __restrict__ P, int dim,
+                                                        size_t first_row, int n_range, int nq,
+                                                        int k_per_split, size_t ldP,
+                                                        size_t strideP) {
+  constexpr int WN = 4 / WQ;
+  constexpr int BQ = 16 * WQ;
+  constexpr int BN = 16 * NT * WN;
+  constexpr int ROWS = BQ + BN;
+  constexpr int PLANE = ROWS + 1;  // float4 slots per kq plane
+  constexpr int KQ = 8;            // BK = 32
+  constexpr int NL = (ROWS * KQ + 255) / 256;
+  __shared__ f32x4 lds[2 * KQ * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wq = w % WQ, wn = w / WQ;
+  const int n0 = blockIdx.x * BN;
+  const int q0 = blockIdx.y * BQ;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
+
+  // per-thread load slots: slot -> (row, kq); 8 consecutive threads read one 128-B row segment
+  const float* src[NL];
+  int dst[NL];
+  bool ok[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int slot = tid + i * 256;
+    const int row = slot >> 3, kq = slot & 7;
+    ok[i] = slot < ROWS * KQ;
+    dst[i] = kq * PLANE + row;
+    src[i] = nullptr;
+    if (ok[i]) {
+      if (row < BQ) {
+        const int qq = q0 + row;
+        if (qq < nq) src[i] = queries + (size_t)qq * dim + kq * 4;
+      } else {
+        const int jj = n0 + (row - BQ);
+        if (jj < n_range) src[i] = db + (first_row + (size_t)jj) * dim + kq * 4;
+      }
+    }
+  }
+  f32x4 pre[NL];
+  auto gload = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int kk = k + (dst[i] / PLANE) * 4;  // = k + kq*4
+      if (src[i] && kk < kend) {
+        const f4u v = *reinterpret_cast<const f4u*>(src[i] + k);
+        pre[i] = f32x4{v.x, v.y, v.z, v.w};
+      } else {
+        pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (ok[i]) lds[buf * KQ * PLANE + dst[i]] = pre[i];
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload(kbeg);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  const int a_row = wq * 16 + (lane & 15);
+  const int b_row0 = BQ + wn * NT * 16 + (lane & 15);
+  for (int k = kbeg; k < kend; k += 32) {
+    const bool more = (k + 32) < kend;
+    if (more) gload(k + 32);
+    const f32x4* L = lds + buf * KQ * PLANE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kq = sub * 4 + (lane >> 4);
+      const f32x4 a = L[kq * PLANE + a_row];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 b = L[kq * PLANE + b_row0 + t * 16];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) {
+      lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // C/D map of the 16x16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
+  float* Pz = P + (size_t)blockIdx.z * strideP;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = n0 + (wn * NT + t) * 16 + (lane & 15);
+    if (j < n_range) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = q0 + wq * 16 + (lane >> 4) * 4 + r;
+        Pz[(size_t)qq * ldP + j] = acc[t][r];  // rows q >= nq land in the padded part of P
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 (top-k part): per-query top-K of a distance row, LDS-staged.  One work-group per query.
+// Elements pass a running threshold tau into an LDS buffer; when the buffer passes half full it
+// is bitonic-sorted, cut to K, and tau tightened.  Output: K keys (ordered d, row index) ascending.
+// MODE 0: dist holds final distances.  MODE 1: dist holds MFMA partial dots; the coarse distance
+// (qn + dn[j]) - 2 * sum_splits P is formed here.
+constexpr int SEL_CAP = 1024;
+
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* buf, int n /* pow2 */, int tid,
+                                                 int nthreads) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < (n >> 1); i += nthreads) {
+        const int lo = ((i / stride) * stride * 2) + (i % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t a = buf[lo], b = buf[hi];
+        if ((a > b) == up) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ dist, size_t ld,
+                                                     size_t strideP, int n_splits,
+                                                     const float* __restrict__ qn,
+                                                     const float* __restrict__ dn,
+                                                     size_t first_row, int n_range, int K,
+                                                     uint64_t* __restrict__ out_keys) {
+  __shared__ uint64_t buf[SEL_CAP];
+  __shared__ int cnt;
+  __shared__ uint64_t tau;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;
+  if (tid == 0) {
+    cnt = 0;
+    tau = KEY_SENTINEL;
+  }
+  __syncthreads();
+  const float* row = dist + (size_t)q * ld;
+  const float qnv = (MODE == 1) ? qn[q] : 0.f;
+  for (int base = 0; base < n_range; base += 512) {
+    const uint64_t t = tau;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = base + u * 256 + tid;
+      if (j < n_range) {
+        float d;
+        if (MODE == 1) {
+          float dot = row[j];
+          for (int s = 1; s < n_splits; ++s) dot += row[(size_t)s * strideP + j];
+          d = (qnv + dn[first_row + (size_t)j]) - 2.f * dot;
+        } else {
+          d = row[j];
+        }
+        const uint64_t key = make_key(d, (uint32_t)(first_row + (size_t)j));
+        if (key < t) {
+          const int pos = atomicAdd(&cnt, 1);
+          buf[pos] = key;  // cnt <= 512 before the round, <= 512 added: never exceeds SEL_CAP
+        }
+      }
+    }
+    __syncthreads();
+    const int c = cnt;
+    if (c > 512) {
+      for (int i = c + tid; i < SEL_CAP; i += 256) buf[i] = KEY_SENTINEL;
+      bitonic_sort_lds(buf, SEL_CAP, tid, 256);
+      if (tid == 0) {
+        cnt = K;
+        tau = buf[K - 1];
+      }
+      __syncthreads();
+    }
+  }
+  const int c = cnt;
+  int n2 = 64;
+  while (n2 < c) n2 <<= 1;
+  for (int i = c + tid; i < n2; i += 256) buf[i] = KEY_SENTINEL;
+  bitonic_sort_lds(buf, n2, tid, 256);
+  for (int i = tid; i < K; i += 256) out_keys[(size_t)q * K + i] = (i < c) ? buf[i] : KEY_SENTINEL;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b: exact re-rank of the MFMA path's candidates + completeness check.  One wave per query
+// (work-group = 1 wave so that exact_pairs_wave's barriers are wave-local).
+//   theta    = coarse_d[k-1] + 2 eps,  eps = 4.5 (dim+2) 2^-24 (qn + dn_max)  (DESIGN.md bound)
+//   m        = candidates with coarse_d <= theta (a prefix); those get reference-order distances
+//   complete = fewer candidates than KC exist, or coarse_d[KC-1] > theta
+// Output: k keys (exact d2, row) ascending; flags[q] = 1 if the candidate set may be incomplete.
+__global__ __launch_bounds__(64) void rerank_kernel(const float* __restrict__ db,
+                                                    const float* __restrict__ queries, int dim,
+                                                    const uint64_t* __restrict__ cand, int KC,
+                                                    int k, int n_range,
+                                                    const float* __restrict__ qn,
+                                                    const uint32_t* __restrict__ dn_max_bits,
+                                                    uint64_t* __restrict__ out_keys,
+                                                    int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) float S[64 * S_PITCH];
+  __shared__ uint32_t rows_sh[64];
+  const int lane = threadIdx.x;
+  const int q = blockIdx.x;
+  const uint64_t key = (lane < KC) ? cand[(size_t)q * KC + lane] : KEY_SENTINEL;
+  const bool valid = key != KEY_SENTINEL;
+  const float dco = ord2f((uint32_t)(key >> 32));
+  const uint32_t idx = (uint32_t)key;
+  const int n_valid = __popcll(__ballot(valid));
+  const int kk = k < n_valid ? k : n_valid;
+  int m = 0;
+  bool complete = true;
+  if (kk > 0) {
+    const float dk = __shfl(dco, kk - 1);
+    const float eps = 4.5f * (float)(dim + 2) * 5.9604645e-8f *
+                      (qn[q] + __uint_as_float(*dn_max_bits)) * 1.01f;
+    const float theta = dk + 2.f * eps;
+    m = __popcll(__ballot(valid && dco <= theta));
+    if (n_valid == KC && n_range > KC) {
+      const float dlast = __shfl(dco, KC - 1);
+      complete = dlast > theta;
+    }
+  }
+  rows_sh[lane] = idx;
+  __syncthreads();
+  auto row_of = [&](int r) -> long long { return r < m ? (long long)rows_sh[r] : -1; };
+  const int RW = (m + 3) & ~3;
+  float d2 = 0.f;
+  if (m > 0) d2 = exact_pairs_wave<1>(db, queries + (size_t)q * dim, dim, RW, row_of, 1, S);
+  const uint64_t ek = (lane < m) ? make_key(d2, idx) : KEY_SENTINEL;
+  // rank by counting (keys are distinct: distinct rows)
+  int rank = 0;
+  for (int i = 0; i < 64; ++i) {
+    const uint64_t o = __shfl(ek, i);
+    rank += (o < ek) ? 1 : 0;
+  }
+  if (lane < m && rank < k) out_keys[(size_t)q * k + rank] = ek;
+  for (int i = m + lane; i < k; i += 64) out_keys[(size_t)q * k + i] = KEY_SENTINEL;
+  if (lane == 0) flags[q] = complete ? 0 : 1;
+}
+
+// keys -> (u64 index + offset, f32 d2); sentinel -> (UINT64_MAX, FLT_MAX)
+__global__ void finalize_kernel(const uint64_t* __restrict__ keys, size_t n, uint64_t offset,
+                                uint64_t* __restrict__ out_idx, float* __restrict__ out_d2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == KEY_SENTINEL) {
+    out_idx[i] = ~0ull;
+    out_d2[i] = 3.402823466e+38f;
+  } else {
+    out_idx[i] = (uint64_t)(uint32_t)k + offset;
+    out_d2[i] = ord2f((uint32_t)(k >> 32));
+  }
+}
+
+// K3: merge n_lists sorted top-k lists per query by (d2, idx).  One wave per query; k*n_lists
+// entries ranked by counting (n_lists*k <= 1024).
+__global__ __launch_bounds__(64) void merge_kernel(const uint64_t* __restrict__ idx,
+                                                   const float* __restrict__ d2, int n_lists,
+                                                   int nq, int k, uint64_t* __restrict__ out_idx,
+                                                   float* __restrict__ out_d2) {
+  __shared__ float sd[1024];
+  __shared__ uint64_t si[1024];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int total = n_lists * k;
+  for (int e = lane; e < total; e += 64) {
+    const int l = e / k, r = e % k;
+    const size_t off = ((size_t)l * nq + q) * k + r;
+    sd[e] = d2[off];
+    si[e] = idx[off];
+  }
+  __syncthreads();
+  for (int e = lane; e < total; e += 64) {
+    const float d = sd[e];
+    const uint64_t i = si[e];
+    int rank = 0;
+    for (int o = 0; o < total; ++o) {
+      const float od = sd[o];
+      const uint64_t oi = si[o];
+      rank += (od < d || (od == d && (oi < i || (oi == i && o < e)))) ? 1 : 0;
+    }
+    if (rank < k) {
+      out_idx[(size_t)q * k + rank] = i;
+      out_d2[(size_t)q * k + rank] = d;
+    }
+  }
+}
+
+}  // namespace knn
+}  // namespace gloc

@@ -1,0 +1,207 @@
+/*
+ * gloc3d.h -- C ABI of the MI355X-native place-retrieval + global-registration hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, `int` status codes, no exceptions and no
+ * torch/HIP types in any signature (streams travel as `void*`).  One handle = one device + one HIP
+ * stream + one caller thread (thread-compatible, not thread-safe -- the same contract as the
+ * reference's RpyPCLoopDetector, registration/loop_detector.h:41-119).  The caller owns every host
+ * buffer; handles own their device memory.  There is NO CPU fallback: every entry point fails with
+ * GLOC_ERR_NODEVICE / GLOC_ERR_HIP when no gfx950 device is usable.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the reference-side bindings.
+ */
+#ifndef GLOC3D_H
+#define GLOC3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLOC3D_ABI_VERSION 1
+
+enum {
+  GLOC_OK = 0,
+  GLOC_ERR_INVALID = 1,  /* bad argument (null pointer, k = 0, k too large, dim mismatch ...) */
+  GLOC_ERR_HIP = 2,      /* a HIP runtime call failed; see gloc_last_error() */
+  GLOC_ERR_NOMEM = 3,    /* device or host allocation failed */
+  GLOC_ERR_NODEVICE = 4, /* no usable gfx950 device */
+  GLOC_ERR_STATE = 5     /* call not valid in the handle's current state */
+};
+
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+const char* gloc_last_error(void);
+int gloc_abi_version(void);
+/* Number of visible HIP devices (0 if none; never fails). */
+int gloc_device_count(void);
+
+/* ============================ descriptor kNN ============================================= *
+ * Replaces the KD-tree the reference builds over its descriptor database,
+ *   InvKeyTree(k_dim_, db_features_, 10)            registration/loop_detector.cpp:36,70
+ *   kdtree_->query(&feat[0], top_k_, idx, d2)        registration/loop_detector.cpp:45,79
+ *   (KDTreeVectorOfVectorsAdaptor<KeyMat,float>::query,
+ *    registration/KDTreeVectorOfVectorsAdaptor.h:95-102)
+ * and its Python twin faiss.IndexFlatL2(pool).add / .search(qFeat, 20), main.py:317-324.
+ * Results are the exact squared-L2 top-k, ascending, with the d2 bit patterns of
+ * nanoflann's L2_Adaptor::evalMetric (registration/nanoflann.hpp:453-487); rows at exactly equal
+ * distance come out in ascending row index.
+ */
+typedef struct gloc_knn gloc_knn;
+
+/* Algorithm selection for gloc_knn_set_option(GLOC_KNN_OPT_ALGO, ...). */
+enum {
+  GLOC_KNN_ALGO_AUTO = 0,  /* exact streaming kernel for few queries, MFMA path otherwise */
+  GLOC_KNN_ALGO_EXACT = 1, /* reference-order fp32 differences on the vector ALUs, one pass */
+  GLOC_KNN_ALGO_MFMA = 2   /* fp32-MFMA -2Q.D^T + norms, LDS top-k', exact re-rank, verified */
+};
+enum {
+  GLOC_KNN_OPT_ALGO = 1,
+  GLOC_KNN_OPT_CANDIDATES = 2, /* k' kept by the MFMA path before the exact re-rank (<= 64) */
+  GLOC_KNN_OPT_PROFILE = 3     /* 1: bracket every kernel with HIP events (gloc_knn_profile) */
+};
+
+/* device: HIP ordinal.  dim: descriptor length (reference: k_dim_ = 512, loop_detector.h:97). */
+int gloc_knn_create(int device, size_t dim, gloc_knn** out);
+int gloc_knn_destroy(gloc_knn* h);
+
+/* Use `hip_stream` (a hipStream_t created by the caller on the same device) for all work of this
+ * handle instead of the handle's own stream.  NULL restores the own stream. */
+int gloc_knn_set_stream(gloc_knn* h, void* hip_stream);
+int gloc_knn_synchronize(gloc_knn* h);
+int gloc_knn_set_option(gloc_knn* h, int option, int64_t value);
+
+/* Append n rows (row-major n x dim, host memory).  Replaces db_features_.push_back(feat)
+ * (registration/loop_detector.cpp:14) and faiss_index.add(dbFeat) (main.py:320).  Unlike the
+ * reference's tree, which silently goes stale after the first detect (loop_detector.cpp:34-37
+ * builds once over a const-ref), rows are searchable immediately. */
+int gloc_knn_add(gloc_knn* h, const float* rows, size_t n);
+/* Same with rows already in device memory on the handle's device. */
+int gloc_knn_add_device(gloc_knn* h, const float* d_rows, size_t n);
+int gloc_knn_reserve(gloc_knn* h, size_t n_rows);
+int gloc_knn_clear(gloc_knn* h);
+int gloc_knn_size(const gloc_knn* h, size_t* n_rows);
+int gloc_knn_dim(const gloc_knn* h, size_t* dim);
+/* Device pointer of the resident row-major database (valid until the next add/reserve/clear). */
+int gloc_knn_device_rows(const gloc_knn* h, const float** d_rows);
+
+/* Top-k over rows [first_row, last_row) for nq queries (host buffers).  last_row is clamped to the
+ * database size; pass SIZE_MAX for "all".  The row window expresses the SLAM-mode exclusion of the
+ * newest frames (db_features_.begin() .. end()-num_exclude_recent_, loop_detector.cpp:66-72).
+ * out_idx: nq x k row indices, out_d2: nq x k squared distances, ascending.  If the window holds
+ * fewer than k rows the tail is idx = UINT64_MAX, d2 = FLT_MAX. */
+int gloc_knn_search(gloc_knn* h, const float* queries, size_t nq, size_t k, size_t first_row,
+                    size_t last_row, uint64_t* out_idx, float* out_d2);
+
+/* Same with device buffers, enqueued on the handle's stream; `index_offset` is added to every
+ * returned index (a shard's first global row, for row-sharded databases).  Returns after the work
+ * is enqueued and -- on the MFMA path -- after its completeness flag has been read back. */
+int gloc_knn_search_device(gloc_knn* h, const float* d_queries, size_t nq, size_t k,
+                           size_t first_row, size_t last_row, uint64_t index_offset,
+                           uint64_t* d_out_idx, float* d_out_d2);
+
+/* Merge `n_lists` sorted top-k lists per query (gathered from the shards of a row-sharded
+ * database: layout [n_lists][nq][k]) into one top-k, ordered by (d2, idx).  Device buffers;
+ * enqueued on `hip_stream` (may be NULL = default stream). */
+int gloc_topk_merge_device(int device, void* hip_stream, const uint64_t* d_idx, const float* d_d2,
+                           size_t n_lists, size_t nq, size_t k, uint64_t* d_out_idx,
+                           float* d_out_d2);
+
+/* Counters since creation: searches on each path, queries that needed the exact fallback. */
+typedef struct gloc_knn_stats {
+  uint64_t searches_exact, searches_mfma, queries_total, queries_fallback;
+  uint32_t last_n_tile, last_k_split, last_candidates;
+} gloc_knn_stats;
+int gloc_knn_get_stats(const gloc_knn* h, gloc_knn_stats* out);
+
+/* With GLOC_KNN_OPT_PROFILE = 1: accumulated HIP-event time of one kernel family since the last
+ * gloc_knn_profile_reset.  Names: "dist_exact", "dist_mfma", "select", "rerank", "norms",
+ * "finalize".  Synchronizes the stream. */
+int gloc_knn_profile(gloc_knn* h, const char* kernel, double* total_ms, uint64_t* launches);
+int gloc_knn_profile_reset(gloc_knn* h);
+
+/* ============================ 3-D registration =========================================== *
+ * Replaces the reference's per-candidate registration seam,
+ *   icp_match_3d(src, tgt, guess, pose)   registration/global_registration.cpp:237-248
+ *   (pcl::IterativeClosestPoint, 30 iterations), and the RANSAC transform estimate the reference
+ *   runs per candidate (cv::estimateAffinePartial2D(..., RANSAC, 3*res, 3000),
+ *   registration/loop_detector.cpp:256-257), as the batched loop over the top-20 candidates of
+ *   GlocEvaluator::global_registraion (registration/global_localization.cpp:511-574).
+ * Semantics: SURVEY.md Appendix B (S1 exact 1-NN, S2 RANSAC 3-point Kabsch/SVD + inlier count +
+ * refit, S3 point-to-point ICP).
+ */
+typedef struct gloc_reg gloc_reg;
+
+typedef struct gloc_reg_params {
+  uint32_t ransac_iters;  /* 3000 (loop_detector.cpp:257); 0 disables RANSAC */
+  float inlier_thresh;    /* 0.6 m = 3 x 0.2 m (loop_detector.cpp:257, loop_detector.h:116) */
+  float min_inlier_ratio; /* ok iff best inliers >= ratio x n_src (and >= 3) */
+  uint32_t icp_iters;     /* 30 (global_registration.cpp:242) */
+  float max_corr_dist;    /* <= 0: no correspondence rejection (PCL default) */
+  uint64_t seed;          /* RANSAC sampling seed */
+} gloc_reg_params;
+
+/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234). */
+void gloc_reg_default_params(gloc_reg_params* p);
+
+int gloc_reg_create(int device, gloc_reg** out);
+int gloc_reg_destroy(gloc_reg* h);
+int gloc_reg_set_stream(gloc_reg* h, void* hip_stream);
+int gloc_reg_synchronize(gloc_reg* h);
+int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
+enum { GLOC_REG_OPT_PROFILE = 1 };
+
+/* Scan store: keep database scans resident in HBM (x,y,z packed fp32, n points).  Returns an id
+ * usable in gloc_reg_batch_ids.  `stride_floats` is 3 for packed xyz or 4 for KITTI x,y,z,i
+ * (registration/global_localization.cpp:160-182). */
+int gloc_reg_scan_upload(gloc_reg* h, const float* pts, size_t n, size_t stride_floats,
+                         uint32_t* scan_id);
+int gloc_reg_scan_count(const gloc_reg* h, size_t* n_scans);
+int gloc_reg_scan_clear(gloc_reg* h);
+
+/* Register one query scan against n_cand candidate scans (host buffers, packed xyz).
+ * init_T: n_cand x 16 row-major 4x4 (query -> candidate frame) or NULL for identity.
+ * Outputs per candidate: out_T (n_cand x 16, query -> db), out_rmse, out_inliers, out_ok
+ * (any may be NULL except out_T).  Candidate c uses RANSAC stream id c. */
+int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* const* cand_xyz,
+                   const size_t* cand_npts, size_t n_cand, const float* init_T,
+                   const gloc_reg_params* params, float* out_T, float* out_rmse,
+                   uint32_t* out_inliers, int* out_ok);
+
+/* Same with the query scan and the candidates taken from the scan store. */
+int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
+                       size_t n_cand, const float* init_T, const gloc_reg_params* params,
+                       float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok);
+
+/* The reference's selection rule: lowest-rank candidate whose registration succeeded
+ * (registration/global_localization.cpp:519-572 stops at the first match()==true).
+ * Returns the rank or -1. */
+int gloc_reg_select_first_ok(const int* ok, size_t n_cand);
+
+/* Building blocks, exposed for tests and for callers that drive ICP themselves (host buffers). */
+int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tgt_xyz,
+                size_t n_tgt, const float* T16 /* may be NULL */, uint32_t* out_idx, float* out_d2);
+int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* tgt_xyz,
+                               const uint32_t* corr, size_t n, uint64_t seed, uint32_t cand,
+                               uint32_t n_hyp, float* out_Rt /* n_hyp x 12 */,
+                               uint32_t* out_valid, uint32_t* out_inliers, float inlier_thresh);
+
+/* HIP-event time per kernel family ("nn", "ransac_hyp", "ransac_score", "accum", "solve",
+ * "transform"), as gloc_knn_profile. */
+int gloc_reg_profile(gloc_reg* h, const char* kernel, double* total_ms, uint64_t* launches);
+int gloc_reg_profile_reset(gloc_reg* h);
+
+/* ============================ synthetic inputs (bench / tests) ============================ *
+ * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).
+ * kind 0: iid N(0,1)/sqrt(dim); kind 1: anchored trajectory (stride 16, noise 0.05).
+ * Appends rows [first_row, first_row+n) of the global synthetic database to the handle. */
+int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n);
+int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed,
+                           uint64_t first_row, size_t n, size_t dim, float* d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOC3D_H */

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """The CPU checker (oracle/): built on demand; tests are its only consumers."""
+    import oracle
+    oracle.build(ref=True)
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def capi():
+    from gloc3d_amd import capi as c
+    c.lib()
+    return c

@@ -16,7 +16,7 @@ SOURCES = ["common.hip", "knn.hip", "reg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact kernels must reproduce the reference's un-fused fp32 arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(out, deps):

@@ -1,25 +1,456 @@
-// reg.hip -- placeholder; replaced by the registration kernels (K4-K6).
+// reg.hip -- C ABI of the batched candidate registration (include/gloc3d.h) over reg_kernels.hpp.
+// Replaces icp_match_3d (registration/global_registration.cpp:237-248) and the per-candidate RANSAC
+// transform estimate (registration/loop_detector.cpp:256-257) of the reference, batched over the
+// top-k candidates of GlocEvaluator::global_registraion (registration/global_localization.cpp:511-574).
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
 #include "common.hpp"
-#define NI { gloc::set_err("registration not built yet"); return GLOC_ERR_STATE; }
+#include "reg_kernels.hpp"
+
+using namespace gloc;
+using namespace gloc::reg;
+
+struct DevScan {
+  float* xyz = nullptr;
+  size_t n = 0;
+};
+
+struct gloc_reg {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<DevScan> scans;  // resident scan store
+  DevBuf tmp_src, tmp_tgt;     // host-pointer API staging
+  DevBuf cands, states;        // CandDesc[], CandState[]
+  DevBuf corr, d2, pairs;      // [cand][ld]
+  DevBuf Rt, valid, inliers;   // RANSAC hypotheses
+  DevBuf partials;
+  std::vector<CandState> h_states;
+  std::vector<CandDesc> h_cands;
+  Profiler prof;
+};
+
+namespace {
+
+int upload_packed(gloc_reg* h, const float* pts, size_t n, size_t stride, float* d_dst) {
+  if (n == 0) return GLOC_OK;
+  if (stride == 3) {
+    GLOC_HIP(hipMemcpyAsync(d_dst, pts, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  } else {
+    GLOC_HIP(hipMemcpy2DAsync(d_dst, 3 * sizeof(float), pts, stride * sizeof(float),
+                              3 * sizeof(float), n, hipMemcpyHostToDevice, h->stream));
+  }
+  return GLOC_OK;
+}
+
+void init_state(CandState& st, const float* T16) {
+  memset(&st, 0, sizeof(st));
+  static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* T = T16 ? T16 : I16;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      st.Tf[3 * i + j] = T[4 * i + j];
+      st.Td[3 * i + j] = (double)T[4 * i + j];
+    }
+    st.Tf[9 + i] = T[4 * i + 3];
+    st.Td[9 + i] = (double)T[4 * i + 3];
+  }
+  st.best_h = 0xFFFFFFFFu;
+}
+
+int launch_nn(gloc_reg* h, const float* d_src, uint32_t n_src, int n_cand, size_t ld) {
+  ProfScope ps(h->prof, "nn", h->stream);
+  dim3 grid((n_src + 256 * NN_S - 1) / (256 * NN_S), (unsigned)n_cand);
+  hipLaunchKernelGGL(nn_kernel, grid, dim3(256), 0, h->stream, d_src, n_src,
+                     h->cands.as<CandDesc>(), h->states.as<CandState>(), h->corr.as<uint32_t>(),
+                     h->d2.as<float>(), ld);
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+// The whole per-query pipeline, device resident: S1 -> S2 (RANSAC + refit) -> S3 (ICP).
+int run_batch(gloc_reg* h, const float* d_src, size_t n_src_sz, const std::vector<CandDesc>& cds,
+              const float* init_T, const gloc_reg_params* prm, float* out_T, float* out_rmse,
+              uint32_t* out_inliers, int* out_ok) {
+  const int n_cand = (int)cds.size();
+  const uint32_t n_src = (uint32_t)n_src_sz;
+  const size_t ld = ((size_t)n_src + 63) & ~(size_t)63;
+  hipStream_t s = h->stream;
+  h->h_states.resize(n_cand);
+  for (int c = 0; c < n_cand; ++c) init_state(h->h_states[c], init_T ? init_T + 16 * c : nullptr);
+  GLOC_TRY(h->cands.ensure(sizeof(CandDesc) * n_cand, s));
+  GLOC_TRY(h->states.ensure(sizeof(CandState) * n_cand, s));
+  GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * ld * n_cand, s));
+  GLOC_TRY(h->d2.ensure(sizeof(float) * ld * n_cand, s));
+  const int nblocks = (int)((n_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK);
+  GLOC_TRY(h->partials.ensure(sizeof(double) * ACC_NV * std::max(nblocks, 1) * n_cand, s));
+  GLOC_HIP(hipMemcpyAsync(h->cands.p, cds.data(), sizeof(CandDesc) * n_cand,
+                          hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states.data(), sizeof(CandState) * n_cand,
+                          hipMemcpyHostToDevice, s));
+  const bool can = n_src >= 3;
+  bool any_tgt = false;
+  for (auto& c : cds) any_tgt |= c.n_tgt >= 1;
+
+  if (can && any_tgt && prm->ransac_iters > 0) {
+    const uint32_t H = prm->ransac_iters;
+    GLOC_TRY(h->pairs.ensure(sizeof(f32x4) * 2 * ld * n_cand, s));
+    GLOC_TRY(h->Rt.ensure(sizeof(float) * 12 * (size_t)H * n_cand, s));
+    GLOC_TRY(h->valid.ensure(sizeof(uint32_t) * (size_t)H * n_cand, s));
+    GLOC_TRY(h->inliers.ensure(sizeof(uint32_t) * (size_t)H * n_cand, s));
+    GLOC_TRY(launch_nn(h, d_src, n_src, n_cand, ld));
+    {
+      ProfScope ps(h->prof, "transform", s);
+      hipLaunchKernelGGL(gather_pairs_kernel, dim3((n_src + 255) / 256, n_cand), dim3(256), 0, s,
+                         d_src, n_src, h->cands.as<CandDesc>(), h->states.as<CandState>(),
+                         h->corr.as<uint32_t>(), ld, h->pairs.as<f32x4>());
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "ransac_hyp", s);
+      hipLaunchKernelGGL(ransac_hyp_kernel, dim3((H + 127) / 128, n_cand), dim3(128), 0, s,
+                         h->pairs.as<f32x4>(), ld, n_src, h->cands.as<CandDesc>(), prm->seed, H,
+                         h->Rt.as<float>(), h->valid.as<uint32_t>());
+      GLOC_HIP(hipGetLastError());
+    }
+    GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)H * n_cand, s));
+    const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
+    {
+      ProfScope ps(h->prof, "ransac_score", s);
+      dim3 grid((H + 255) / 256, (n_src + SC_CHUNK - 1) / SC_CHUNK, n_cand);
+      hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
+                         n_src, H, h->Rt.as<float>(), h->valid.as<uint32_t>(), thr2,
+                         h->inliers.as<uint32_t>());
+      GLOC_HIP(hipGetLastError());
+      hipLaunchKernelGGL(ransac_best_kernel, dim3(n_cand), dim3(256), 0, s,
+                         h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
+                         n_src, prm->min_inlier_ratio, h->states.as<CandState>());
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "accum", s);
+      hipLaunchKernelGGL(accum_kernel<1>, dim3(nblocks, n_cand), dim3(ACC_THREADS), 0, s, d_src,
+                         n_src, h->cands.as<CandDesc>(), h->states.as<CandState>(),
+                         h->corr.as<uint32_t>(), h->d2.as<float>(), h->pairs.as<f32x4>(), ld, thr2,
+                         h->partials.as<double>());
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "solve", s);
+      if (prm->icp_iters == 0) {
+        hipLaunchKernelGGL(sumd2_kernel, dim3(n_cand), dim3(256), 0, s, h->d2.as<float>(), ld,
+                           n_src, n_cand, h->states.as<CandState>());
+      }
+      hipLaunchKernelGGL(solve_kernel<1>, dim3((n_cand + 63) / 64), dim3(64), 0, s,
+                         h->partials.as<double>(), nblocks, n_cand, h->states.as<CandState>());
+      GLOC_HIP(hipGetLastError());
+    }
+  }
+  const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
+  for (uint32_t it = 0; it < prm->icp_iters && can && any_tgt; ++it) {
+    GLOC_TRY(launch_nn(h, d_src, n_src, n_cand, ld));
+    {
+      ProfScope ps(h->prof, "accum", s);
+      hipLaunchKernelGGL(accum_kernel<0>, dim3(nblocks, n_cand), dim3(ACC_THREADS), 0, s, d_src,
+                         n_src, h->cands.as<CandDesc>(), h->states.as<CandState>(),
+                         h->corr.as<uint32_t>(), h->d2.as<float>(), (const f32x4*)nullptr, ld,
+                         gate2, h->partials.as<double>());
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "solve", s);
+      hipLaunchKernelGGL(solve_kernel<0>, dim3((n_cand + 63) / 64), dim3(64), 0, s,
+                         h->partials.as<double>(), nblocks, n_cand, h->states.as<CandState>());
+      GLOC_HIP(hipGetLastError());
+    }
+  }
+  GLOC_HIP(hipMemcpyAsync(h->h_states.data(), h->states.p, sizeof(CandState) * n_cand,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipStreamSynchronize(s));
+  for (int c = 0; c < n_cand; ++c) {
+    const CandState& st = h->h_states[c];
+    float* T = out_T + 16 * c;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) T[4 * i + j] = st.Tf[3 * i + j];
+      T[4 * i + 3] = st.Tf[9 + i];
+    }
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+    if (out_rmse) out_rmse[c] = n_src ? (float)std::sqrt(st.sum_d2 / (double)n_src) : 0.f;
+    if (out_inliers) out_inliers[c] = st.best_inl;
+    if (out_ok) out_ok[c] = st.ok;
+  }
+  return GLOC_OK;
+}
+
+int check_params(const gloc_reg_params* p) {
+  GLOC_REQUIRE(p, GLOC_ERR_INVALID, "params is null");
+  GLOC_REQUIRE(p->ransac_iters <= (1u << 20), GLOC_ERR_INVALID, "ransac_iters too large");
+  GLOC_REQUIRE(p->icp_iters <= 10000, GLOC_ERR_INVALID, "icp_iters too large");
+  GLOC_REQUIRE(p->ransac_iters == 0 || p->inlier_thresh > 0.f, GLOC_ERR_INVALID,
+               "inlier_thresh must be > 0");
+  return GLOC_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
 void gloc_reg_default_params(gloc_reg_params* p) {
   if (!p) return;
-  p->ransac_iters = 3000; p->inlier_thresh = 0.6f; p->min_inlier_ratio = 0.3f;
-  p->icp_iters = 30; p->max_corr_dist = 0.f; p->seed = 1234;
+  p->ransac_iters = 3000;   // registration/loop_detector.cpp:257
+  p->inlier_thresh = 0.6f;  // 3 * 0.2 m: loop_detector.cpp:257, loop_detector.h:116
+  p->min_inlier_ratio = 0.3f;
+  p->icp_iters = 30;  // registration/global_registration.cpp:242
+  p->max_corr_dist = 0.f;
+  p->seed = 1234;
 }
-int gloc_reg_create(int, gloc_reg**) NI
-int gloc_reg_destroy(gloc_reg*) NI
-int gloc_reg_set_stream(gloc_reg*, void*) NI
-int gloc_reg_synchronize(gloc_reg*) NI
-int gloc_reg_set_option(gloc_reg*, int, int64_t) NI
-int gloc_reg_scan_upload(gloc_reg*, const float*, size_t, size_t, uint32_t*) NI
-int gloc_reg_scan_count(const gloc_reg*, size_t*) NI
-int gloc_reg_scan_clear(gloc_reg*) NI
-int gloc_reg_batch(gloc_reg*, const float*, size_t, const float* const*, const size_t*, size_t, const float*, const gloc_reg_params*, float*, float*, uint32_t*, int*) NI
-int gloc_reg_batch_ids(gloc_reg*, uint32_t, const uint32_t*, size_t, const float*, const gloc_reg_params*, float*, float*, uint32_t*, int*) NI
-int gloc_reg_select_first_ok(const int* ok, size_t n) { for (size_t i = 0; i < n; ++i) if (ok[i]) return (int)i; return -1; }
-int gloc_reg_nn(gloc_reg*, const float*, size_t, const float*, size_t, const float*, uint32_t*, float*) NI
-int gloc_reg_ransac_hypotheses(gloc_reg*, const float*, const float*, const uint32_t*, size_t, uint64_t, uint32_t, uint32_t, float*, uint32_t*, uint32_t*, float) NI
-int gloc_reg_profile(gloc_reg*, const char*, double*, uint64_t*) NI
-int gloc_reg_profile_reset(gloc_reg*) NI
+
+int gloc_reg_create(int device, gloc_reg** out) {
+  GLOC_REQUIRE(out, GLOC_ERR_INVALID, "out is null");
+  *out = nullptr;
+  GLOC_TRY(select_device(device));
+  gloc_reg* h = new (std::nothrow) gloc_reg;
+  GLOC_REQUIRE(h, GLOC_ERR_NOMEM, "host allocation failed");
+  h->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete h;
+    return GLOC_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return GLOC_OK;
 }
+
+int gloc_reg_scan_clear(gloc_reg* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  for (auto& s : h->scans)
+    if (s.xyz) (void)hipFree(s.xyz);
+  h->scans.clear();
+  return GLOC_OK;
+}
+
+int gloc_reg_destroy(gloc_reg* h) {
+  if (!h) return GLOC_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)gloc_reg_scan_clear(h);
+  h->prof.destroy();
+  for (DevBuf* b : {&h->tmp_src, &h->tmp_tgt, &h->cands, &h->states, &h->corr, &h->d2, &h->pairs,
+                    &h->Rt, &h->valid, &h->inliers, &h->partials})
+    b->release();
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return GLOC_OK;
+}
+
+int gloc_reg_set_stream(gloc_reg* h, void* hip_stream) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return GLOC_OK;
+}
+
+int gloc_reg_synchronize(gloc_reg* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  return GLOC_OK;
+}
+
+int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  if (option == GLOC_REG_OPT_PROFILE) {
+    h->prof.enabled = value != 0;
+    return GLOC_OK;
+  }
+  set_err("unknown option %d", option);
+  return GLOC_ERR_INVALID;
+}
+
+int gloc_reg_scan_upload(gloc_reg* h, const float* pts, size_t n, size_t stride_floats,
+                         uint32_t* scan_id) {
+  GLOC_REQUIRE(h && scan_id && (pts || n == 0), GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(stride_floats >= 3 && stride_floats <= 16, GLOC_ERR_INVALID,
+               "stride_floats = %zu outside [3,16]", stride_floats);
+  GLOC_REQUIRE(n < (1ull << 31), GLOC_ERR_INVALID, "scan too large");
+  GLOC_HIP(hipSetDevice(h->device));
+  DevScan s;
+  s.n = n;
+  GLOC_HIP(hipMalloc((void**)&s.xyz, std::max<size_t>(n, 1) * 3 * sizeof(float)));
+  int rc = upload_packed(h, pts, n, stride_floats, s.xyz);
+  if (rc == GLOC_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GLOC_ERR_HIP;
+  if (rc != GLOC_OK) {
+    (void)hipFree(s.xyz);
+    return rc;
+  }
+  h->scans.push_back(s);
+  *scan_id = (uint32_t)(h->scans.size() - 1);
+  return GLOC_OK;
+}
+
+int gloc_reg_scan_count(const gloc_reg* h, size_t* n_scans) {
+  GLOC_REQUIRE(h && n_scans, GLOC_ERR_INVALID, "null argument");
+  *n_scans = h->scans.size();
+  return GLOC_OK;
+}
+
+int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* const* cand_xyz,
+                   const size_t* cand_npts, size_t n_cand, const float* init_T,
+                   const gloc_reg_params* params, float* out_T, float* out_rmse,
+                   uint32_t* out_inliers, int* out_ok) {
+  GLOC_REQUIRE(h && out_T && (q_xyz || nq_pts == 0), GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_cand >= 1 && n_cand <= 4096 && cand_xyz && cand_npts, GLOC_ERR_INVALID,
+               "n_cand = %zu outside [1,4096] or null candidate arrays", n_cand);
+  GLOC_REQUIRE(nq_pts < (1ull << 31), GLOC_ERR_INVALID, "query scan too large");
+  GLOC_TRY(check_params(params));
+  GLOC_HIP(hipSetDevice(h->device));
+  size_t total = 0;
+  for (size_t c = 0; c < n_cand; ++c) {
+    GLOC_REQUIRE(cand_xyz[c] || cand_npts[c] == 0, GLOC_ERR_INVALID, "candidate %zu is null", c);
+    GLOC_REQUIRE(cand_npts[c] < (1ull << 31), GLOC_ERR_INVALID, "candidate scan too large");
+    total += cand_npts[c];
+  }
+  GLOC_TRY(h->tmp_src.ensure(std::max<size_t>(nq_pts, 1) * 3 * sizeof(float), h->stream));
+  GLOC_TRY(h->tmp_tgt.ensure(std::max<size_t>(total, 1) * 3 * sizeof(float), h->stream));
+  GLOC_TRY(upload_packed(h, q_xyz, nq_pts, 3, h->tmp_src.as<float>()));
+  std::vector<CandDesc> cds(n_cand);
+  size_t off = 0;
+  for (size_t c = 0; c < n_cand; ++c) {
+    float* dst = h->tmp_tgt.as<float>() + off * 3;
+    GLOC_TRY(upload_packed(h, cand_xyz[c], cand_npts[c], 3, dst));
+    cds[c] = CandDesc{dst, (uint32_t)cand_npts[c], (uint32_t)c};
+    off += cand_npts[c];
+  }
+  return run_batch(h, h->tmp_src.as<float>(), nq_pts, cds, init_T, params, out_T, out_rmse,
+                   out_inliers, out_ok);
+}
+
+int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
+                       size_t n_cand, const float* init_T, const gloc_reg_params* params,
+                       float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  GLOC_REQUIRE(h && out_T && cand_scan_ids, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_cand >= 1 && n_cand <= 4096, GLOC_ERR_INVALID, "n_cand = %zu outside [1,4096]",
+               n_cand);
+  GLOC_REQUIRE(q_scan_id < h->scans.size(), GLOC_ERR_INVALID, "unknown query scan id %u", q_scan_id);
+  GLOC_TRY(check_params(params));
+  GLOC_HIP(hipSetDevice(h->device));
+  std::vector<CandDesc> cds(n_cand);
+  for (size_t c = 0; c < n_cand; ++c) {
+    GLOC_REQUIRE(cand_scan_ids[c] < h->scans.size(), GLOC_ERR_INVALID, "unknown scan id %u",
+                 cand_scan_ids[c]);
+    const DevScan& s = h->scans[cand_scan_ids[c]];
+    cds[c] = CandDesc{s.xyz, (uint32_t)s.n, (uint32_t)c};
+  }
+  const DevScan& q = h->scans[q_scan_id];
+  return run_batch(h, q.xyz, q.n, cds, init_T, params, out_T, out_rmse, out_inliers, out_ok);
+}
+
+int gloc_reg_select_first_ok(const int* ok, size_t n_cand) {
+  if (!ok) return -1;
+  for (size_t i = 0; i < n_cand; ++i)
+    if (ok[i]) return (int)i;
+  return -1;
+}
+
+int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tgt_xyz,
+                size_t n_tgt, const float* T16, uint32_t* out_idx, float* out_d2) {
+  GLOC_REQUIRE(h && out_idx && out_d2 && (src_xyz || !n_src) && (tgt_xyz || !n_tgt),
+               GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_src < (1ull << 31) && n_tgt < (1ull << 31), GLOC_ERR_INVALID, "scan too large");
+  if (n_src == 0) return GLOC_OK;
+  GLOC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t ld = (n_src + 63) & ~(size_t)63;
+  GLOC_TRY(h->tmp_src.ensure(n_src * 3 * sizeof(float), s));
+  GLOC_TRY(h->tmp_tgt.ensure(std::max<size_t>(n_tgt, 1) * 3 * sizeof(float), s));
+  GLOC_TRY(h->cands.ensure(sizeof(CandDesc), s));
+  GLOC_TRY(h->states.ensure(sizeof(CandState), s));
+  GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * ld, s));
+  GLOC_TRY(h->d2.ensure(sizeof(float) * ld, s));
+  GLOC_TRY(upload_packed(h, src_xyz, n_src, 3, h->tmp_src.as<float>()));
+  GLOC_TRY(upload_packed(h, tgt_xyz, n_tgt, 3, h->tmp_tgt.as<float>()));
+  CandDesc cd{h->tmp_tgt.as<float>(), (uint32_t)n_tgt, 0};
+  CandState st;
+  init_state(st, T16);
+  GLOC_HIP(hipMemcpyAsync(h->cands.p, &cd, sizeof(cd), hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(h->states.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  GLOC_TRY(launch_nn(h, h->tmp_src.as<float>(), (uint32_t)n_src, 1, ld));
+  GLOC_HIP(hipMemcpyAsync(out_idx, h->corr.p, sizeof(uint32_t) * n_src, hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipMemcpyAsync(out_d2, h->d2.p, sizeof(float) * n_src, hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipStreamSynchronize(s));
+  return GLOC_OK;
+}
+
+int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* tgt_xyz,
+                               const uint32_t* corr, size_t n, uint64_t seed, uint32_t cand,
+                               uint32_t n_hyp, float* out_Rt, uint32_t* out_valid,
+                               uint32_t* out_inliers, float inlier_thresh) {
+  GLOC_REQUIRE(h && src_xyz && tgt_xyz && corr && out_Rt && out_valid && out_inliers,
+               GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n >= 3 && n < (1ull << 31) && n_hyp >= 1 && n_hyp <= (1u << 20), GLOC_ERR_INVALID,
+               "bad sizes");
+  GLOC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t ld = (n + 63) & ~(size_t)63;
+  // pairs are built on the host from (src, tgt[corr]) -- src is taken as already moved
+  std::vector<float> hp(ld * 8, 0.f);
+  for (size_t i = 0; i < n; ++i) {
+    for (int a = 0; a < 3; ++a) {
+      hp[i * 8 + a] = src_xyz[3 * i + a];
+      hp[i * 8 + 4 + a] = tgt_xyz[3 * (size_t)corr[i] + a];
+    }
+  }
+  GLOC_TRY(h->pairs.ensure(sizeof(float) * 8 * ld, s));
+  GLOC_TRY(h->cands.ensure(sizeof(CandDesc), s));
+  GLOC_TRY(h->Rt.ensure(sizeof(float) * 12 * (size_t)n_hyp, s));
+  GLOC_TRY(h->valid.ensure(sizeof(uint32_t) * (size_t)n_hyp, s));
+  GLOC_TRY(h->inliers.ensure(sizeof(uint32_t) * (size_t)n_hyp, s));
+  CandDesc cd{nullptr, 0, cand};
+  GLOC_HIP(hipMemcpyAsync(h->cands.p, &cd, sizeof(cd), hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(h->pairs.p, hp.data(), sizeof(float) * 8 * ld, hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)n_hyp, s));
+  hipLaunchKernelGGL(ransac_hyp_kernel, dim3((n_hyp + 127) / 128, 1), dim3(128), 0, s,
+                     h->pairs.as<f32x4>(), ld, (uint32_t)n, h->cands.as<CandDesc>(), seed, n_hyp,
+                     h->Rt.as<float>(), h->valid.as<uint32_t>());
+  GLOC_HIP(hipGetLastError());
+  dim3 grid((n_hyp + 255) / 256, (unsigned)((n + SC_CHUNK - 1) / SC_CHUNK), 1);
+  hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
+                     (uint32_t)n, n_hyp, h->Rt.as<float>(), h->valid.as<uint32_t>(),
+                     inlier_thresh * inlier_thresh, h->inliers.as<uint32_t>());
+  GLOC_HIP(hipGetLastError());
+  GLOC_HIP(hipMemcpyAsync(out_Rt, h->Rt.p, sizeof(float) * 12 * (size_t)n_hyp,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipMemcpyAsync(out_valid, h->valid.p, sizeof(uint32_t) * (size_t)n_hyp,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipMemcpyAsync(out_inliers, h->inliers.p, sizeof(uint32_t) * (size_t)n_hyp,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipStreamSynchronize(s));
+  return GLOC_OK;
+}
+
+int gloc_reg_profile(gloc_reg* h, const char* kernel, double* total_ms, uint64_t* launches) {
+  GLOC_REQUIRE(h && kernel, GLOC_ERR_INVALID, "null argument");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(h->prof.collect(h->stream));
+  auto it = h->prof.fam.find(kernel);
+  if (total_ms) *total_ms = it == h->prof.fam.end() ? 0.0 : it->second.total_ms;
+  if (launches) *launches = it == h->prof.fam.end() ? 0 : it->second.launches;
+  return GLOC_OK;
+}
+
+int gloc_reg_profile_reset(gloc_reg* h) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->prof.reset();
+  return GLOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// reg_kernels.hpp -- device kernels of the batched candidate registration (gfx950).
+//
+//   K4 nn_kernel            exact brute-force 1-NN (coalesced LDS-staged targets, per-lane running
+//                           min, per-chunk argmin bookkeeping, one-chunk rescan for the index)
+//   K5 ransac_hyp_kernel    one thread per hypothesis: counter-RNG sample, 3-point Kabsch (fp64 SVD)
+//      ransac_score_kernel  thread <-> hypothesis, correspondences broadcast from LDS, inlier counts
+//      ransac_best_kernel   argmax (inliers, -h) per candidate
+//   K6 accum_kernel         fp64 raw moments of the (moved source, matched target) pairs
+//      solve_kernel         Kabsch from the moments, T <- dT * T (fp64 state), fp32 copy for K4
+//
+// All fp32 point arithmetic uses the fixed, un-fused order of oracle/reg_oracle.c (this unit is
+// compiled with -ffp-contract=off): p' = ((r0 x + r1 y) + r2 z) + t, d2 = (dx dx + dy dy) + dz dz
+// (nanoflann L2_Simple order, registration/nanoflann.hpp:521-532).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "synth_kernels.hpp"  // mix64 / rng_key / rng_draw
+
+namespace gloc {
+namespace reg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct CandDesc {
+  const float* tgt;  // packed xyz
+  uint32_t n_tgt;
+  uint32_t cand_id;  // RANSAC stream id
+};
+
+// per-candidate state, device resident
+struct CandState {
+  double Td[12];      // current absolute transform (R row-major 9, t 3), fp64
+  float Tf[12];       // fp32 copy used to move points
+  float bestRt[12];   // best RANSAC hypothesis (fp32)
+  uint32_t best_h, best_inl;
+  int ok, frozen;
+  double sum_d2;      // of the last S1 pass
+  uint32_t n_pairs;
+  uint32_t pad_;
+};
+
+__device__ __forceinline__ void xform(const float* __restrict__ T, float x, float y, float z,
+                                      float& ox, float& oy, float& oz) {
+  ox = ((T[0] * x + T[1] * y) + T[2] * z) + T[9];
+  oy = ((T[3] * x + T[4] * y) + T[5] * z) + T[10];
+  oz = ((T[6] * x + T[7] * y) + T[8] * z) + T[11];
+}
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4.  grid = (ceil(n_src / (256*NN_S)), n_cand).  Each lane owns NN_S source points; targets are
+// staged 256 at a time into LDS as float4 and read back as wave-uniform broadcasts.
+constexpr int NN_S = 4;
+constexpr int NN_TC = 256;
+constexpr float NN_FAR = 1.0e18f;  // padding coordinate: squares to +inf, never the minimum
+
+__global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, uint32_t n_src,
+                                                 const CandDesc* __restrict__ cands,
+                                                 const CandState* __restrict__ states,
+                                                 uint32_t* __restrict__ corr,
+                                                 float* __restrict__ d2out, size_t ld) {
+  __shared__ f32x4 tl[2][NN_TC];
+  const int tid = threadIdx.x;
+  const int cand = blockIdx.y;
+  const float* __restrict__ tgt = cands[cand].tgt;
+  const uint32_t n_tgt = cands[cand].n_tgt;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = states[cand].Tf[i];
+
+  float px[NN_S], py[NN_S], pz[NN_S], best[NN_S];
+  uint32_t bchunk[NN_S];
+  const uint32_t base = blockIdx.x * (256 * NN_S);
+#pragma unroll
+  for (int s = 0; s < NN_S; ++s) {
+    const uint32_t i = base + s * 256 + tid;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < n_src) {
+      x = src[3 * (size_t)i + 0];
+      y = src[3 * (size_t)i + 1];
+      z = src[3 * (size_t)i + 2];
+    }
+    xform(T, x, y, z, px[s], py[s], pz[s]);
+    best[s] = 3.402823466e+38f;
+    bchunk[s] = 0;
+  }
+  const uint32_t nchunks = (n_tgt + NN_TC - 1) / NN_TC;
+  auto stage = [&](uint32_t c, int buf) {
+    const uint32_t j = c * NN_TC + tid;
+    f32x4 v = {NN_FAR, NN_FAR, NN_FAR, 0.f};
+    if (j < n_tgt) {
+      v.x = tgt[3 * (size_t)j + 0];
+      v.y = tgt[3 * (size_t)j + 1];
+      v.z = tgt[3 * (size_t)j + 2];
+    }
+    tl[buf][tid] = v;
+  };
+  if (nchunks) stage(0, 0);
+  __syncthreads();
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+    float m[NN_S];
+#pragma unroll
+    for (int s = 0; s < NN_S; ++s) m[s] = 3.402823466e+38f;
+#pragma unroll 8
+    for (int t = 0; t < NN_TC; t += 2) {
+      const f32x4 q0 = tl[buf][t];
+      const f32x4 q1 = tl[buf][t + 1];
+#pragma unroll
+      for (int s = 0; s < NN_S; ++s) {
+        const float d0 = dist2(px[s], py[s], pz[s], q0.x, q0.y, q0.z);
+        const float d1 = dist2(px[s], py[s], pz[s], q1.x, q1.y, q1.z);
+        m[s] = fminf(fminf(m[s], d0), d1);  // v_min3_f32
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NN_S; ++s) {
+      if (m[s] < best[s]) {  // strict: the earliest chunk holding the minimum wins
+        best[s] = m[s];
+        bchunk[s] = c;
+      }
+    }
+    __syncthreads();
+  }
+  // index recovery: first target of the winning chunk whose distance equals the minimum
+#pragma unroll
+  for (int s = 0; s < NN_S; ++s) {
+    const uint32_t i = base + s * 256 + tid;
+    if (i >= n_src) continue;
+    uint32_t bj = 0xFFFFFFFFu;
+    if (n_tgt) {
+      const uint32_t j0 = bchunk[s] * NN_TC;
+      const uint32_t j1 = (j0 + NN_TC) < n_tgt ? (j0 + NN_TC) : n_tgt;
+      for (uint32_t j = j0; j < j1; ++j) {
+        const float d = dist2(px[s], py[s], pz[s], tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1],
+                              tgt[3 * (size_t)j + 2]);
+        if (d == best[s]) {
+          bj = j;
+          break;
+        }
+      }
+    }
+    corr[(size_t)cand * ld + i] = bj;
+    d2out[(size_t)cand * ld + i] = best[s];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (moved source, matched target) pairs as 2 x float4, so the RANSAC scorer reads them coalesced.
+__global__ void gather_pairs_kernel(const float* __restrict__ src, uint32_t n_src,
+                                    const CandDesc* __restrict__ cands,
+                                    const CandState* __restrict__ states,
+                                    const uint32_t* __restrict__ corr, size_t ld,
+                                    f32x4* __restrict__ pairs) {
+  const int cand = blockIdx.y;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_src) return;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = states[cand].Tf[k];
+  float x, y, z;
+  xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], x, y, z);
+  const uint32_t j = corr[(size_t)cand * ld + i];
+  const float* t = cands[cand].tgt + 3 * (size_t)j;
+  pairs[((size_t)cand * ld + i) * 2 + 0] = f32x4{x, y, z, 0.f};
+  pairs[((size_t)cand * ld + i) * 2 + 1] = f32x4{t[0], t[1], t[2], 0.f};
+}
+
+// ---- fp64 3x3 helpers: the same operation sequence as oracle/reg_oracle.c --------------------
+__device__ inline void jacobi_eig3(double A[9], double V[9]) {
+  V[0] = 1; V[1] = 0; V[2] = 0;
+  V[3] = 0; V[4] = 1; V[5] = 0;
+  V[6] = 0; V[7] = 0; V[8] = 1;
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+    for (int e = 0; e < 3; ++e) {
+      const int p = (e == 2) ? 1 : 0, q = (e == 0) ? 1 : 2;
+      const double apq = A[3 * p + q];
+      if (apq == 0.0) continue;
+      const double app = A[3 * p + p], aqq = A[3 * q + q];
+      const double theta = (aqq - app) / (2.0 * apq);
+      const double at = theta < 0 ? -theta : theta;
+      double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+      if (theta < 0) t = -t;
+      const double c = 1.0 / sqrt(t * t + 1.0);
+      const double s = t * c;
+      for (int k = 0; k < 3; ++k) {
+        const double akp = A[3 * k + p], akq = A[3 * k + q];
+        A[3 * k + p] = c * akp - s * akq;
+        A[3 * k + q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; ++k) {
+        const double apk = A[3 * p + k], aqk = A[3 * q + k];
+        A[3 * p + k] = c * apk - s * aqk;
+        A[3 * q + k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; ++k) {
+        const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+        V[3 * k + p] = c * vkp - s * vkq;
+        V[3 * k + q] = s * vkp + c * vkq;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
+                                       const double qbar[3], double R[9], double t[3]) {
+  double A[9], V[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      A[3 * i + j] = (M[0 + i] * M[0 + j] + M[3 + i] * M[3 + j]) + M[6 + i] * M[6 + j];
+  jacobi_eig3(A, V);
+  int o0 = 0, o1 = 1, o2 = 2;
+  double l0 = A[0], l1 = A[4], l2 = A[8];
+  if (l1 > l0) { int ti = o0; o0 = o1; o1 = ti; double td = l0; l0 = l1; l1 = td; }
+  if (l2 > l1) { int ti = o1; o1 = o2; o2 = ti; double td = l1; l1 = l2; l2 = td; }
+  if (l1 > l0) { int ti = o0; o0 = o1; o1 = ti; double td = l0; l0 = l1; l1 = td; }
+  (void)o2; (void)l2;
+  double v1[3] = {V[0 + o0], V[3 + o0], V[6 + o0]};
+  double v2[3] = {V[0 + o1], V[3 + o1], V[6 + o1]};
+  double v3[3];
+  cross3(v1, v2, v3);
+  double u1[3], u2[3], u3[3];
+  for (int i = 0; i < 3; ++i) {
+    u1[i] = (M[3 * i + 0] * v1[0] + M[3 * i + 1] * v1[1]) + M[3 * i + 2] * v1[2];
+    u2[i] = (M[3 * i + 0] * v2[0] + M[3 * i + 1] * v2[1]) + M[3 * i + 2] * v2[2];
+  }
+  double n1 = sqrt((u1[0] * u1[0] + u1[1] * u1[1]) + u1[2] * u1[2]);
+  if (!(n1 > 1e-300)) {
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) t[i] = qbar[i] - pbar[i];
+    return;
+  }
+  for (int i = 0; i < 3; ++i) u1[i] = u1[i] / n1;
+  const double d12 = (u1[0] * u2[0] + u1[1] * u2[1]) + u1[2] * u2[2];
+  for (int i = 0; i < 3; ++i) u2[i] = u2[i] - d12 * u1[i];
+  double n2 = sqrt((u2[0] * u2[0] + u2[1] * u2[1]) + u2[2] * u2[2]);
+  if (!(n2 > 1e-300)) {
+    double ax[3] = {0, 0, 0};
+    const double a0 = u1[0] < 0 ? -u1[0] : u1[0], a1 = u1[1] < 0 ? -u1[1] : u1[1],
+                 a2 = u1[2] < 0 ? -u1[2] : u1[2];
+    ax[(a0 <= a1 && a0 <= a2) ? 0 : ((a1 <= a2) ? 1 : 2)] = 1.0;
+    cross3(u1, ax, u2);
+    n2 = sqrt((u2[0] * u2[0] + u2[1] * u2[1]) + u2[2] * u2[2]);
+  }
+  for (int i = 0; i < 3; ++i) u2[i] = u2[i] / n2;
+  cross3(u1, u2, u3);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = (v1[i] * u1[j] + v2[i] * u2[j]) + v3[i] * u3[j];
+  for (int i = 0; i < 3; ++i)
+    t[i] = qbar[i] - ((R[3 * i + 0] * pbar[0] + R[3 * i + 1] * pbar[1]) + R[3 * i + 2] * pbar[2]);
+}
+
+__device__ __forceinline__ uint32_t mulhi_idx(uint64_t u, uint32_t n) {
+  return (uint32_t)__umul64hi(u, (uint64_t)n);
+}
+
+// K5a.  One thread per (candidate, hypothesis).  pairs: [cand][ld][2] float4.
+__global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, uint32_t n,
+                                  const CandDesc* __restrict__ cands, uint64_t seed,
+                                  uint32_t n_hyp, float* __restrict__ Rt /* [cand][n_hyp][12] */,
+                                  uint32_t* __restrict__ valid) {
+  const int cand = blockIdx.y;
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hyp) return;
+  const size_t o = (size_t)cand * n_hyp + h;
+  valid[o] = 0;
+  if (n < 3) return;
+  const uint64_t key = synth::rng_key(seed, ((uint64_t)cands[cand].cand_id << 32) | (uint64_t)h);
+  uint64_t ctr = 0;
+  uint32_t s0 = mulhi_idx(synth::rng_draw(key, ctr++), n), s1 = s0, s2 = s0;
+  for (int tries = 0; tries < 16 && s1 == s0; ++tries) s1 = mulhi_idx(synth::rng_draw(key, ctr++), n);
+  for (int tries = 0; tries < 16 && (s2 == s0 || s2 == s1); ++tries)
+    s2 = mulhi_idx(synth::rng_draw(key, ctr++), n);
+  if (s0 == s1 || s0 == s2 || s1 == s2) return;
+  const uint32_t sidx[3] = {s0, s1, s2};
+  double p[3][3], q[3][3];
+  for (int k = 0; k < 3; ++k) {
+    const f32x4 pv = pairs[((size_t)cand * ld + sidx[k]) * 2 + 0];
+    const f32x4 qv = pairs[((size_t)cand * ld + sidx[k]) * 2 + 1];
+    p[k][0] = (double)pv.x; p[k][1] = (double)pv.y; p[k][2] = (double)pv.z;
+    q[k][0] = (double)qv.x; q[k][1] = (double)qv.y; q[k][2] = (double)qv.z;
+  }
+  double a[3], b[3], c[3];
+  for (int i = 0; i < 3; ++i) {
+    a[i] = p[1][i] - p[0][i];
+    b[i] = p[2][i] - p[0][i];
+  }
+  cross3(a, b, c);
+  const double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+  const double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+  const double cc = (c[0] * c[0] + c[1] * c[1]) + c[2] * c[2];
+  if (!(aa > 1e-12) || !(bb > 1e-12) || !(cc > 1e-6 * (aa * bb))) return;
+  double pbar[3], qbar[3], M[9];
+  for (int i = 0; i < 3; ++i) {
+    pbar[i] = ((p[0][i] + p[1][i]) + p[2][i]) / 3.0;
+    qbar[i] = ((q[0][i] + q[1][i]) + q[2][i]) / 3.0;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      M[3 * i + j] = ((p[0][i] - pbar[i]) * (q[0][j] - qbar[j]) +
+                      (p[1][i] - pbar[i]) * (q[1][j] - qbar[j])) +
+                     (p[2][i] - pbar[i]) * (q[2][j] - qbar[j]);
+  double Rd[9], td[3];
+  kabsch_from_cov(M, pbar, qbar, Rd, td);
+  float* out = Rt + o * 12;
+  for (int i = 0; i < 9; ++i) out[i] = (float)Rd[i];
+  for (int i = 0; i < 3; ++i) out[9 + i] = (float)td[i];
+  valid[o] = 1;
+}
+
+// K5b.  thread <-> hypothesis (R,t in registers); a chunk of SC correspondences per work-group
+// streams through LDS and is read as wave-uniform broadcasts.  grid = (hyp tiles, corr chunks, cand)
+constexpr int SC_CHUNK = 4096;
+constexpr int SC_STAGE = 256;
+
+__global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restrict__ pairs,
+                                                           size_t ld, uint32_t n, uint32_t n_hyp,
+                                                           const float* __restrict__ Rt,
+                                                           const uint32_t* __restrict__ valid,
+                                                           float thr2,
+                                                           uint32_t* __restrict__ inliers) {
+  __shared__ f32x4 sp[2 * SC_STAGE];
+  const int cand = blockIdx.z;
+  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  const bool hv = h < n_hyp && valid[(size_t)cand * n_hyp + h];
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = hv ? Rt[((size_t)cand * n_hyp + h) * 12 + i] : 0.f;
+  const uint32_t i0 = blockIdx.y * SC_CHUNK;
+  const uint32_t i1 = (i0 + SC_CHUNK) < n ? (i0 + SC_CHUNK) : n;
+  uint32_t cnt = 0;
+  for (uint32_t b = i0; b < i1; b += SC_STAGE) {
+    const uint32_t i = b + threadIdx.x;
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f}, qv = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // padding: never inlier
+    if (i < i1) {
+      pv = pairs[((size_t)cand * ld + i) * 2 + 0];
+      qv = pairs[((size_t)cand * ld + i) * 2 + 1];
+    }
+    __syncthreads();
+    sp[2 * threadIdx.x + 0] = pv;
+    sp[2 * threadIdx.x + 1] = qv;
+    __syncthreads();
+#pragma unroll 4
+    for (int t = 0; t < SC_STAGE; ++t) {
+      const f32x4 p = sp[2 * t], q = sp[2 * t + 1];
+      float x, y, z;
+      xform(T, p.x, p.y, p.z, x, y, z);
+      cnt += (dist2(x, y, z, q.x, q.y, q.z) < thr2) ? 1u : 0u;
+    }
+  }
+  if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);
+}
+
+// K5c.  best = max inliers, tie -> smallest h.  One work-group per candidate.
+__global__ __launch_bounds__(256) void ransac_best_kernel(const uint32_t* __restrict__ inliers,
+                                                          const uint32_t* __restrict__ valid,
+                                                          const float* __restrict__ Rt,
+                                                          uint32_t n_hyp, uint32_t n,
+                                                          float min_inlier_ratio,
+                                                          CandState* __restrict__ states) {
+  __shared__ unsigned long long best_sh[256];
+  const int cand = blockIdx.x;
+  unsigned long long best = 0;  // (inliers << 32) | (0xFFFFFFFF - h): larger is better
+  for (uint32_t h = threadIdx.x; h < n_hyp; h += 256) {
+    if (!valid[(size_t)cand * n_hyp + h]) continue;
+    const uint32_t inl = inliers[(size_t)cand * n_hyp + h];
+    if (inl == 0) continue;
+    const unsigned long long key = ((unsigned long long)inl << 32) | (0xFFFFFFFFu - h);
+    best = key > best ? key : best;
+  }
+  best_sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o && best_sh[threadIdx.x + o] > best_sh[threadIdx.x])
+      best_sh[threadIdx.x] = best_sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    CandState& st = states[cand];
+    const unsigned long long b = best_sh[0];
+    if (b == 0) {
+      st.best_h = 0xFFFFFFFFu;
+      st.best_inl = 0;
+      st.ok = 0;
+    } else {
+      const uint32_t h = 0xFFFFFFFFu - (uint32_t)b;
+      st.best_h = h;
+      st.best_inl = (uint32_t)(b >> 32);
+      uint32_t min_inl = (uint32_t)(min_inlier_ratio * (float)n);
+      if (min_inl < 3) min_inl = 3;
+      st.ok = st.best_inl >= min_inl;
+      for (int i = 0; i < 12; ++i) st.bestRt[i] = Rt[((size_t)cand * n_hyp + h) * 12 + i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6a.  fp64 raw moments over pairs.  MODE 0 (ICP): source moved by Tf on the fly, targets via
+// corr; optional gate d2 < gate2 on the pair distance.  MODE 1 (RANSAC refit): pre-gathered pairs,
+// gate = inlier of states[cand].bestRt.  Each work-group writes 17 partial sums
+// (n, sp[3], sq[3], spq[9], sum_d2_all) -- reduced in a fixed order by solve_kernel.
+constexpr int ACC_THREADS = 256;
+constexpr int ACC_PER_BLOCK = 2048;
+constexpr int ACC_NV = 17;
+
+template <int MODE>
+__global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
+    const float* __restrict__ src, uint32_t n_src, const CandDesc* __restrict__ cands,
+    const CandState* __restrict__ states, const uint32_t* __restrict__ corr,
+    const float* __restrict__ d2in, const f32x4* __restrict__ pairs, size_t ld, float gate2,
+    double* __restrict__ partials /* [cand][nblocks][ACC_NV] */) {
+  __shared__ double red[ACC_THREADS / 64][ACC_NV];
+  const int cand = blockIdx.y;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = (MODE == 0) ? states[cand].Tf[k] : states[cand].bestRt[k];
+  double v[ACC_NV];
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+  const uint32_t b0 = blockIdx.x * ACC_PER_BLOCK;
+  for (uint32_t i = b0 + threadIdx.x; i < b0 + ACC_PER_BLOCK && i < n_src; i += ACC_THREADS) {
+    float px, py, pz, qx, qy, qz;
+    bool use;
+    if (MODE == 0) {
+      xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], px, py, pz);
+      const uint32_t j = corr[(size_t)cand * ld + i];
+      const float* t = cands[cand].tgt + 3 * (size_t)j;
+      qx = t[0]; qy = t[1]; qz = t[2];
+      const float d2 = d2in[(size_t)cand * ld + i];
+      v[16] += (double)d2;
+      use = !(gate2 > 0.f) || (d2 < gate2);
+    } else {
+      const f32x4 p = pairs[((size_t)cand * ld + i) * 2 + 0];
+      const f32x4 q = pairs[((size_t)cand * ld + i) * 2 + 1];
+      px = p.x; py = p.y; pz = p.z;
+      qx = q.x; qy = q.y; qz = q.z;
+      float x, y, z;
+      xform(T, px, py, pz, x, y, z);
+      use = dist2(x, y, z, qx, qy, qz) < gate2;
+    }
+    if (use) {
+      const double P[3] = {(double)px, (double)py, (double)pz};
+      const double Q[3] = {(double)qx, (double)qy, (double)qz};
+      v[0] += 1.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        v[1 + a] += P[a];
+        v[4 + a] += Q[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += P[a] * Q[b];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) {
+    double x = v[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[w][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_NV) {
+    double s = 0.0;
+    for (int ww = 0; ww < ACC_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
+    partials[((size_t)cand * gridDim.x + blockIdx.x) * ACC_NV + threadIdx.x] = s;
+  }
+}
+
+// K6b.  One thread per candidate: reduce the partials in block order, Kabsch, compose.
+// MODE 0 (ICP step): T <- dT * T.   MODE 1 (RANSAC refit): T <- T_r * T0, falling back to the
+// un-refitted best hypothesis when fewer than 3 inliers, or to T0 when no hypothesis was valid.
+template <int MODE>
+__global__ void solve_kernel(const double* __restrict__ partials, int nblocks, int n_cand,
+                             CandState* __restrict__ states) {
+  const int cand = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cand >= n_cand) return;
+  CandState& st = states[cand];
+  double v[ACC_NV];
+  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int k = 0; k < ACC_NV; ++k) v[k] += partials[((size_t)cand * nblocks + b) * ACC_NV + k];
+  double Rd[9], td[3];
+  bool have = false;
+  if (MODE == 0) {
+    if (st.frozen) return;
+    st.sum_d2 = v[16];
+    if (v[0] < 3.0) {
+      st.frozen = 1;
+      return;
+    }
+  } else {
+    if (st.best_h == 0xFFFFFFFFu) return;  // keep T0
+    if (v[0] < 3.0) {
+      for (int i = 0; i < 9; ++i) Rd[i] = (double)st.bestRt[i];
+      for (int i = 0; i < 3; ++i) td[i] = (double)st.bestRt[9 + i];
+      have = true;
+    }
+  }
+  if (!have) {
+    const double cnt = v[0];
+    const double inv = 1.0 / cnt;
+    double pbar[3], qbar[3], M[9];
+    for (int a = 0; a < 3; ++a) {
+      pbar[a] = v[1 + a] * inv;
+      qbar[a] = v[4 + a] * inv;
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) M[3 * a + b] = v[7 + 3 * a + b] - cnt * (pbar[a] * qbar[b]);
+    kabsch_from_cov(M, pbar, qbar, Rd, td);
+  }
+  // (Rd,td) o (Td)
+  double Rn[9], tn[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      Rn[3 * i + j] = (Rd[3 * i + 0] * st.Td[0 + j] + Rd[3 * i + 1] * st.Td[3 + j]) +
+                      Rd[3 * i + 2] * st.Td[6 + j];
+    tn[i] = ((Rd[3 * i + 0] * st.Td[9] + Rd[3 * i + 1] * st.Td[10]) + Rd[3 * i + 2] * st.Td[11]) +
+            td[i];
+  }
+  for (int i = 0; i < 9; ++i) {
+    st.Td[i] = Rn[i];
+    st.Tf[i] = (float)Rn[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    st.Td[9 + i] = tn[i];
+    st.Tf[9 + i] = (float)tn[i];
+  }
+}
+
+// sum of the NN pass's d2 only (used when RANSAC runs but ICP does not, to report rmse)
+__global__ void sumd2_kernel(const float* __restrict__ d2in, size_t ld, uint32_t n, int n_cand,
+                             CandState* __restrict__ states) {
+  __shared__ double red[256];
+  const int cand = blockIdx.x;
+  double s = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) s += (double)d2in[(size_t)cand * ld + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) states[cand].sum_d2 = red[0];
+}
+
+}  // namespace reg
+}  // namespace gloc

@@ -31,7 +31,7 @@ constexpr uint64_t TAG_NOISE = 0x6E6F697365ULL;
 
 // kind 0: iid N(0,1)/sqrt(dim).  kind 1: anchored trajectory, stride 16, noise 0.05
 // (descriptors_traj in synth.py: ((1-t) a_k + t a_{k+1}) + 0.05 noise).
-__global__ void fill_kernel(int kind, uint64_t seed, uint64_t first_row, size_t n, size_t dim,
+static __global__ void fill_kernel(int kind, uint64_t seed, uint64_t first_row, size_t n, size_t dim,
                             float scale, float* __restrict__ out) {
   const size_t total = n * dim;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;

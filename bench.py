@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- localization queries/sec (kNN + top-20 registration) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one localization query through the hot path, everything resident in HBM when the timed
+region starts:  descriptor top-20 (gloc_knn_search_device) -> the 20 retrieved candidate scans ->
+batched RANSAC(3000) + ICP(20) registration (gloc_reg_batch_ids) -> lowest-rank successful candidate.
+
+N = 1  (BASELINE.json configs[3], the configuration the metric is quoted on):
+        KITTI-00-sized database, 4541 places x 4096-D, ~124k-point scans.
+N > 1  (configs[4] + [3]): 1M x 4096 database interleave-sharded over the N ranks, per-shard top-k
+        all-gathered over RCCL/xGMI and merged on every rank; candidates registered on the ranks that
+        own their scans, results combined with one all-reduce.  Total work per step is fixed
+        ("strong" scaling).
+
+Prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel (K4 point-NN,
+HIP-event timed inside the timed region on the stream it runs on) and the `cpu_baseline` object
+(the CPU oracle timed on this box's host cores, rank 0, N = 1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIM = 4096
+TOP_K = 20
+N_PLACES_1GPU = 4541          # KITTI odometry 00 (dataset/kitti_i2i.py:46 of the reference)
+N_PLACES_SHARDED = 1_000_000  # BASELINE.json configs[4]
+SCAN_POOL = 24                # distinct synthetic scans; place g carries scan g % SCAN_POOL
+QUERY_POOL = 4
+RANSAC_ITERS = 3000           # registration/loop_detector.cpp:257
+ICP_ITERS = 20                # BASELINE.json configs[2]
+DB_SEED = 4001
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+FLOP_PER_PAIR = 8             # 3 sub + 3 mul + 2 add per (source, target) pair
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def build_scans(n_pool, n_query):
+    """Procedural world, a short drive: pool scan s at pose P_s, query scans between poses."""
+    from gloc3d_amd import synth
+    w = synth.make_world(1001)
+    pool, qs = [], []
+    for s in range(n_pool):
+        T = synth.se3(0.8 * (s - n_pool / 2), (0.5 * s, 0.1 * s, 0.0))
+        pool.append(np.ascontiguousarray(synth.lidar_scan(w, T, seed=3000 + s)[:, :3]))
+    for s in range(n_query):
+        j = (s * 5 + 3) % n_pool
+        T = synth.se3(0.8 * (j - n_pool / 2) + 1.5, (0.5 * j + 0.3, 0.1 * j - 0.2, 0.02))
+        qs.append(np.ascontiguousarray(synth.lidar_scan(w, T, seed=9000 + s)[:, :3]))
+    return pool, qs
+
+
+def cpu_baseline(pool, qscans, n_places):
+    """The CPU oracle on this host, 1 thread (the reference's kNN and registration are
+    single-threaded): kNN of one query + full registration of ONE of its 20 candidates,
+    extrapolated to 20 candidates."""
+    import oracle
+    from gloc3d_amd import synth
+    oracle.build(ref=False)
+    db = synth.descriptors_traj(DB_SEED, 0, n_places, DIM)
+    q = synth.queries_near(DB_SEED, [1234], DIM)
+    t0 = time.time()
+    oracle.knn_search(db, q, TOP_K)
+    t_knn = time.time() - t0
+    t0 = time.time()
+    oracle.reg_one(qscans[0], pool[3], cand_id=0, ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
+    t_cand = time.time() - t0
+    per_query = t_knn + TOP_K * t_cand
+    return {"value": 1.0 / per_query, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"1 query: kNN over {n_places}x{DIM} ({t_knn*1e3:.0f} ms) + RANSAC{RANSAC_ITERS}"
+                      f"+ICP{ICP_ITERS} registration of 1 of its {TOP_K} candidates "
+                      f"({t_cand:.1f} s, ~124k-pt scans), extrapolated x{TOP_K} candidates",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--places", type=int, default=0, help="override the database size")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    import torch.distributed as dist
+    from gloc3d_amd import capi, sharded, synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_places = args.places or (N_PLACES_1GPU if world == 1 else N_PLACES_SHARDED)
+    n_steps, n_warm = args.steps, args.warmup
+    t_setup = time.time()
+
+    # ---- resident state -----------------------------------------------------------------------
+    index = capi.KnnIndex(DIM, device=local_rank)
+    n_local = len(sharded.shard_rows(n_places, rank, world))
+    index.reserve(n_local)
+    index.add_synthetic(1, DB_SEED, rank, n_local, row_stride=world)   # this rank's interleaved shard
+    index.synchronize()
+    log(f"database: {n_places} x {DIM} ({n_local} rows on rank 0), generated on device")
+
+    pool, qscans = build_scans(SCAN_POOL, QUERY_POOL)
+    reg = capi.Registrar(device=local_rank)
+    reg.set_option(capi.REG_OPT_PROFILE, 1)
+    pool_ids = [reg.scan_upload(p) for p in pool]
+    q_ids = [reg.scan_upload(q) for q in qscans]
+    params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
+    mean_pts = float(np.mean([p.shape[0] for p in pool]))
+    log(f"scans: {SCAN_POOL} pool + {QUERY_POOL} query scans, ~{mean_pts:.0f} pts each, resident")
+
+    # queries: noisy copies of database places (replicated on every rank)
+    total = n_steps + n_warm
+    q_rows = (np.arange(total, dtype=np.int64) * 977 + 211) % n_places
+    queries = torch.from_numpy(synth.queries_near(DB_SEED, q_rows, DIM)).to(dev)
+
+    knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank))
+    base_register = sharded.hip_local_register(reg, params)
+
+    def local_register(q_id, local_rows, ranks):
+        # place g = local_row * world + rank carries pool scan g % SCAN_POOL
+        g = np.asarray(local_rows, np.int64) * world + rank
+        return base_register(q_id, [pool_ids[int(x) % SCAN_POOL] for x in g], ranks)
+
+    sreg = sharded.ShardedRegistrar(rank, world, local_register)
+    pairs_per_launch = []
+
+    def step(i):
+        idx, d2 = knn.search(queries[i:i + 1], TOP_K)
+        cand = idx[0].cpu().numpy()                       # global place ids, retrieval order
+        table = sreg.register(q_ids[i % QUERY_POOL], cand, dev)
+        sel = sreg.select_first_ok(table)
+        if i >= n_warm:
+            mine = cand[(cand >= 0) & (cand % world == rank)]
+            nq = qscans[i % QUERY_POOL].shape[0]
+            pairs_per_launch.append(float(nq) * float(sum(pool[int(g) % SCAN_POOL].shape[0] for g in mine)))
+        return cand, sel, table
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"setup {time.time() - t_setup:.1f} s; warmup {n_warm}, timing {n_steps} steps")
+    for i in range(n_warm):
+        cand, sel, _ = step(i)
+        assert cand[0] == q_rows[i], f"retrieval sanity: top-1 {cand[0]} != query place {q_rows[i]}"
+    fence()
+    reg.profile_reset()
+    t0 = time.time()
+    sels = []
+    for i in range(n_warm, total):
+        cand, sel, table = step(i)
+        sels.append(sel)
+    fence()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (K4 point-NN), from the HIP events of the timed region --
+    nn_ms, nn_launches = reg.profile("nn")
+    stage_ms = {n: reg.profile(n)[0] for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve", "transform")}
+    passes = 1 + ICP_ITERS
+    avg_pairs = float(np.mean(pairs_per_launch)) if pairs_per_launch else 0.0
+    avg_launch_s = (nn_ms / max(nn_launches, 1)) * 1e-3
+    achieved = FLOP_PER_PAIR * avg_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+    roofline = {"kernel": "gloc::reg::nn_kernel", "bound": "mfma", "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": None,
+                "note": f"algorithmic {FLOP_PER_PAIR} flop/pair x {avg_pairs:.3e} pairs/launch "
+                        f"(rank 0) / {avg_launch_s*1e3:.3f} ms avg over {nn_launches} launches; "
+                        f"fp32 peak (vector = MFMA) {PEAK_FP32_TFLOPS} TF"}
+
+    out = {
+        "metric": "localization queries/sec (kNN+top-20 reg), KITTI-00-sized DB",
+        "value": n_steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": n_steps,
+        "warmup": n_warm, "ms_per_step": elapsed / n_steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("cfgD: KITTI-00-sized DB " if world == 1 else "cfgE+D: sharded DB ")
+                               + f"{n_places}x{DIM} fp32, 1 query/step -> top-{TOP_K} -> {TOP_K} candidate "
+                                 f"scans (~{mean_pts:.0f} pts) x (RANSAC {RANSAC_ITERS} + ICP {ICP_ITERS})",
+                   "places": n_places, "dim": DIM, "top_k": TOP_K, "points_per_scan": int(mean_pts),
+                   "ransac_iters": RANSAC_ITERS, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
+                   "parallelism": "1 gpu" if world == 1 else
+                   f"db rows + candidates interleave-sharded over {world} ranks; all-gather top-k, all-reduce poses"},
+        "roofline": roofline,
+        "stage_ms_per_step": {k_: v / n_steps for k_, v in stage_ms.items()},
+        "selected_candidate_rank": sels,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("timing the CPU oracle (bounded sample, ~30 s) ...")
+        out["cpu_baseline"] = cpu_baseline(pool, qscans, n_places)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,7 +47,10 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        # Linked WITHOUT a NEEDED entry for libamdhip64: the host process decides which HIP runtime
+        # it runs on (PyTorch bundles its own; two runtimes in one process cannot share the GPU).
+        # gloc3d_amd.capi preloads one with RTLD_GLOBAL; the C++ command lines link /opt/rocm's.
+        run(["g++", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 
@@ -66,7 +69,8 @@ def build_cli(force=False, verbose=False):
         if force or _stale(out, deps):
             cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "include"),
                    "-I" + os.path.join(CSRC, "host"), src, "-o", out, "-L" + LIBDIR, "-lgloc3d",
-                   "-Wl,-rpath,$ORIGIN/../lib"]
+                   "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib",
+                   "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -72,21 +72,45 @@ _PROTOS = [
     ("gloc_reg_scan_upload", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_reg_scan_count", _i, [_vp, C.POINTER(_sz)]),
     ("gloc_reg_scan_clear", _i, [_vp]),
-    ("gloc_reg_batch", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp,
+    ("gloc_reg_batch", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp,
                             C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
-    ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
+    ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
+                                _vp]),
     ("gloc_reg_select_first_ok", _i, [_vp, _sz]),
     ("gloc_reg_nn", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     ("gloc_reg_ransac_hypotheses", _i, [_vp, _vp, _vp, _vp, _sz, _u64, _u32, _u32, _vp, _vp, _vp,
                                         C.c_float]),
     ("gloc_reg_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_reg_profile_reset", _i, [_vp]),
-    ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz]),
-    ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _vp]),
+    ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz, _u64]),
+    ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _u64, _vp]),
 ]
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    """libgloc3d.so carries no NEEDED entry for the HIP runtime: exactly one must be in the process.
+    PyTorch bundles its own libamdhip64; when torch is installed we run on that copy so that torch
+    tensors, torch.distributed (RCCL) and our kernels share one runtime.  GLOC3D_HIP_RUNTIME
+    overrides the choice."""
+    cands = []
+    if os.environ.get("GLOC3D_HIP_RUNTIME"):
+        cands.append(os.environ["GLOC3D_HIP_RUNTIME"])
+    try:
+        import torch  # noqa: F401  (loads its bundled runtime)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for p in cands:
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return p
+        except OSError:
+            continue
+    raise RuntimeError("no HIP runtime (libamdhip64.so) found: " + ", ".join(cands))
 
 
 def lib():
@@ -97,6 +121,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -m gloc3d_amd.build or __graft_entry__.build()); there is no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in _PROTOS:
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
@@ -162,8 +187,8 @@ class KnnIndex:
     def add_device(self, dev_ptr, n):
         check(lib().gloc_knn_add_device(self._h, C.c_void_p(dev_ptr), n))
 
-    def add_synthetic(self, kind, seed, first_row, n):
-        check(lib().gloc_knn_add_synthetic(self._h, kind, seed, first_row, n))
+    def add_synthetic(self, kind, seed, first_row, n, row_stride=1):
+        check(lib().gloc_knn_add_synthetic(self._h, kind, seed, first_row, n, row_stride))
 
     def device_rows(self):
         p = C.c_void_p()
@@ -206,9 +231,9 @@ def topk_merge_device(device, stream, idx_ptr, d2_ptr, n_lists, nq, k, out_idx_p
                                        C.c_void_p(out_idx_ptr), C.c_void_p(out_d2_ptr)))
 
 
-def synth_fill_device(device, stream, kind, seed, first_row, n, dim, out_ptr):
+def synth_fill_device(device, stream, kind, seed, first_row, n, dim, out_ptr, row_stride=1):
     check(lib().gloc_synth_fill_device(device, C.c_void_p(stream or 0), kind, seed, first_row, n,
-                                       dim, C.c_void_p(out_ptr)))
+                                       dim, row_stride, C.c_void_p(out_ptr)))
 
 
 def default_reg_params(**over):
@@ -268,7 +293,7 @@ class Registrar:
         return (np.empty((n, 4, 4), np.float32), np.empty(n, np.float32), np.empty(n, np.uint32),
                 np.empty(n, np.int32))
 
-    def batch(self, q_xyz, cands, init_T=None, params=None):
+    def batch(self, q_xyz, cands, init_T=None, params=None, stream_ids=None):
         q = np.ascontiguousarray(q_xyz, np.float32).reshape(-1, 3)
         cs = [np.ascontiguousarray(c, np.float32).reshape(-1, 3) for c in cands]
         n = len(cs)
@@ -277,18 +302,22 @@ class Registrar:
         prm = params or default_reg_params()
         it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(n, 16)
         T, rmse, inl, ok = self._outs(n)
+        sid = None if stream_ids is None else np.ascontiguousarray(stream_ids, np.uint32)
         check(lib().gloc_reg_batch(self._h, _np_ptr(q), q.shape[0], ptrs, cnts, n,
+                                   None if sid is None else _np_ptr(sid),
                                    None if it is None else _np_ptr(it), C.byref(prm), _np_ptr(T),
                                    _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
         return dict(T=T, rmse=rmse, inliers=inl, ok=ok.astype(bool))
 
-    def batch_ids(self, q_id, cand_ids, init_T=None, params=None):
+    def batch_ids(self, q_id, cand_ids, init_T=None, params=None, stream_ids=None):
         ids = np.ascontiguousarray(cand_ids, np.uint32)
         n = ids.shape[0]
         prm = params or default_reg_params()
         it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(n, 16)
         T, rmse, inl, ok = self._outs(n)
+        sid = None if stream_ids is None else np.ascontiguousarray(stream_ids, np.uint32)
         check(lib().gloc_reg_batch_ids(self._h, int(q_id), _np_ptr(ids), n,
+                                       None if sid is None else _np_ptr(sid),
                                        None if it is None else _np_ptr(it), C.byref(prm),
                                        _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
         return dict(T=T, rmse=rmse, inliers=inl, ok=ok.astype(bool))

@@ -379,14 +379,15 @@ int gloc_knn_add_device(gloc_knn* h, const float* d_rows, size_t n) {
   return GLOC_OK;
 }
 
-int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n) {
+int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n,
+                           uint64_t row_stride) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   GLOC_REQUIRE(kind == 0 || kind == 1, GLOC_ERR_INVALID, "kind must be 0 (iid) or 1 (trajectory)");
   if (n == 0) return GLOC_OK;
   GLOC_REQUIRE(h->n + n < (1ull << 32) - 1, GLOC_ERR_INVALID, "database limited to 2^32-2 rows");
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_TRY(ensure_rows(h, h->n + n));
-  gloc::synth::launch_fill(h->stream, kind, seed, first_row, n, h->dim,
+  gloc::synth::launch_fill(h->stream, kind, seed, first_row, n, h->dim, row_stride ? row_stride : 1,
                            h->rows.as<float>() + h->n * h->dim);
   GLOC_HIP(hipGetLastError());
   GLOC_TRY(update_norms(h, h->n, n));
@@ -395,12 +396,14 @@ int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_
 }
 
 int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed,
-                           uint64_t first_row, size_t n, size_t dim, float* d_out) {
+                           uint64_t first_row, size_t n, size_t dim, uint64_t row_stride,
+                           float* d_out) {
   GLOC_REQUIRE(d_out || n == 0, GLOC_ERR_INVALID, "null output");
   GLOC_REQUIRE(kind == 0 || kind == 1, GLOC_ERR_INVALID, "kind must be 0 (iid) or 1 (trajectory)");
   GLOC_TRY(select_device(device));
   if (n == 0) return GLOC_OK;
-  gloc::synth::launch_fill((hipStream_t)hip_stream, kind, seed, first_row, n, dim, d_out);
+  gloc::synth::launch_fill((hipStream_t)hip_stream, kind, seed, first_row, n, dim,
+                           row_stride ? row_stride : 1, d_out);
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;
 }

@@ -302,9 +302,9 @@ int gloc_reg_scan_count(const gloc_reg* h, size_t* n_scans) {
 }
 
 int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* const* cand_xyz,
-                   const size_t* cand_npts, size_t n_cand, const float* init_T,
-                   const gloc_reg_params* params, float* out_T, float* out_rmse,
-                   uint32_t* out_inliers, int* out_ok) {
+                   const size_t* cand_npts, size_t n_cand, const uint32_t* cand_stream_ids,
+                   const float* init_T, const gloc_reg_params* params, float* out_T,
+                   float* out_rmse, uint32_t* out_inliers, int* out_ok) {
   GLOC_REQUIRE(h && out_T && (q_xyz || nq_pts == 0), GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_cand >= 1 && n_cand <= 4096 && cand_xyz && cand_npts, GLOC_ERR_INVALID,
                "n_cand = %zu outside [1,4096] or null candidate arrays", n_cand);
@@ -325,7 +325,7 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   for (size_t c = 0; c < n_cand; ++c) {
     float* dst = h->tmp_tgt.as<float>() + off * 3;
     GLOC_TRY(upload_packed(h, cand_xyz[c], cand_npts[c], 3, dst));
-    cds[c] = CandDesc{dst, (uint32_t)cand_npts[c], (uint32_t)c};
+    cds[c] = CandDesc{dst, (uint32_t)cand_npts[c], cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c};
     off += cand_npts[c];
   }
   return run_batch(h, h->tmp_src.as<float>(), nq_pts, cds, init_T, params, out_T, out_rmse,
@@ -333,8 +333,9 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
 }
 
 int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
-                       size_t n_cand, const float* init_T, const gloc_reg_params* params,
-                       float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+                       size_t n_cand, const uint32_t* cand_stream_ids, const float* init_T,
+                       const gloc_reg_params* params, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, int* out_ok) {
   GLOC_REQUIRE(h && out_T && cand_scan_ids, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_cand >= 1 && n_cand <= 4096, GLOC_ERR_INVALID, "n_cand = %zu outside [1,4096]",
                n_cand);
@@ -346,7 +347,7 @@ int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_sca
     GLOC_REQUIRE(cand_scan_ids[c] < h->scans.size(), GLOC_ERR_INVALID, "unknown scan id %u",
                  cand_scan_ids[c]);
     const DevScan& s = h->scans[cand_scan_ids[c]];
-    cds[c] = CandDesc{s.xyz, (uint32_t)s.n, (uint32_t)c};
+    cds[c] = CandDesc{s.xyz, (uint32_t)s.n, cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c};
   }
   const DevScan& q = h->scans[q_scan_id];
   return run_batch(h, q.xyz, q.n, cds, init_T, params, out_T, out_rmse, out_inliers, out_ok);

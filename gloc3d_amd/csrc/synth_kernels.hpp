@@ -31,12 +31,13 @@ constexpr uint64_t TAG_NOISE = 0x6E6F697365ULL;
 
 // kind 0: iid N(0,1)/sqrt(dim).  kind 1: anchored trajectory, stride 16, noise 0.05
 // (descriptors_traj in synth.py: ((1-t) a_k + t a_{k+1}) + 0.05 noise).
-static __global__ void fill_kernel(int kind, uint64_t seed, uint64_t first_row, size_t n, size_t dim,
-                            float scale, float* __restrict__ out) {
+static __global__ void fill_kernel(int kind, uint64_t seed, uint64_t first_row, size_t n,
+                                   size_t dim, uint64_t row_stride, float scale,
+                                   float* __restrict__ out) {
   const size_t total = n * dim;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t row = first_row + i / dim;
+    const uint64_t row = first_row + (i / dim) * row_stride;
     const uint64_t c = i % dim;
     float v;
     if (kind == 0) {
@@ -58,12 +59,12 @@ static __global__ void fill_kernel(int kind, uint64_t seed, uint64_t first_row, 
 }
 
 inline void launch_fill(hipStream_t s, int kind, uint64_t seed, uint64_t first_row, size_t n,
-                        size_t dim, float* d_out) {
+                        size_t dim, uint64_t row_stride, float* d_out) {
   const float scale = (float)(1.0 / __builtin_sqrt((double)dim));
   const size_t total = n * dim;
   unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, kind, seed, first_row, n, dim,
-                     scale, d_out);
+                     row_stride, scale, d_out);
 }
 
 }  // namespace synth

@@ -1,0 +1,135 @@
+"""Multi-GPU hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+Sharding:
+  * descriptor database: place g lives on rank g % G at local row g // G (interleaved, so the
+    consecutive places a query retrieves spread over all ranks); queries are replicated; each rank
+    searches its shard, the per-shard top-k (d2, global index) lists are ALL-GATHERED (Q x k x 12 B
+    per rank: latency-bound, one fused buffer) and every rank runs the same G*k -> k merge (K3), so
+    the result is replicated and bit-equal to the single-GPU search.
+  * registration: candidate c of a query is registered by the rank that owns its scan
+    (g_c % G); results (pose, rmse, inliers, ok) are combined with one ALL-REDUCE of a small
+    zero-initialised table; the reference's selection rule (lowest-rank successful candidate,
+    registration/global_localization.cpp:519-572) is then evaluated identically on every rank.
+
+The orchestration below is backend-agnostic: `local_search`, `merge` and `local_register` default to
+the HIP C-ABI calls; the CPU `gloo` tests inject checker callables to exercise the collectives.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+I64_SENTINEL = -1  # UINT64_MAX reinterpreted: "no row"
+RESULT_COLS = 19   # 16 pose + rmse + inliers + ok
+
+
+def owner_rank(global_idx, world):
+    return global_idx % world
+
+
+def local_row(global_idx, world):
+    return global_idx // world
+
+
+def global_row(local_idx, rank, world):
+    return local_idx * world + rank
+
+
+def shard_rows(n_global, rank, world):
+    """Global ids of the places this rank owns, ascending."""
+    return np.arange(rank, n_global, world, dtype=np.int64)
+
+
+class ShardedKnn:
+    """Row-sharded exact top-k with an all-gather of per-shard lists."""
+
+    def __init__(self, rank, world, local_search, merge, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.local_search = local_search  # (q [Q,D] tensor, k) -> (local idx int64 [Q,k], d2 f32 [Q,k])
+        self.merge = merge                # (idx [G,Q,k], d2 [G,Q,k]) -> (idx [Q,k], d2 [Q,k])
+
+    def search(self, q, k):
+        li, ld = self.local_search(q, k)
+        gi = torch.where(li == I64_SENTINEL, li, li * self.world + self.rank)
+        if self.world == 1:
+            return gi, ld
+        # one fused buffer per rank: [Q, k, 3] int32 words = (idx lo, idx hi, d2 bits)
+        Q = gi.shape[0]
+        packed = torch.empty((Q, k, 3), dtype=torch.int32, device=gi.device)
+        packed[..., :2] = gi.contiguous().view(torch.int32).view(Q, k, 2)
+        packed[..., 2] = ld.contiguous().view(torch.int32)
+        gathered = torch.empty((self.world, Q, k, 3), dtype=torch.int32, device=gi.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        all_i = gathered[..., :2].contiguous().view(torch.int64).view(self.world, Q, k)
+        all_d = gathered[..., 2].contiguous().view(torch.float32)
+        return self.merge(all_i, all_d)
+
+
+class ShardedRegistrar:
+    """Candidate-sharded registration: each rank registers the candidates whose scans it owns."""
+
+    def __init__(self, rank, world, local_register, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        # (query handle, local scan ids [m], retrieval ranks [m]) -> float32 [m, RESULT_COLS]
+        self.local_register = local_register
+
+    def register(self, query, cand_global, device):
+        cand_global = np.asarray(cand_global, dtype=np.int64)
+        n = cand_global.shape[0]
+        table = torch.zeros((n, RESULT_COLS), dtype=torch.float32, device=device)
+        mine = np.nonzero((cand_global >= 0) & (cand_global % self.world == self.rank))[0]
+        if mine.size:
+            res = self.local_register(query, cand_global[mine] // self.world, mine.astype(np.uint32))
+            table[torch.as_tensor(mine, device=device)] = torch.as_tensor(res, device=device)
+        if self.world > 1:
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)  # disjoint rows: exact
+        return table
+
+    @staticmethod
+    def select_first_ok(table):
+        """Lowest retrieval rank whose registration succeeded, or -1 (global_localization.cpp:519)."""
+        ok = (table[:, 18] > 0.5).nonzero()
+        return int(ok[0, 0]) if ok.numel() else -1
+
+
+# ---- HIP-backed defaults ------------------------------------------------------------------------
+
+def hip_local_search(index):
+    """local_search over a gloc3d_amd.capi.KnnIndex holding this rank's shard (device tensors)."""
+    def fn(q, k):
+        Q = q.shape[0]
+        idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+        d2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        index.search_device(q.data_ptr(), Q, k, idx.data_ptr(), d2.data_ptr())
+        index.synchronize()
+        return idx, d2
+    return fn
+
+
+def hip_merge(device_ordinal):
+    from . import capi
+
+    def fn(all_i, all_d):
+        G, Q, k = all_i.shape
+        oi = torch.empty((Q, k), dtype=torch.int64, device=all_i.device)
+        od = torch.empty((Q, k), dtype=torch.float32, device=all_i.device)
+        capi.topk_merge_device(device_ordinal, torch.cuda.current_stream().cuda_stream,
+                               all_i.data_ptr(), all_d.data_ptr(), G, Q, k, oi.data_ptr(),
+                               od.data_ptr())
+        return oi, od
+    return fn
+
+
+def hip_local_register(registrar, params):
+    """local_register over a gloc3d_amd.capi.Registrar whose scan store holds this rank's scans
+    (local scan id = local row) plus the replicated query scans."""
+    def fn(query_scan_id, local_scan_ids, retrieval_ranks):
+        r = registrar.batch_ids(query_scan_id, np.asarray(local_scan_ids, np.uint32), params=params,
+                                stream_ids=retrieval_ranks)
+        m = len(local_scan_ids)
+        out = np.zeros((m, RESULT_COLS), np.float32)
+        out[:, :16] = r["T"].reshape(m, 16)
+        out[:, 16] = r["rmse"]
+        out[:, 17] = r["inliers"].astype(np.float32)  # < 2^24: exact
+        out[:, 18] = r["ok"].astype(np.float32)
+        return out
+    return fn

@@ -163,17 +163,21 @@ int gloc_reg_scan_clear(gloc_reg* h);
 
 /* Register one query scan against n_cand candidate scans (host buffers, packed xyz).
  * init_T: n_cand x 16 row-major 4x4 (query -> candidate frame) or NULL for identity.
+ * cand_stream_ids: RANSAC sampling stream of each candidate, or NULL for 0..n_cand-1 (its rank in
+ * the retrieval list).  A rank that registers only a subset of a query's candidates passes their
+ * ranks here so that the result is independent of how candidates are sharded over GPUs.
  * Outputs per candidate: out_T (n_cand x 16, query -> db), out_rmse, out_inliers, out_ok
- * (any may be NULL except out_T).  Candidate c uses RANSAC stream id c. */
+ * (any may be NULL except out_T). */
 int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* const* cand_xyz,
-                   const size_t* cand_npts, size_t n_cand, const float* init_T,
-                   const gloc_reg_params* params, float* out_T, float* out_rmse,
-                   uint32_t* out_inliers, int* out_ok);
+                   const size_t* cand_npts, size_t n_cand, const uint32_t* cand_stream_ids,
+                   const float* init_T, const gloc_reg_params* params, float* out_T,
+                   float* out_rmse, uint32_t* out_inliers, int* out_ok);
 
 /* Same with the query scan and the candidates taken from the scan store. */
 int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
-                       size_t n_cand, const float* init_T, const gloc_reg_params* params,
-                       float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok);
+                       size_t n_cand, const uint32_t* cand_stream_ids, const float* init_T,
+                       const gloc_reg_params* params, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, int* out_ok);
 
 /* The reference's selection rule: lowest-rank candidate whose registration succeeded
  * (registration/global_localization.cpp:519-572 stops at the first match()==true).
@@ -196,10 +200,13 @@ int gloc_reg_profile_reset(gloc_reg* h);
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).
  * kind 0: iid N(0,1)/sqrt(dim); kind 1: anchored trajectory (stride 16, noise 0.05).
- * Appends rows [first_row, first_row+n) of the global synthetic database to the handle. */
-int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n);
+ * Appends n rows of the global synthetic database to the handle: global rows first_row,
+ * first_row + row_stride, ... (row_stride = G gives rank first_row's interleaved shard). */
+int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_row, size_t n,
+                           uint64_t row_stride);
 int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed,
-                           uint64_t first_row, size_t n, size_t dim, float* d_out);
+                           uint64_t first_row, size_t n, size_t dim, uint64_t row_stride,
+                           float* d_out);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,9 @@ def lib():
         L.oracle_knn_search.argtypes = [_f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t,
                                         C.c_size_t, C.c_size_t, C.c_size_t, _u64p, _f32p]
         L.oracle_knn_search_mt.argtypes = L.oracle_knn_search.argtypes + [C.c_int]
+        L.oracle_recall_at.restype = C.c_size_t
+        L.oracle_recall_at.argtypes = [_u64p, C.c_size_t, C.c_size_t, _u64p, _u64p,
+                                       C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_float)]
         L.oracle_transform_points.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
         L.oracle_nn3.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _u32p, _f32p]
         L.oracle_nn3_grid.argtypes = L.oracle_nn3.argtypes
@@ -122,6 +125,22 @@ def knn_search(db, queries, k, first_row=0, last_row=None, threads=1):
     else:
         lib().oracle_knn_search(db, n, dim, queries, nq, k, first_row, last_row, idx, d2)
     return idx, d2
+
+
+def recall_at(idx, positives, k_values=(1, 5, 10, 20)):
+    """recall@N with the reference's first-hit semantics; positives = list of index lists."""
+    idx = np.ascontiguousarray(idx, np.uint64)
+    nq, k = idx.shape
+    off = np.zeros(nq + 1, np.uint64)
+    off[1:] = np.cumsum([len(p) for p in positives])
+    pos = np.ascontiguousarray(np.concatenate([np.asarray(p, np.uint64) for p in positives] +
+                                              [np.zeros(0, np.uint64)]), np.uint64)
+    if pos.size == 0:
+        pos = np.zeros(1, np.uint64)
+    kv = (C.c_int * len(k_values))(*k_values)
+    rec = (C.c_float * len(k_values))()
+    valid = lib().oracle_recall_at(idx, nq, k, pos, off, kv, len(k_values), rec)
+    return valid, list(rec)
 
 
 def ref_knn_search(db, queries, k):

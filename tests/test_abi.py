@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gloc3d.h declares, and refuses to
+compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gloc3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gloc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(capi):
+    L = capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gloc3d.h but not exported"
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version_and_defaults(capi):
+    L = capi.lib()
+    assert L.gloc_abi_version() == 1
+    p = capi.default_reg_params()
+    # constants mirrored from the reference: loop_detector.cpp:257, global_registration.cpp:242
+    assert p.ransac_iters == 3000 and abs(p.inlier_thresh - 0.6) < 1e-7 and p.icp_iters == 30
+    assert capi.reg_select_first_ok([0, 0, 1, 1]) == 2
+    assert capi.reg_select_first_ok([0, 0]) == -1
+
+
+def test_no_cpu_fallback_without_gpu(capi):
+    if capi.lib().gloc_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.GlocError) as e:
+        capi.KnnIndex(512)
+    assert e.value.code == 4  # GLOC_ERR_NODEVICE
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(capi.GlocError):
+        capi.Registrar()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gloc3d_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
+                assert "oracle/" not in txt.replace("oracle/reg_oracle.c", "").replace(
+                    "oracle/knn_oracle.c", ""), f

@@ -1,0 +1,84 @@
+"""CPU: the registration oracle -- pinned 3-D NN, known-answer Kabsch / RANSAC / ICP."""
+import numpy as np
+import pytest
+
+from util import bits, load_nn3_case
+
+
+def test_nn3_matches_reference_golden(oracle_mod):
+    src, tgt, g_idx, g_bits = load_nn3_case()
+    for grid in (False, True):
+        idx, d2 = oracle_mod.nn3(src, tgt, grid=grid)
+        assert (idx == g_idx).all()
+        assert (bits(d2) == g_bits).all()
+
+
+def test_nn3_grid_equals_bruteforce_with_ties_and_outliers(oracle_mod):
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(-30, 30, (3000, 3)).astype(np.float32)
+    tgt[100] = tgt[7]            # duplicate target: smallest index must win
+    src = np.concatenate([tgt[[7, 500]], rng.uniform(-60, 60, (500, 3)).astype(np.float32)])
+    a = oracle_mod.nn3(src, tgt)
+    b = oracle_mod.nn3(src, tgt, grid=True)
+    assert (a[0] == b[0]).all() and (bits(a[1]) == bits(b[1])).all()
+    assert a[0][0] == 7 and a[1][0] == 0
+
+
+def test_kabsch_recovers_rotation(oracle_mod):
+    from gloc3d_amd import synth
+    rng = np.random.default_rng(1)
+    T = synth.se3(33.0, (1.0, -2.0, 0.5), pitch_deg=5.0, roll_deg=-3.0)
+    P = rng.standard_normal((50, 3))
+    Q = P @ T[:3, :3].T + T[:3, 3]
+    pb, qb = P.mean(0), Q.mean(0)
+    M = (P - pb).T @ (Q - qb)
+    R = np.empty(9)
+    t = np.empty(3)
+    oracle_mod.lib().oracle_kabsch_from_cov(np.ascontiguousarray(M.reshape(9)), pb, qb, R, t)
+    assert np.abs(R.reshape(3, 3) - T[:3, :3]).max() < 1e-12
+    assert np.abs(t - T[:3, 3]).max() < 1e-12
+    # reflection case: planar points (rank 2) must still give a proper rotation
+    P[:, 2] = 0
+    Q = P @ T[:3, :3].T + T[:3, 3]
+    pb, qb = P.mean(0), Q.mean(0)
+    M = (P - pb).T @ (Q - qb)
+    oracle_mod.lib().oracle_kabsch_from_cov(np.ascontiguousarray(M.reshape(9)), pb, qb, R, t)
+    assert abs(np.linalg.det(R.reshape(3, 3)) - 1) < 1e-12
+    assert np.abs(R.reshape(3, 3) - T[:3, :3]).max() < 1e-9
+
+
+def test_ransac_sample_distinct_and_deterministic(oracle_mod):
+    s = np.empty(3, np.uint32)
+    seen = set()
+    for h in range(200):
+        oracle_mod.lib().oracle_ransac_sample(1234, 2, h, 10, s)
+        assert len(set(s.tolist())) == 3 and (s < 10).all()
+        seen.add(tuple(s.tolist()))
+    assert len(seen) > 100
+    a = s.copy()
+    oracle_mod.lib().oracle_ransac_sample(1234, 2, 199, 10, s)
+    assert (a == s).all()
+
+
+def test_registration_recovers_constructed_pose(oracle_mod):
+    # known-answer: target = rigidly moved copy of the source (+ small noise): exact correspondences
+    # exist, so RANSAC + ICP must recover the constructed SE(3)
+    from gloc3d_amd import synth
+    rng = np.random.default_rng(5)
+    P = rng.uniform(-20, 20, (1500, 3)).astype(np.float32)
+    T = synth.se3(4.0, (0.4, -0.3, 0.05))
+    Q = (P.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.005, P.shape)).astype(np.float32)
+    r = oracle_mod.reg_one(P, Q[rng.permutation(len(Q))], ransac_iters=300, icp_iters=15)
+    er, ep = oracle_mod.pose_error(T, r["T"])
+    assert ep < 5e-3 and er < 0.1 and r["ok"] and r["rmse"] < 0.02
+
+
+def test_pose_error_metric(oracle_mod):
+    from gloc3d_amd import synth
+    a = synth.se3(10.0, (1, 2, 3))
+    b = synth.se3(13.0, (1, 2, 4))
+    er, ep = oracle_mod.pose_error(a, b)
+    assert abs(er - 3.0) < 1e-3 and abs(ep - 1.0) < 1e-6
+    # ~180 degree flips are forgiven (global_localization.cpp:305)
+    er, _ = oracle_mod.pose_error(a, synth.se3(10.0 + 179.0, (1, 2, 3)))
+    assert abs(er - 1.0) < 1e-2

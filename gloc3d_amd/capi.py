@@ -16,7 +16,8 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
              5: "GLOC_ERR_STATE"}
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
-REG_OPT_PROFILE = 1
+REG_OPT_PROFILE, REG_OPT_NN_MODE = 1, 2
+REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
 SIZE_MAX = C.c_size_t(-1).value
 
 
@@ -82,6 +83,7 @@ _PROTOS = [
                                         C.c_float]),
     ("gloc_reg_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_reg_profile_reset", _i, [_vp]),
+    ("gloc_reg_nn_stats", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz, _u64]),
     ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _u64, _vp]),
 ]
@@ -351,6 +353,11 @@ class Registrar:
 
     def profile_reset(self):
         check(lib().gloc_reg_profile_reset(self._h))
+
+    def nn_stats(self):
+        c, n = C.c_uint64(), C.c_uint64()
+        check(lib().gloc_reg_nn_stats(self._h, C.byref(c), C.byref(n)))
+        return c.value, n.value
 
 
 def reg_select_first_ok(ok):

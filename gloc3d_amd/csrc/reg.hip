@@ -7,15 +7,22 @@
 #include <new>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.hpp"
+#include "nn_culled.hpp"
 #include "reg_kernels.hpp"
 
 using namespace gloc;
 using namespace gloc::reg;
 
+// A scan resident in HBM: original-order xyz plus its search index (Morton-sorted copy with the
+// original indices, chunk boxes, sorted keys, inverse permutation).  One allocation per scan.
 struct DevScan {
+  void* block = nullptr;
   float* xyz = nullptr;
   size_t n = 0;
+  ScanIndexDev idx{};
 };
 
 struct gloc_reg {
@@ -27,8 +34,13 @@ struct gloc_reg {
   DevBuf corr, d2, pairs;      // [cand][ld]
   DevBuf Rt, valid, inliers;   // RANSAC hypotheses
   DevBuf partials;
+  DevBuf ccands;                          // CulledCand[]
+  DevBuf sort_tmp, sort_keys, sort_vals, sort_perm;  // scan indexing scratch
+  DevBuf counters;                        // [0] = chunks evaluated by nn_culled_kernel
   std::vector<CandState> h_states;
   std::vector<CandDesc> h_cands;
+  int nn_mode = 0;                        // 0 culled (default), 1 exhaustive
+  uint64_t nn_launches = 0;
   Profiler prof;
 };
 
@@ -42,6 +54,73 @@ int upload_packed(gloc_reg* h, const float* pts, size_t n, size_t stride, float*
     GLOC_HIP(hipMemcpy2DAsync(d_dst, 3 * sizeof(float), pts, stride * sizeof(float),
                               3 * sizeof(float), n, hipMemcpyHostToDevice, h->stream));
   }
+  return GLOC_OK;
+}
+
+void free_scan(DevScan& s) {
+  if (s.block) (void)hipFree(s.block);
+  s = DevScan{};
+}
+
+// Allocate a scan, upload its points and build its search index (Morton sort + chunk boxes).
+int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* out) {
+  DevScan s;
+  s.n = n;
+  const size_t nch = (n + CH - 1) / CH;
+  const size_t n1 = std::max<size_t>(n, 1), c1 = std::max<size_t>(nch, 1);
+  // layout: pts4 | box_lo | box_hi | xyz | keys | inv   (16-byte aligned parts first)
+  const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1) + sizeof(float) * 3 * n1 + sizeof(uint32_t) * 2 * n1;
+  GLOC_HIP(hipMalloc(&s.block, bytes));
+  f32x4* p4 = reinterpret_cast<f32x4*>(s.block);
+  f32x4* lo = p4 + n1;
+  f32x4* hi = lo + c1;
+  s.xyz = reinterpret_cast<float*>(hi + c1);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * n1);
+  uint32_t* inv = keys + n1;
+  int rc = upload_packed(h, pts, n, stride, s.xyz);
+  if (rc != GLOC_OK) {
+    free_scan(s);
+    return rc;
+  }
+  // bounding box on the host (the caller's buffer is at hand) -> Morton grid of 1024^3 cells
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float v = pts[i * stride + a];
+      if (i == 0 || v < mn[a]) mn[a] = v;
+      if (i == 0 || v > mx[a]) mx[a] = v;
+    }
+  const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+  const float cell = std::max(0.25f, ext / 1023.0f);
+  s.idx = ScanIndexDev{p4, lo, hi, keys, inv, (uint32_t)n, (uint32_t)nch, mn[0], mn[1], mn[2], 1.0f / cell};
+  if (n) {
+    hipStream_t st = h->stream;
+    auto fail = [&](int code) { free_scan(s); return code; };
+    if (h->sort_keys.ensure(sizeof(uint32_t) * n, st) || h->sort_vals.ensure(sizeof(uint32_t) * n, st) ||
+        h->sort_perm.ensure(sizeof(uint32_t) * n, st))
+      return fail(GLOC_ERR_NOMEM);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.xyz,
+                       (uint32_t)n, mn[0], mn[1], mn[2], 1.0f / cell, h->sort_keys.as<uint32_t>(),
+                       h->sort_vals.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->sort_keys.as<uint32_t>(), keys,
+                                           h->sort_vals.as<uint32_t>(), h->sort_perm.as<uint32_t>(),
+                                           (int)n, 0, 30, st) != hipSuccess)
+      return fail(GLOC_ERR_HIP);
+    if (h->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), st)) return fail(GLOC_ERR_NOMEM);
+    if (hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, tmp_bytes, h->sort_keys.as<uint32_t>(), keys,
+                                           h->sort_vals.as<uint32_t>(), h->sort_perm.as<uint32_t>(),
+                                           (int)n, 0, 30, st) != hipSuccess)
+      return fail(GLOC_ERR_HIP);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.xyz,
+                       h->sort_perm.as<uint32_t>(), (uint32_t)n, p4, inv);
+    hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, st, p4, (uint32_t)n, lo, hi);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      set_err("scan indexing failed: %s", hipGetErrorString(hipGetLastError()));
+      return fail(GLOC_ERR_HIP);
+    }
+  }
+  *out = s;
   return GLOC_OK;
 }
 
@@ -60,27 +139,53 @@ void init_state(CandState& st, const float* T16) {
   st.best_h = 0xFFFFFFFFu;
 }
 
-int launch_nn(gloc_reg* h, const float* d_src, uint32_t n_src, int n_cand, size_t ld) {
+int launch_nn(gloc_reg* h, const DevScan& src, int n_cand, size_t ld, bool warm) {
   ProfScope ps(h->prof, "nn", h->stream);
-  dim3 grid((n_src + 256 * NN_S - 1) / (256 * NN_S), (unsigned)n_cand);
-  hipLaunchKernelGGL(nn_kernel, grid, dim3(256), 0, h->stream, d_src, n_src,
-                     h->cands.as<CandDesc>(), h->states.as<CandState>(), h->corr.as<uint32_t>(),
-                     h->d2.as<float>(), ld);
+  const uint32_t n_src = (uint32_t)src.n;
+  h->nn_launches++;
+  if (h->nn_mode == 1) {
+    dim3 grid((n_src + 256 * NN_S - 1) / (256 * NN_S), (unsigned)n_cand);
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(256), 0, h->stream, src.xyz, n_src,
+                       h->cands.as<CandDesc>(), h->states.as<CandState>(), h->corr.as<uint32_t>(),
+                       h->d2.as<float>(), ld);
+  } else {
+    dim3 grid((n_src + 256 * CS - 1) / (256 * CS), (unsigned)n_cand);
+    hipLaunchKernelGGL(nn_culled_kernel, grid, dim3(256), 0, h->stream, src.idx.pts, n_src,
+                       h->ccands.as<CulledCand>(), h->states.as<CandState>(),
+                       warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr,
+                       h->corr.as<uint32_t>(), h->d2.as<float>(), ld,
+                       h->prof.enabled ? h->counters.as<unsigned long long>()
+                                       : (unsigned long long*)nullptr);
+  }
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;
 }
 
 // The whole per-query pipeline, device resident: S1 -> S2 (RANSAC + refit) -> S3 (ICP).
-int run_batch(gloc_reg* h, const float* d_src, size_t n_src_sz, const std::vector<CandDesc>& cds,
-              const float* init_T, const gloc_reg_params* prm, float* out_T, float* out_rmse,
-              uint32_t* out_inliers, int* out_ok) {
-  const int n_cand = (int)cds.size();
-  const uint32_t n_src = (uint32_t)n_src_sz;
+int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>& tg,
+              const uint32_t* stream_ids, const float* init_T, const gloc_reg_params* prm,
+              float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  const int n_cand = (int)tg.size();
+  const uint32_t n_src = (uint32_t)src.n;
+  const float* d_src = src.xyz;
+  std::vector<CandDesc> cds(n_cand);
+  std::vector<CulledCand> ccs(n_cand);
+  for (int c = 0; c < n_cand; ++c) {
+    cds[c] = CandDesc{tg[c]->xyz, (uint32_t)tg[c]->n, stream_ids ? stream_ids[c] : (uint32_t)c};
+    ccs[c] = CulledCand{tg[c]->idx, tg[c]->xyz};
+  }
   const size_t ld = ((size_t)n_src + 63) & ~(size_t)63;
   hipStream_t s = h->stream;
   h->h_states.resize(n_cand);
   for (int c = 0; c < n_cand; ++c) init_state(h->h_states[c], init_T ? init_T + 16 * c : nullptr);
   GLOC_TRY(h->cands.ensure(sizeof(CandDesc) * n_cand, s));
+  GLOC_TRY(h->ccands.ensure(sizeof(CulledCand) * n_cand, s));
+  if (!h->counters.p) {
+    GLOC_TRY(h->counters.ensure(64, s));
+    GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 64, s));
+  }
+  GLOC_HIP(hipMemcpyAsync(h->ccands.p, ccs.data(), sizeof(CulledCand) * n_cand,
+                          hipMemcpyHostToDevice, s));
   GLOC_TRY(h->states.ensure(sizeof(CandState) * n_cand, s));
   GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * ld * n_cand, s));
   GLOC_TRY(h->d2.ensure(sizeof(float) * ld * n_cand, s));
@@ -91,6 +196,7 @@ int run_batch(gloc_reg* h, const float* d_src, size_t n_src_sz, const std::vecto
   GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states.data(), sizeof(CandState) * n_cand,
                           hipMemcpyHostToDevice, s));
   const bool can = n_src >= 3;
+  bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
   bool any_tgt = false;
   for (auto& c : cds) any_tgt |= c.n_tgt >= 1;
 
@@ -100,7 +206,8 @@ int run_batch(gloc_reg* h, const float* d_src, size_t n_src_sz, const std::vecto
     GLOC_TRY(h->Rt.ensure(sizeof(float) * 12 * (size_t)H * n_cand, s));
     GLOC_TRY(h->valid.ensure(sizeof(uint32_t) * (size_t)H * n_cand, s));
     GLOC_TRY(h->inliers.ensure(sizeof(uint32_t) * (size_t)H * n_cand, s));
-    GLOC_TRY(launch_nn(h, d_src, n_src, n_cand, ld));
+    GLOC_TRY(launch_nn(h, src, n_cand, ld, false));
+    have_corr = true;
     {
       ProfScope ps(h->prof, "transform", s);
       hipLaunchKernelGGL(gather_pairs_kernel, dim3((n_src + 255) / 256, n_cand), dim3(256), 0, s,
@@ -150,7 +257,8 @@ int run_batch(gloc_reg* h, const float* d_src, size_t n_src_sz, const std::vecto
   }
   const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
   for (uint32_t it = 0; it < prm->icp_iters && can && any_tgt; ++it) {
-    GLOC_TRY(launch_nn(h, d_src, n_src, n_cand, ld));
+    GLOC_TRY(launch_nn(h, src, n_cand, ld, have_corr));
+    have_corr = true;
     {
       ProfScope ps(h->prof, "accum", s);
       hipLaunchKernelGGL(accum_kernel<0>, dim3(nblocks, n_cand), dim3(ACC_THREADS), 0, s, d_src,
@@ -229,8 +337,7 @@ int gloc_reg_scan_clear(gloc_reg* h) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_HIP(hipStreamSynchronize(h->stream));
-  for (auto& s : h->scans)
-    if (s.xyz) (void)hipFree(s.xyz);
+  for (auto& s : h->scans) free_scan(s);
   h->scans.clear();
   return GLOC_OK;
 }
@@ -242,7 +349,8 @@ int gloc_reg_destroy(gloc_reg* h) {
   (void)gloc_reg_scan_clear(h);
   h->prof.destroy();
   for (DevBuf* b : {&h->tmp_src, &h->tmp_tgt, &h->cands, &h->states, &h->corr, &h->d2, &h->pairs,
-                    &h->Rt, &h->valid, &h->inliers, &h->partials})
+                    &h->Rt, &h->valid, &h->inliers, &h->partials, &h->ccands, &h->sort_tmp,
+                    &h->sort_keys, &h->sort_vals, &h->sort_perm, &h->counters})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -270,6 +378,12 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
     h->prof.enabled = value != 0;
     return GLOC_OK;
   }
+  if (option == GLOC_REG_OPT_NN_MODE) {
+    GLOC_REQUIRE(value == GLOC_REG_NN_CULLED || value == GLOC_REG_NN_EXHAUSTIVE, GLOC_ERR_INVALID,
+                 "bad nn mode %lld", (long long)value);
+    h->nn_mode = (int)value;
+    return GLOC_OK;
+  }
   set_err("unknown option %d", option);
   return GLOC_ERR_INVALID;
 }
@@ -282,14 +396,7 @@ int gloc_reg_scan_upload(gloc_reg* h, const float* pts, size_t n, size_t stride_
   GLOC_REQUIRE(n < (1ull << 31), GLOC_ERR_INVALID, "scan too large");
   GLOC_HIP(hipSetDevice(h->device));
   DevScan s;
-  s.n = n;
-  GLOC_HIP(hipMalloc((void**)&s.xyz, std::max<size_t>(n, 1) * 3 * sizeof(float)));
-  int rc = upload_packed(h, pts, n, stride_floats, s.xyz);
-  if (rc == GLOC_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GLOC_ERR_HIP;
-  if (rc != GLOC_OK) {
-    (void)hipFree(s.xyz);
-    return rc;
-  }
+  GLOC_TRY(make_scan(h, pts, n, stride_floats, &s));
   h->scans.push_back(s);
   *scan_id = (uint32_t)(h->scans.size() - 1);
   return GLOC_OK;
@@ -311,25 +418,24 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   GLOC_REQUIRE(nq_pts < (1ull << 31), GLOC_ERR_INVALID, "query scan too large");
   GLOC_TRY(check_params(params));
   GLOC_HIP(hipSetDevice(h->device));
-  size_t total = 0;
   for (size_t c = 0; c < n_cand; ++c) {
     GLOC_REQUIRE(cand_xyz[c] || cand_npts[c] == 0, GLOC_ERR_INVALID, "candidate %zu is null", c);
     GLOC_REQUIRE(cand_npts[c] < (1ull << 31), GLOC_ERR_INVALID, "candidate scan too large");
-    total += cand_npts[c];
   }
-  GLOC_TRY(h->tmp_src.ensure(std::max<size_t>(nq_pts, 1) * 3 * sizeof(float), h->stream));
-  GLOC_TRY(h->tmp_tgt.ensure(std::max<size_t>(total, 1) * 3 * sizeof(float), h->stream));
-  GLOC_TRY(upload_packed(h, q_xyz, nq_pts, 3, h->tmp_src.as<float>()));
-  std::vector<CandDesc> cds(n_cand);
-  size_t off = 0;
-  for (size_t c = 0; c < n_cand; ++c) {
-    float* dst = h->tmp_tgt.as<float>() + off * 3;
-    GLOC_TRY(upload_packed(h, cand_xyz[c], cand_npts[c], 3, dst));
-    cds[c] = CandDesc{dst, (uint32_t)cand_npts[c], cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c};
-    off += cand_npts[c];
+  // temporary resident copies (uploaded + indexed), released on return
+  std::vector<DevScan> tmp(n_cand + 1);
+  int rc = make_scan(h, q_xyz, nq_pts, 3, &tmp[0]);
+  for (size_t c = 0; rc == GLOC_OK && c < n_cand; ++c)
+    rc = make_scan(h, cand_xyz[c], cand_npts[c], 3, &tmp[c + 1]);
+  if (rc == GLOC_OK) {
+    std::vector<const DevScan*> tg(n_cand);
+    for (size_t c = 0; c < n_cand; ++c) tg[c] = &tmp[c + 1];
+    rc = run_batch(h, tmp[0], tg, cand_stream_ids, init_T, params, out_T, out_rmse, out_inliers,
+                   out_ok);
   }
-  return run_batch(h, h->tmp_src.as<float>(), nq_pts, cds, init_T, params, out_T, out_rmse,
-                   out_inliers, out_ok);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& s : tmp) free_scan(s);
+  return rc;
 }
 
 int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
@@ -342,15 +448,14 @@ int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_sca
   GLOC_REQUIRE(q_scan_id < h->scans.size(), GLOC_ERR_INVALID, "unknown query scan id %u", q_scan_id);
   GLOC_TRY(check_params(params));
   GLOC_HIP(hipSetDevice(h->device));
-  std::vector<CandDesc> cds(n_cand);
+  std::vector<const DevScan*> tg(n_cand);
   for (size_t c = 0; c < n_cand; ++c) {
     GLOC_REQUIRE(cand_scan_ids[c] < h->scans.size(), GLOC_ERR_INVALID, "unknown scan id %u",
                  cand_scan_ids[c]);
-    const DevScan& s = h->scans[cand_scan_ids[c]];
-    cds[c] = CandDesc{s.xyz, (uint32_t)s.n, cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c};
+    tg[c] = &h->scans[cand_scan_ids[c]];
   }
-  const DevScan& q = h->scans[q_scan_id];
-  return run_batch(h, q.xyz, q.n, cds, init_T, params, out_T, out_rmse, out_inliers, out_ok);
+  return run_batch(h, h->scans[q_scan_id], tg, cand_stream_ids, init_T, params, out_T, out_rmse,
+                   out_inliers, out_ok);
 }
 
 int gloc_reg_select_first_ok(const int* ok, size_t n_cand) {
@@ -369,24 +474,37 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const size_t ld = (n_src + 63) & ~(size_t)63;
-  GLOC_TRY(h->tmp_src.ensure(n_src * 3 * sizeof(float), s));
-  GLOC_TRY(h->tmp_tgt.ensure(std::max<size_t>(n_tgt, 1) * 3 * sizeof(float), s));
-  GLOC_TRY(h->cands.ensure(sizeof(CandDesc), s));
-  GLOC_TRY(h->states.ensure(sizeof(CandState), s));
-  GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * ld, s));
-  GLOC_TRY(h->d2.ensure(sizeof(float) * ld, s));
-  GLOC_TRY(upload_packed(h, src_xyz, n_src, 3, h->tmp_src.as<float>()));
-  GLOC_TRY(upload_packed(h, tgt_xyz, n_tgt, 3, h->tmp_tgt.as<float>()));
-  CandDesc cd{h->tmp_tgt.as<float>(), (uint32_t)n_tgt, 0};
+  DevScan src, tgt;
+  GLOC_TRY(make_scan(h, src_xyz, n_src, 3, &src));
+  int rc = make_scan(h, tgt_xyz, n_tgt, 3, &tgt);
+  auto done = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    free_scan(src);
+    free_scan(tgt);
+    return code;
+  };
+  if (rc != GLOC_OK) return done(rc);
+  if (h->cands.ensure(sizeof(CandDesc), s) || h->ccands.ensure(sizeof(CulledCand), s) ||
+      h->states.ensure(sizeof(CandState), s) || h->corr.ensure(sizeof(uint32_t) * ld, s) ||
+      h->d2.ensure(sizeof(float) * ld, s) || h->counters.ensure(64, s))
+    return done(GLOC_ERR_NOMEM);
+  CandDesc cd{tgt.xyz, (uint32_t)n_tgt, 0};
+  CulledCand cc{tgt.idx, tgt.xyz};
   CandState st;
   init_state(st, T16);
-  GLOC_HIP(hipMemcpyAsync(h->cands.p, &cd, sizeof(cd), hipMemcpyHostToDevice, s));
-  GLOC_HIP(hipMemcpyAsync(h->states.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
-  GLOC_TRY(launch_nn(h, h->tmp_src.as<float>(), (uint32_t)n_src, 1, ld));
-  GLOC_HIP(hipMemcpyAsync(out_idx, h->corr.p, sizeof(uint32_t) * n_src, hipMemcpyDeviceToHost, s));
-  GLOC_HIP(hipMemcpyAsync(out_d2, h->d2.p, sizeof(float) * n_src, hipMemcpyDeviceToHost, s));
-  GLOC_HIP(hipStreamSynchronize(s));
-  return GLOC_OK;
+  if (hipMemcpyAsync(h->cands.p, &cd, sizeof(cd), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(h->ccands.p, &cc, sizeof(cc), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(h->states.p, &st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess)
+    return done(GLOC_ERR_HIP);
+  rc = launch_nn(h, src, 1, ld, false);
+  if (rc != GLOC_OK) return done(rc);
+  if (hipMemcpyAsync(out_idx, h->corr.p, sizeof(uint32_t) * n_src, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(out_d2, h->d2.p, sizeof(float) * n_src, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    set_err("gloc_reg_nn: copy back failed: %s", hipGetErrorString(hipGetLastError()));
+    return done(GLOC_ERR_HIP);
+  }
+  return done(GLOC_OK);
 }
 
 int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* tgt_xyz,
@@ -436,6 +554,19 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   return GLOC_OK;
 }
 
+int gloc_reg_nn_stats(gloc_reg* h, uint64_t* chunks_evaluated, uint64_t* launches) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  unsigned long long c = 0;
+  if (h->counters.p) {
+    GLOC_HIP(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (chunks_evaluated) *chunks_evaluated = c;
+  if (launches) *launches = h->nn_launches;
+  return GLOC_OK;
+}
+
 int gloc_reg_profile(gloc_reg* h, const char* kernel, double* total_ms, uint64_t* launches) {
   GLOC_REQUIRE(h && kernel, GLOC_ERR_INVALID, "null argument");
   GLOC_HIP(hipSetDevice(h->device));
@@ -451,6 +582,8 @@ int gloc_reg_profile_reset(gloc_reg* h) {
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_HIP(hipStreamSynchronize(h->stream));
   h->prof.reset();
+  h->nn_launches = 0;
+  if (h->counters.p) GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 64, h->stream));
   return GLOC_OK;
 }
 

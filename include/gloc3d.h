@@ -151,7 +151,14 @@ int gloc_reg_destroy(gloc_reg* h);
 int gloc_reg_set_stream(gloc_reg* h, void* hip_stream);
 int gloc_reg_synchronize(gloc_reg* h);
 int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
-enum { GLOC_REG_OPT_PROFILE = 1 };
+enum {
+  GLOC_REG_OPT_PROFILE = 1, /* 1: bracket every kernel with HIP events (gloc_reg_profile) */
+  GLOC_REG_OPT_NN_MODE = 2  /* how S1 (exact 1-NN) is searched; the result is identical */
+};
+enum {
+  GLOC_REG_NN_CULLED = 0,    /* default: Morton-sorted scans, chunk boxes, skip what cannot win */
+  GLOC_REG_NN_EXHAUSTIVE = 1 /* every (source, target) pair */
+};
 
 /* Scan store: keep database scans resident in HBM (x,y,z packed fp32, n points).  Returns an id
  * usable in gloc_reg_batch_ids.  `stride_floats` is 3 for packed xyz or 4 for KITTI x,y,z,i
@@ -196,6 +203,9 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
  * "transform"), as gloc_knn_profile. */
 int gloc_reg_profile(gloc_reg* h, const char* kernel, double* total_ms, uint64_t* launches);
 int gloc_reg_profile_reset(gloc_reg* h);
+/* With profiling on: 128-target chunks evaluated by the culled 1-NN kernel (each against the 256
+ * source points of one wave) and 1-NN launches since the last gloc_reg_profile_reset. */
+int gloc_reg_nn_stats(gloc_reg* h, uint64_t* chunks_evaluated, uint64_t* launches);
 
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).

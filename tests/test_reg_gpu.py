@@ -27,9 +27,12 @@ def scans():
     return dict(A=np.ascontiguousarray(A), B=np.ascontiguousarray(B), C=np.ascontiguousarray(C_), T=T)
 
 
-@pytest.fixture(scope="module")
-def reg(capi):
+@pytest.fixture(scope="module", params=["culled", "exhaustive"])
+def reg(capi, request):
+    """Every registration test runs on both 1-NN search modes: the results must not differ."""
     r = capi.Registrar()
+    r.set_option(capi.REG_OPT_NN_MODE,
+                 capi.REG_NN_CULLED if request.param == "culled" else capi.REG_NN_EXHAUSTIVE)
     yield r
     r.close()
 
@@ -140,6 +143,22 @@ def test_scan_store_ids_equal_host_buffers(reg, capi, scans):
     with pytest.raises(capi.GlocError):
         reg.batch_ids(99, ids, params=prm)
     reg.scan_clear()
+
+
+def test_culled_equals_exhaustive_full_size(capi, scans):
+    """Full-size scans, warm-started ICP passes included: both search modes, bit for bit."""
+    outs = []
+    for mode in (capi.REG_NN_CULLED, capi.REG_NN_EXHAUSTIVE):
+        r = capi.Registrar()
+        r.set_option(capi.REG_OPT_NN_MODE, mode)
+        prm = capi.default_reg_params(ransac_iters=300, icp_iters=4)
+        outs.append(r.batch(scans["B"], [scans["A"], scans["C"]], params=prm))
+        outs.append(r.nn(scans["B"], scans["A"], scans["T"].astype(np.float32)))
+        r.close()
+    assert (bits(outs[0]["T"]) == bits(outs[2]["T"])).all()
+    assert (outs[0]["inliers"] == outs[2]["inliers"]).all()
+    assert (bits(outs[0]["rmse"]) == bits(outs[2]["rmse"])).all()
+    assert (outs[1][0] == outs[3][0]).all() and (bits(outs[1][1]) == bits(outs[3][1])).all()
 
 
 def test_degenerate_inputs(reg, capi):

@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--places", type=int, default=0, help="override the database size")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
                     help="1-NN search of the registration (identical results)")
     args = ap.parse_args()
@@ -107,11 +110,18 @@ def main():
     import torch.distributed as dist
     from gloc3d_amd import capi, sharded, synth
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            comm_dev = torch.device("cpu")
 
     n_places = args.places or (N_PLACES_1GPU if world == 1 else N_PLACES_SHARDED)
     n_steps, n_warm = args.steps, args.warmup
@@ -141,7 +151,8 @@ def main():
     q_rows = (np.arange(total, dtype=np.int64) * 977 + 211) % n_places
     queries = torch.from_numpy(synth.queries_near(DB_SEED, q_rows, DIM)).to(dev)
 
-    knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank))
+    knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank),
+                             comm_device=comm_dev)
     base_register = sharded.hip_local_register(reg, params)
 
     def local_register(q_id, local_rows, ranks):
@@ -149,7 +160,7 @@ def main():
         g = np.asarray(local_rows, np.int64) * world + rank
         return base_register(q_id, [pool_ids[int(x) % SCAN_POOL] for x in g], ranks)
 
-    sreg = sharded.ShardedRegistrar(rank, world, local_register)
+    sreg = sharded.ShardedRegistrar(rank, world, local_register, comm_device=comm_dev)
     pairs_per_launch = []
 
     def step(i):
@@ -183,7 +194,7 @@ def main():
     fence()
     elapsed = time.time() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

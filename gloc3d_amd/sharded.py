@@ -42,8 +42,9 @@ def shard_rows(n_global, rank, world):
 class ShardedKnn:
     """Row-sharded exact top-k with an all-gather of per-shard lists."""
 
-    def __init__(self, rank, world, local_search, merge, group=None):
+    def __init__(self, rank, world, local_search, merge, group=None, comm_device=None):
         self.rank, self.world, self.group = rank, world, group
+        self.comm_device = comm_device    # stage collectives through this device (gloo rehearsal)
         self.local_search = local_search  # (q [Q,D] tensor, k) -> (local idx int64 [Q,k], d2 f32 [Q,k])
         self.merge = merge                # (idx [G,Q,k], d2 [G,Q,k]) -> (idx [Q,k], d2 [Q,k])
 
@@ -57,8 +58,12 @@ class ShardedKnn:
         packed = torch.empty((Q, k, 3), dtype=torch.int32, device=gi.device)
         packed[..., :2] = gi.contiguous().view(torch.int32).view(Q, k, 2)
         packed[..., 2] = ld.contiguous().view(torch.int32)
-        gathered = torch.empty((self.world, Q, k, 3), dtype=torch.int32, device=gi.device)
+        # output laid out as the concatenation along dim 0 (the form every backend accepts)
+        cdev = self.comm_device or gi.device
+        packed = packed.to(cdev)
+        gathered = torch.empty((self.world * Q, k, 3), dtype=torch.int32, device=cdev)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        gathered = gathered.to(gi.device).view(self.world, Q, k, 3)
         all_i = gathered[..., :2].contiguous().view(torch.int64).view(self.world, Q, k)
         all_d = gathered[..., 2].contiguous().view(torch.float32)
         return self.merge(all_i, all_d)
@@ -67,8 +72,9 @@ class ShardedKnn:
 class ShardedRegistrar:
     """Candidate-sharded registration: each rank registers the candidates whose scans it owns."""
 
-    def __init__(self, rank, world, local_register, group=None):
+    def __init__(self, rank, world, local_register, group=None, comm_device=None):
         self.rank, self.world, self.group = rank, world, group
+        self.comm_device = comm_device
         # (query handle, local scan ids [m], retrieval ranks [m]) -> float32 [m, RESULT_COLS]
         self.local_register = local_register
 
@@ -81,7 +87,9 @@ class ShardedRegistrar:
             res = self.local_register(query, cand_global[mine] // self.world, mine.astype(np.uint32))
             table[torch.as_tensor(mine, device=device)] = torch.as_tensor(res, device=device)
         if self.world > 1:
-            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)  # disjoint rows: exact
+            t = table.to(self.comm_device) if self.comm_device else table
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # disjoint rows: exact
+            table = t.to(device)
         return table
 
     @staticmethod

@@ -1,0 +1,109 @@
+"""CPU: the multi-GPU orchestration (gloc3d_amd/sharded.py) over `gloo`, world_size 2 and 3.
+The HIP calls are replaced by checker callables (the oracle) -- what is under test is the sharding
+arithmetic, the fused all-gather, the replicated merge order and the candidate all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _checker_merge(all_i, all_d):
+    G, Q, k = all_i.shape
+    oi = torch.empty((Q, k), dtype=torch.int64)
+    od = torch.empty((Q, k), dtype=torch.float32)
+    for q in range(Q):
+        d = all_d[:, q].reshape(-1).numpy()
+        i = all_i[:, q].reshape(-1).numpy().astype(np.uint64)  # -1 -> UINT64_MAX sorts last
+        order = np.lexsort((i, d))[:k]
+        oi[q] = torch.from_numpy(i[order].astype(np.int64))
+        od[q] = torch.from_numpy(d[order])
+    return oi, od
+
+
+def _worker(rank, world, port, n_places, dim, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import oracle
+    from gloc3d_amd import sharded, synth
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rows = sharded.shard_rows(n_places, rank, world)
+    shard = np.concatenate([synth.descriptors_traj(77, int(g), 1, dim) for g in rows])
+
+    def local_search(q, k):
+        idx, d2 = oracle.knn_search(shard, q.numpy(), k)
+        return torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(d2)
+
+    knn = sharded.ShardedKnn(rank, world, local_search, _checker_merge)
+    q_rows = np.array([5, 40, n_places - 1, 17, 63])
+    q = torch.from_numpy(synth.queries_near(77, q_rows, dim))
+    gi, gd = knn.search(q, 20)
+
+    # candidate-sharded "registration": a deterministic stand-in keyed by (place, retrieval rank)
+    calls = []
+
+    def local_register(query, local_rows, ranks):
+        calls.append((list(map(int, local_rows)), list(map(int, ranks))))
+        out = np.zeros((len(local_rows), sharded.RESULT_COLS), np.float32)
+        for r, (l, c) in enumerate(zip(local_rows, ranks)):
+            g = int(l) * world + rank
+            out[r, :16] = np.arange(16) + g
+            out[r, 16] = 0.5 * c
+            out[r, 17] = g
+            out[r, 18] = 1.0 if (c >= 3 and g % 2 == 0) else 0.0
+        return out
+
+    sreg = sharded.ShardedRegistrar(rank, world, local_register)
+    table = sreg.register(0, gi[0].numpy(), torch.device("cpu"))
+    sel = sreg.select_first_ok(table)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), gi=gi.numpy(), gd=gd.numpy(), table=table.numpy(),
+             sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
+    from gloc3d_amd import sharded, synth
+    n_places, dim = 203, 64
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_places, dim, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    # single-database truth
+    db = synth.descriptors_traj(77, 0, n_places, dim)
+    q = synth.queries_near(77, np.array([5, 40, n_places - 1, 17, 63]), dim)
+    oi, od = oracle_mod.knn_search(db, q, 20)
+    for o in outs:                                   # replicated and equal to the 1-GPU result
+        assert (o["gi"].astype(np.uint64) == oi).all()
+        assert (o["gd"].view(np.uint32) == od.view(np.uint32)).all()
+        assert (o["table"] == outs[0]["table"]).all() and o["sel"] == outs[0]["sel"]
+    # every candidate registered exactly once, by its owner
+    cand = oi[0].astype(np.int64)
+    t = outs[0]["table"]
+    assert (t[:, 17] == cand).all() and np.allclose(t[:, 16], 0.5 * np.arange(20))
+    for r, o in enumerate(outs):
+        assert sorted(o["mine"].tolist()) == sorted((cand[cand % world == r] // world).tolist())
+    expect = [c for c in range(20) if c >= 3 and cand[c] % 2 == 0]
+    assert outs[0]["sel"] == (expect[0] if expect else -1)
+
+
+def test_sharding_arithmetic():
+    from gloc3d_amd import sharded
+    for world in (1, 2, 8):
+        seen = np.concatenate([sharded.shard_rows(1000, r, world) for r in range(world)])
+        assert sorted(seen.tolist()) == list(range(1000))
+        for r in range(world):
+            rows = sharded.shard_rows(1000, r, world)
+            assert (sharded.owner_rank(rows, world) == r).all()
+            assert (sharded.global_row(sharded.local_row(rows, world), r, world) == rows).all()

@@ -1,0 +1,176 @@
+// global_localization -- drop-in for the reference's evaluator
+// (registration/global_localization.cpp:577-600):
+//
+//   global_localization VALSET POSES DESCRIPTORS [x]
+//
+// Same argv positions and the same report: recall@{1,5,10,20}, success rate, rot/pos error
+// mean +/- std, failed_detect_indices.txt and failed_registration_indices.txt in the CWD.
+// argv[3] is the descriptor file that stands in for the TorchScript model (the CNN is out of the
+// hot path's scope): "GLOCDESC" u32 n u32 dim, then db descriptors followed by query descriptors in
+// valset order.  A 4th argument selected ground alignment in the reference (:584-588); that
+// pre-step is not part of this build and is reported as ignored.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <memory>
+
+#include "loop_detector.hpp"
+
+using namespace gloc_host;
+
+namespace {
+
+struct GlocEvaluator {
+  Valset vs;
+  std::vector<Mat4> poses_db_q;
+  std::vector<float> desc;
+  size_t n_desc = 0, dim = 0;
+  std::unique_ptr<RpyPCLoopDetector> det;
+  std::vector<std::vector<size_t>> queried_idx;
+  std::vector<std::pair<size_t, Mat4>> located;  // {db idx, pose in db}
+  double time_sum_match = 0, times_call_match = 0;
+
+  static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
+  void construct_db() {  // :419-449
+    det.reset(new RpyPCLoopDetector(dim));
+    double t_add = 0;
+    for (size_t i = 0; i < vs.db_files.size(); ++i) {
+      std::vector<float> scan = read_lidar_kitti(vs.db_files[i]);
+      std::vector<float> d(desc.begin() + i * dim, desc.begin() + (i + 1) * dim);
+      const double t0 = now_ms();
+      det->add_keyframe(d, scan.data(), scan.size() / 4);
+      t_add += now_ms() - t0;
+    }
+    std::printf("time cost for add_keyframe (upload + index): %f ms.\n", t_add / std::max<size_t>(1, vs.db_files.size()));
+  }
+
+  void locate_all_query() {  // :211-217, :482-509, :342-356
+    const size_t ndb = vs.db_files.size();
+    double t_det = 0;
+    queried_idx.clear();
+    located.assign(vs.q_files.size(), {ndb + 1, identity4()});
+    for (size_t q = 0; q < vs.q_files.size(); ++q) {
+      std::vector<float> d(desc.begin() + (ndb + q) * dim, desc.begin() + (ndb + q + 1) * dim);
+      std::vector<size_t> idx;
+      std::vector<float> d2;
+      const double t0 = now_ms();
+      det->detect(d, idx, d2);
+      t_det += now_ms() - t0;
+      queried_idx.push_back(idx);
+      if (idx.empty()) continue;
+      std::vector<float> scan = read_lidar_kitti(vs.q_files[q]);
+      Mat4 pose = identity4();
+      const double t1 = now_ms();
+      const int r = det->match(scan.data(), scan.size() / 4, idx, pose);
+      time_sum_match += now_ms() - t1;
+      times_call_match += 1;
+      if (r >= 0) located[q] = {idx[(size_t)r], pose};
+    }
+    std::printf("Each query cost: %f ms.\n", t_det / std::max<size_t>(1, vs.q_files.size()));
+  }
+
+  void recognition_recalls() {  // :221-268
+    const int k_values[4] = {1, 5, 10, 20};
+    float k_recalls[4] = {0, 0, 0, 0};
+    int valid = 0;
+    std::vector<size_t> failed;
+    for (size_t i = 0; i < vs.q_files.size(); ++i) {
+      if (i >= vs.pos_idx.size() || vs.pos_idx[i].empty()) continue;
+      valid++;
+      if (queried_idx[i].empty()) {
+        failed.push_back(i);
+        continue;
+      }
+      bool detected = false;
+      for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < k_values[k] && j < (int)queried_idx[i].size(); ++j)
+          if (std::find(vs.pos_idx[i].begin(), vs.pos_idx[i].end(), queried_idx[i][j]) != vs.pos_idx[i].end()) {
+            k_recalls[k] += 1;
+            detected = true;
+            break;
+          }
+      if (!detected) failed.push_back(i);
+    }
+    if (valid > 0)
+      for (int i = 0; i < 4; ++i) std::printf("Recall @ %d: %g\n", k_values[i], k_recalls[i] / valid);
+    std::ofstream ofs("failed_detect_indices.txt", std::ios::out);
+    for (size_t idx : failed) ofs << idx << " ";
+    ofs << "\n";
+  }
+
+  void registration_recalls() {  // :270-335
+    const size_t ndb = vs.db_files.size();
+    int all_tests = (int)located.size(), succeed = 0;
+    std::vector<double> rot_err, pos_err;
+    std::vector<size_t> failed;
+    for (size_t i = 0; i < located.size(); ++i) {
+      const size_t db_idx = located[i].first;
+      if (db_idx >= ndb) {
+        failed.push_back(i);
+        continue;
+      }
+      const Mat4 q2db = mul4(rigid_inverse(poses_db_q[db_idx]), poses_db_q[i + ndb]);
+      float er, ep;
+      pose_error(q2db, located[i].second, er, ep);
+      if (ep < 1.0f && er < 5.f) {
+        succeed++;
+        rot_err.push_back(er);
+        pos_err.push_back(ep);
+      }
+    }
+    double mr = 0, sr = 0, mp = 0, sp = 0;
+    if (!pos_err.empty()) {
+      mean_std(pos_err, mp, sp);
+      mean_std(rot_err, mr, sr);
+    }
+    std::printf("%d, %d\n", succeed, all_tests);
+    std::printf("Success rate: %g\n", all_tests ? (float)succeed / (float)all_tests : 0.f);
+    std::printf("Rot error: %g, %g\n", mr, sr);
+    std::printf("Pos error: %g, %g\n", mp, sp);
+    std::ofstream ofs("failed_registration_indices.txt", std::ios::out);
+    for (size_t idx : failed) ofs << idx << " ";
+    ofs << "\n";
+    std::printf("Average 3D match costs %g ms.\n", times_call_match ? time_sum_match / times_call_match : 0.0);
+  }
+};
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s VALSET POSES DESCRIPTORS [x]\n", argv[0]);
+    return 2;
+  }
+  GlocEvaluator g;
+  if (argc == 5) std::printf("note: ground alignment (4th argument) is outside this build's scope; ignored\n");
+  if (!read_valset(argv[1], g.vs) || !read_valset_pose(argv[2], g.poses_db_q)) return 1;
+  std::printf("db_num and db_files: %zu\nq_num and q_files: %zu\nq_num and q_pos_index: %zu\n", g.vs.db_files.size(),
+              g.vs.q_files.size(), g.vs.pos_idx.size());
+  std::printf("Read poses with size: %zu\n", g.poses_db_q.size());
+  if (!read_descriptors(argv[3], g.desc, g.n_desc, g.dim)) {
+    std::fprintf(stderr,
+                 "%s is not a descriptor file (GLOCDESC header).  The reference loads a TorchScript model here; the "
+                 "descriptor network is upstream of this build's hot path -- export its outputs for the valset's db "
+                 "then query scans and pass that file instead.\n", argv[3]);
+    return 1;
+  }
+  if (g.n_desc != g.vs.db_files.size() + g.vs.q_files.size() ||
+      g.poses_db_q.size() != g.vs.db_files.size() + g.vs.q_files.size()) {
+    std::fprintf(stderr, "descriptor/pose count does not match the valset\n");
+    return 1;
+  }
+  try {
+    g.construct_db();
+    g.locate_all_query();
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "fatal: %s\n", e.what());
+    return 1;
+  }
+  g.recognition_recalls();
+  g.registration_recalls();
+  return 0;
+}

@@ -1,0 +1,138 @@
+// loop_detector.hpp -- host-side mirror of the reference's RpyPCLoopDetector
+// (registration/loop_detector.h:41-119) for the hot path: same method names, argument meaning and
+// guards, over the C ABI (include/gloc3d.h).  Differences, all forced by scope:
+//   * the descriptor comes from the caller (the CNN + BEV projection are upstream of the hot path);
+//   * match() is the 3-D registration (RANSAC-SVD + ICP) of north_star, not the 2-D SURF match.
+// Not thread-safe; single caller thread, like the reference.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gloc3d.h"
+#include "gloc_io.hpp"
+
+namespace gloc_host {
+
+class RpyPCLoopDetector {
+ public:
+  explicit RpyPCLoopDetector(size_t k_dim = 512, int device = 0) : k_dim_(k_dim) {
+    if (gloc_knn_create(device, k_dim_, &knn_) != GLOC_OK) throw std::runtime_error(gloc_last_error());
+    if (gloc_reg_create(device, &reg_) != GLOC_OK) {
+      std::string e = gloc_last_error();
+      gloc_knn_destroy(knn_);
+      throw std::runtime_error(e);
+    }
+    gloc_reg_default_params(&reg_params_);
+  }
+  ~RpyPCLoopDetector() {
+    gloc_reg_destroy(reg_);
+    gloc_knn_destroy(knn_);
+  }
+  RpyPCLoopDetector(const RpyPCLoopDetector&) = delete;
+  RpyPCLoopDetector& operator=(const RpyPCLoopDetector&) = delete;
+
+  const int NUM_EXCLUDE_RECENT = 30;  // loop_detector.h:77
+
+  // add_keyframe (loop_detector.cpp:10-20): one descriptor + its scan (x,y,z,i quadruples).
+  void add_keyframe(const std::vector<float>& descriptor, const float* scan_xyzi, size_t n_pts) {
+    if (descriptor.size() != k_dim_) throw std::runtime_error("descriptor length != k_dim_");
+    check(gloc_knn_add(knn_, descriptor.data(), 1));
+    uint32_t sid = 0;
+    check(gloc_reg_scan_upload(reg_, scan_xyzi, n_pts, 4, &sid));
+    db_scan_ids_.push_back(sid);
+    db_size_++;
+  }
+
+  // global localization (loop_detector.cpp:22-46).  Leaves the vectors untouched when the
+  // database is too small ("Not enough keyframes in database.", :27-30).
+  void detect(const std::vector<float>& q_descriptor, std::vector<size_t>& loop_indices,
+              std::vector<float>& out_dists_sqr) {
+    if (db_size_ <= num_exclude_recent_ + top_k_) {
+      std::printf("Not enough keyframes in database.\n");
+      return;
+    }
+    query(q_descriptor.data(), 0, db_size_, loop_indices, out_dists_sqr);
+  }
+
+  // SLAM mode (loop_detector.cpp:48-81): the newest frame is the query; every
+  // tree_making_period_ calls the searchable window is refreshed to db[0 : end-30]; a loop is
+  // accepted iff the best SQUARED distance is below 0.8 (:54, loop_detector.h:103).
+  bool detect(size_t& q_idx, size_t& loop_idx, const std::vector<float>& last_descriptor) {
+    if (db_size_ <= num_exclude_recent_ + top_k_) return false;
+    if (tree_making_period_counter_ % tree_making_period_ == 0)
+      searchable_end_ = db_size_ - num_exclude_recent_;
+    tree_making_period_counter_++;
+    std::vector<size_t> idx;
+    std::vector<float> d2;
+    query(last_descriptor.data(), 0, searchable_end_, idx, d2);
+    if (idx.empty()) return false;
+    if (d2[0] < loop_metric_dist_th_) {
+      q_idx = db_size_ - 1;
+      loop_idx = idx[0];
+      return true;
+    }
+    return false;
+  }
+
+  // Register a query scan against retrieved candidates in one batch; returns the rank of the first
+  // successful candidate (global_localization.cpp:519-572) or -1, and its pose (query -> db).
+  int match(const float* q_scan_xyzi, size_t n_pts, const std::vector<size_t>& db_indices,
+            Mat4& pose_in_db, std::vector<Mat4>* all_poses = nullptr, std::vector<int>* all_ok = nullptr) {
+    uint32_t qid = 0;
+    check(gloc_reg_scan_upload(reg_, q_scan_xyzi, n_pts, 4, &qid));  // kept until clear_queries()
+    query_scan_ids_.push_back(qid);
+    return match_ids(qid, db_indices, pose_in_db, all_poses, all_ok);
+  }
+
+  int match_ids(uint32_t q_scan_id, const std::vector<size_t>& db_indices, Mat4& pose_in_db,
+                std::vector<Mat4>* all_poses, std::vector<int>* all_ok) {
+    const size_t n = db_indices.size();
+    if (n == 0) return -1;
+    std::vector<uint32_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = db_scan_ids_.at(db_indices[i]);
+    std::vector<float> T(16 * n);
+    std::vector<int> ok(n);
+    check(gloc_reg_batch_ids(reg_, q_scan_id, ids.data(), n, nullptr, nullptr, &reg_params_, T.data(),
+                             nullptr, nullptr, ok.data()));
+    if (all_poses) {
+      all_poses->resize(n);
+      for (size_t i = 0; i < n; ++i) std::copy(T.begin() + 16 * i, T.begin() + 16 * (i + 1), (*all_poses)[i].begin());
+    }
+    if (all_ok) *all_ok = ok;
+    const int r = gloc_reg_select_first_ok(ok.data(), n);
+    if (r >= 0) std::copy(T.begin() + 16 * r, T.begin() + 16 * (r + 1), pose_in_db.begin());
+    return r;
+  }
+
+  gloc_reg_params& registration_params() { return reg_params_; }
+  size_t size() const { return db_size_; }
+  size_t top_k() const { return top_k_; }
+
+ private:
+  void check(int rc) {
+    if (rc != GLOC_OK) throw std::runtime_error(gloc_last_error());
+  }
+  void query(const float* q, size_t first, size_t last, std::vector<size_t>& idx, std::vector<float>& d2) {
+    std::vector<uint64_t> i64(top_k_);
+    idx.resize(top_k_);   // loop_detector.cpp:42-43
+    d2.resize(top_k_);
+    check(gloc_knn_search(knn_, q, 1, top_k_, first, last, i64.data(), d2.data()));
+    for (size_t i = 0; i < top_k_; ++i) idx[i] = (size_t)i64[i];
+  }
+
+  const size_t k_dim_;
+  const size_t top_k_ = 20;                // loop_detector.h:98
+  const size_t num_exclude_recent_ = 30;   // :99
+  const size_t tree_making_period_ = 30;   // :100
+  size_t tree_making_period_counter_ = 0;  // :101
+  const float loop_metric_dist_th_ = 0.8f; // :103
+  size_t db_size_ = 0, searchable_end_ = 0;
+  gloc_knn* knn_ = nullptr;
+  gloc_reg* reg_ = nullptr;
+  gloc_reg_params reg_params_{};
+  std::vector<uint32_t> db_scan_ids_, query_scan_ids_;
+};
+
+}  // namespace gloc_host

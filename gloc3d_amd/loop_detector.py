@@ -1,0 +1,127 @@
+"""Python mirror of the reference's RpyPCLoopDetector + GlocEvaluator for the hot path
+(registration/loop_detector.h:41-119, registration/global_localization.cpp:202-574): same method
+names, guards and constants, over the C ABI.  Descriptors come from the caller (the CNN and the BEV
+projection are upstream of the hot path); match() is the 3-D RANSAC-SVD + ICP registration.
+"""
+import numpy as np
+
+from . import capi
+
+
+class RpyPCLoopDetector:
+    NUM_EXCLUDE_RECENT = 30            # loop_detector.h:77
+
+    def __init__(self, k_dim=512, device=0, top_k=20):
+        self.k_dim_ = k_dim            # loop_detector.h:97
+        self.top_k_ = top_k            # :98
+        self.num_exclude_recent_ = 30  # :99
+        self.tree_making_period_ = 30  # :100
+        self.tree_making_period_counter_ = 0
+        self.loop_metric_dist_th_ = 0.8  # :103, compared with the SQUARED distance (:54)
+        self._searchable_end = 0
+        self._index = capi.KnnIndex(k_dim, device)
+        self._reg = capi.Registrar(device)
+        self._db_scan_ids = []
+        self._last_descriptor = None
+        self.reg_params = capi.default_reg_params()
+
+    def close(self):
+        self._index.close()
+        self._reg.close()
+
+    def __len__(self):
+        return len(self._db_scan_ids)
+
+    def add_keyframe(self, descriptor, scan):
+        """loop_detector.cpp:10-20: append one place (descriptor + its scan [n,3|4])."""
+        d = np.ascontiguousarray(descriptor, np.float32).reshape(1, self.k_dim_)
+        self._index.add(d)
+        self._db_scan_ids.append(self._reg.scan_upload(scan))
+        self._last_descriptor = d
+
+    def detect(self, q_descriptor):
+        """Global localization (loop_detector.cpp:22-46): (indices, squared distances), or two
+        empty arrays when the database is too small (:27-30)."""
+        if len(self) <= self.num_exclude_recent_ + self.top_k_:
+            print("Not enough keyframes in database.")
+            return np.zeros(0, np.uint64), np.zeros(0, np.float32)
+        idx, d2 = self._index.search(np.asarray(q_descriptor, np.float32).reshape(1, -1), self.top_k_)
+        return idx[0], d2[0]
+
+    def detect_slam(self):
+        """SLAM mode (loop_detector.cpp:48-81): the newest keyframe is the query; every 30th call
+        the searchable window is refreshed to db[0 : end-30]; accept iff best d2 < 0.8.
+        Returns (found, q_idx, loop_idx)."""
+        n = len(self)
+        if n <= self.num_exclude_recent_ + self.top_k_:
+            return False, None, None
+        if self.tree_making_period_counter_ % self.tree_making_period_ == 0:
+            self._searchable_end = n - self.num_exclude_recent_
+        self.tree_making_period_counter_ += 1
+        idx, d2 = self._index.search(self._last_descriptor, self.top_k_, 0, self._searchable_end)
+        if d2[0, 0] < self.loop_metric_dist_th_:
+            return True, n - 1, int(idx[0, 0])
+        return False, None, None
+
+    def match(self, q_scan, db_indices):
+        """Register the query scan against the retrieved places in one batch; returns
+        (rank of the first successful candidate or -1, its 4x4 pose query->db, full result)."""
+        ids = [self._db_scan_ids[int(i)] for i in db_indices]
+        q = np.ascontiguousarray(q_scan, np.float32)
+        qid = self._reg.scan_upload(q)
+        res = self._reg.batch_ids(qid, ids, params=self.reg_params)
+        r = capi.reg_select_first_ok(res["ok"].astype(np.int32))
+        return r, (res["T"][r] if r >= 0 else np.eye(4, dtype=np.float32)), res
+
+
+def recognition_recalls(queried_idx, gt_pos, k_values=(1, 5, 10, 20)):
+    """recall@N with the reference's first-hit semantics (global_localization.cpp:221-268,
+    main.py:336-348).  Returns (recalls, failed query indices)."""
+    rec = np.zeros(len(k_values))
+    valid, failed = 0, []
+    for i, pos in enumerate(gt_pos):
+        if len(pos) == 0:
+            continue
+        valid += 1
+        cand = list(queried_idx[i])
+        if len(cand) == 0:
+            failed.append(i)
+            continue
+        detected = False
+        for ki, k in enumerate(k_values):
+            if any(int(c) in set(int(p) for p in pos) for c in cand[:k]):
+                rec[ki] += 1
+                detected = True
+        if not detected:
+            failed.append(i)
+    return (rec / valid if valid else rec), failed
+
+
+def pose_error(q2db_gt, est):
+    """err_rot (deg, ~180-degree flips forgiven) and err_pos (m): global_localization.cpp:288-306."""
+    g, e = np.asarray(q2db_gt, np.float32), np.asarray(est, np.float32)
+    off = np.float32(0.5) * (np.trace(g[:3, :3].T @ e[:3, :3]) - np.float32(1))
+    off = min(max(off, -0.999999), 0.999999)
+    er = abs(float(np.arccos(off))) * 180.0 / np.pi
+    ep = float(np.linalg.norm(g[:3, 3] - e[:3, 3]))
+    if abs(er - 180.0) < 5.0:
+        er = abs(er - 180.0)
+    return er, ep
+
+
+def registration_recalls(located, poses_db_q, n_db):
+    """Success = err_pos < 1 m and err_rot < 5 deg (global_localization.cpp:270-335).
+    located: list of (db_idx or >= n_db for failure, 4x4 pose)."""
+    ok_rot, ok_pos, failed = [], [], []
+    for i, (db_idx, pose) in enumerate(located):
+        if db_idx >= n_db:
+            failed.append(i)
+            continue
+        q2db = np.linalg.inv(poses_db_q[db_idx].astype(np.float64)) @ poses_db_q[n_db + i]
+        er, ep = pose_error(q2db, pose)
+        if ep < 1.0 and er < 5.0:
+            ok_rot.append(er)
+            ok_pos.append(ep)
+    n = len(located)
+    return dict(success_rate=(len(ok_pos) / n if n else 0.0), rot_mean=float(np.mean(ok_rot)) if ok_rot else 0.0,
+                pos_mean=float(np.mean(ok_pos)) if ok_pos else 0.0, failed=failed, succeeded=len(ok_pos))

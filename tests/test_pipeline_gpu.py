@@ -1,0 +1,101 @@
+"""GPU: end to end through the host mirrors -- the Python RpyPCLoopDetector/GlocEvaluator mirror and
+the two drop-in command lines -- on a small synthetic drive (db places along a path, queries near
+some of them), checked against the oracle and against each other."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_DB, N_Q, DIM = 60, 5, 512
+Q_AT = [7, 19, 33, 41, 55]
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    from gloc3d_amd import gloc_io, synth
+    d = tmp_path_factory.mktemp("drive")
+    w = synth.make_world(1001)
+    poses, files = [], []
+    for i in range(N_DB):
+        T = synth.se3(0.5 * (i - 30), (0.6 * i - 18.0, 0.1 * i, 0.0))
+        s = synth.lidar_scan(w, T, seed=100 + i, n_az=360)
+        f = str(d / f"db_{i:06d}.bin")
+        synth.write_kitti_bin(f, s)
+        poses.append(T)
+        files.append(f)
+    qfiles, qposes = [], []
+    for qi, j in enumerate(Q_AT):
+        T = synth.se3(0.5 * (j - 30) + 1.0, (0.6 * j - 18.0 + 0.25, 0.1 * j - 0.2, 0.03))
+        s = synth.lidar_scan(w, T, seed=900 + qi, n_az=360)
+        f = str(d / f"q_{qi:06d}.bin")
+        synth.write_kitti_bin(f, s)
+        qfiles.append(f)
+        qposes.append(T)
+    desc_db = synth.descriptors_traj(4001, 0, N_DB, DIM)
+    desc_q = synth.queries_near(4001, np.array(Q_AT), DIM)
+    positives = [[j - 1, j, j + 1] for j in Q_AT]
+    gloc_io.write_valset(d / "valset.txt", files, qfiles, positives)
+    gloc_io.write_poses(d / "poses.txt", poses + qposes)
+    gloc_io.write_descriptors(d / "desc.bin", np.concatenate([desc_db, desc_q]))
+    return dict(dir=d, files=files, qfiles=qfiles, poses=poses, qposes=qposes, desc_db=desc_db, desc_q=desc_q,
+                positives=positives)
+
+
+def test_python_mirror_guards_retrieval_and_registration(dataset, oracle_mod):
+    from gloc3d_amd import loop_detector as ld, synth
+    det = ld.RpyPCLoopDetector(DIM)
+    det.reg_params.icp_iters = 20
+    idx, d2 = None, None
+    for i in range(N_DB):
+        if i == 40:  # 40 <= 30 + 20: the reference's "not enough keyframes" guard (loop_detector.cpp:27)
+            idx, d2 = det.detect(dataset["desc_q"][0])
+            assert len(idx) == 0 and det.detect_slam() == (False, None, None)
+        det.add_keyframe(dataset["desc_db"][i], synth.read_kitti_bin(dataset["files"][i]))
+    queried, located = [], []
+    for qi in range(N_Q):
+        idx, d2 = det.detect(dataset["desc_q"][qi])
+        oi, od = oracle_mod.knn_search(dataset["desc_db"], dataset["desc_q"][qi:qi + 1], 20)
+        assert (idx == oi[0]).all() and (d2.view(np.uint32) == od[0].view(np.uint32)).all()
+        queried.append(idx)
+        r, pose, res = det.match(synth.read_kitti_bin(dataset["qfiles"][qi]), idx)
+        located.append((int(idx[r]) if r >= 0 else N_DB + 1, pose))
+    rec, failed = ld.recognition_recalls(queried, dataset["positives"])
+    assert rec[0] == 1.0 and not failed
+    poses = [np.asarray(p, np.float32) for p in dataset["poses"] + dataset["qposes"]]
+    out = ld.registration_recalls(located, poses, N_DB)
+    assert out["success_rate"] == 1.0 and out["pos_mean"] < 0.3
+    # SLAM mode: the newest keyframe finds its neighbour outside the 30-frame exclusion window
+    det.add_keyframe(dataset["desc_db"][3], synth.read_kitti_bin(dataset["files"][3]))  # revisit place 3
+    found, q_idx, loop_idx = det.detect_slam()
+    assert found and q_idx == N_DB and loop_idx == 3
+    det.close()
+
+
+def _run(cmd, cwd):
+    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p.stdout
+
+
+def test_command_lines(dataset):
+    bindir = os.path.join(ROOT, "gloc3d_amd", "bin")
+    d = dataset["dir"]
+    out = _run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
+                str(d / "desc.bin")], cwd=d)
+    rec = dict((int(k), float(v)) for k, v in re.findall(r"Recall @ (\d+): ([\d.eE+-]+)", out))
+    assert rec == {1: 1.0, 5: 1.0, 10: 1.0, 20: 1.0}
+    assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) == 1.0
+    assert (d / "failed_detect_indices.txt").read_text().strip() == ""
+    assert (d / "failed_registration_indices.txt").read_text().strip() == ""
+    out = _run([os.path.join(bindir, "global_registration"), str(d / "valset.txt"), str(d / "poses.txt")], cwd=d)
+    errs = re.findall(r"err_pos, err_rot: ([\d.eE+-]+), ([\d.eE+-]+)", out)
+    assert len(errs) == 3 * N_Q
+    assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) > 0.9
+    # a TorchScript model path instead of descriptors: explained, not crashed
+    p = subprocess.run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
+                        str(d / "valset.txt")], cwd=d, capture_output=True, text=True)
+    assert p.returncode == 1 and "descriptor" in p.stderr

@@ -36,7 +36,8 @@ N_PLACES_1GPU = 4541          # KITTI odometry 00 (dataset/kitti_i2i.py:46 of th
 N_PLACES_SHARDED = 1_000_000  # BASELINE.json configs[4]
 SCAN_POOL = 24                # distinct synthetic scans; place g carries scan g % SCAN_POOL
 QUERY_POOL = 4
-RANSAC_ITERS = 3000           # registration/loop_detector.cpp:257
+RANSAC_ITERS = 3000           # registration/loop_detector.cpp:257 (cap; adaptive stop at the
+                              # reference's OpenCV default confidence 0.99, see gloc_reg_params)
 ICP_ITERS = 20                # BASELINE.json configs[2]
 DB_SEED = 4001
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
@@ -96,6 +97,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
+    ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
                     help="1-NN search of the registration (identical results)")
     args = ap.parse_args()
@@ -140,6 +142,8 @@ def main():
     reg.set_option(capi.REG_OPT_PROFILE, 1)
     reg.set_option(capi.REG_OPT_NN_MODE,
                    capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
+    if args.nn_src_per_lane:
+        reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
     pool_ids = [reg.scan_upload(p) for p in pool]
     q_ids = [reg.scan_upload(q) for q in qscans]
     params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
@@ -202,13 +206,13 @@ def main():
     nn_ms, nn_launches = reg.profile("nn")
     stage_ms = {n: reg.profile(n)[0] for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve", "transform")}
     passes = 1 + ICP_ITERS
-    chunks, _ = reg.nn_stats()
+    pairs_eval, _ = reg.nn_stats()
     all_pairs = float(np.mean(pairs_per_launch)) if pairs_per_launch else 0.0   # exhaustive pair count
     avg_launch_s = (nn_ms / max(nn_launches, 1)) * 1e-3
     if args.nn_mode == "exhaustive":
         eval_pairs = all_pairs
-    else:  # culled: pairs the kernel actually evaluated (chunks x 256 sources x 128 targets)
-        eval_pairs = chunks * 256.0 * 128.0 / max(nn_launches, 1)
+    else:  # culled: pairs the kernel actually evaluated (its own counter)
+        eval_pairs = float(pairs_eval) / max(nn_launches, 1)
     achieved = FLOP_PER_PAIR * eval_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
     kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_culled_kernel"
     roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,
@@ -231,7 +235,7 @@ def main():
                                  f"scans (~{mean_pts:.0f} pts) x (RANSAC {RANSAC_ITERS} + ICP {ICP_ITERS})",
                    "places": n_places, "dim": DIM, "top_k": TOP_K, "points_per_scan": int(mean_pts),
                    "ransac_iters": RANSAC_ITERS, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
-                   "nn_mode": args.nn_mode,
+                   "nn_mode": args.nn_mode, "ransac_confidence": float(params.ransac_confidence),
                    "parallelism": "1 gpu" if world == 1 else
                    f"db rows + candidates interleave-sharded over {world} ranks; all-gather top-k, all-reduce poses"},
         "roofline": roofline,

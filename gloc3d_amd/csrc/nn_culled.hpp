@@ -22,12 +22,16 @@
 namespace gloc {
 namespace reg {
 
+#define GPTR(T) const T __attribute__((address_space(1)))*
 constexpr int CH = 128;  // points per chunk
+constexpr int SB = 16;   // points per sub-block (second-level boxes, argmin bookkeeping)
 
 struct ScanIndexDev {
   const f32x4* pts;      // Morton order: x, y, z, bits(original index)
-  const f32x4* box_lo;   // per chunk
+  const f32x4* box_lo;   // per chunk of CH points
   const f32x4* box_hi;
+  const f32x4* sb_lo;    // per sub-block of SB points
+  const f32x4* sb_hi;
   const uint32_t* keys;  // sorted Morton keys
   const uint32_t* inv;   // original index -> sorted position
   uint32_t n, nchunks;
@@ -102,6 +106,25 @@ __global__ __launch_bounds__(64) void chunk_boxes_kernel(const f32x4* __restrict
   }
 }
 
+// one thread per sub-block of SB points
+__global__ void subblock_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n, uint32_t nsb,
+                                      f32x4* __restrict__ lo, f32x4* __restrict__ hi) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nsb) return;
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (uint32_t t = 0; t < SB; ++t) {
+    const uint32_t j = b * SB + t;
+    if (j < n) {
+      const f32x4 p = pts[j];
+      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+  lo[b] = f32x4{mn[0], mn[1], mn[2], 0.f};
+  hi[b] = f32x4{mx[0], mx[1], mx[2], 0.f};
+}
+
 // squared distance from a point to a box, scaled down by 2^-20 so that fp32 rounding can never
 // push it above the (fp32) distance of any point inside the box
 __device__ __forceinline__ float box_lb(float px, float py, float pz, const f32x4& lo,
@@ -112,31 +135,46 @@ __device__ __forceinline__ float box_lb(float px, float py, float pz, const f32x
   return ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
 }
 
-constexpr int CS = 4;  // source points per lane
 
-// grid = (ceil(n_src / 1024), n_cand); work-group = 4 independent waves of 256 sources each.
+// CS = source points per lane.  grid = (ceil(n_src / (256*CS)), n_cand); work-group = 4 independent
+// waves of 64*CS sources each.
 // src4: Morton-sorted source points (x, y, z, bits(original index)).
 // prev_corr (may be null): the previous pass's correspondences [cand][ld] by original source index.
+template <int CS>
 __global__ __launch_bounds__(256) void nn_culled_kernel(
     const f32x4* __restrict__ src4, uint32_t n_src, const CulledCand* __restrict__ ccands,
     const CandState* __restrict__ states, const uint32_t* __restrict__ prev_corr,
     uint32_t* __restrict__ corr, float* __restrict__ d2out, size_t ld,
-    unsigned long long* __restrict__ stat_chunks) {
+    unsigned long long* __restrict__ stat_chunks /* pairs evaluated */,
+    uint32_t* __restrict__ trace /* dev only: [wave][4] = cycles, candidate chunks, chunks, sub-blocks */) {
   __shared__ f32x4 stage_all[4][CH];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4* stage = stage_all[w];
   const int cand = blockIdx.y;
-  const ScanIndexDev ix = ccands[cand].idx;
-  const float* __restrict__ txyz = ccands[cand].xyz;
+  // The index arrays are reached through pointers loaded from memory, which the compiler would
+  // treat as generic (flat_load): view them in the global address space explicitly.
+  struct IndexView {
+    GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb_lo; GPTR(f32x4) sb_hi;
+    GPTR(uint32_t) keys; GPTR(uint32_t) inv;
+    uint32_t n, nchunks;
+    float ox, oy, oz, inv_cell;
+  };
+  const ScanIndexDev ixg = ccands[cand].idx;
+  const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
+                     (GPTR(f32x4))ixg.sb_lo, (GPTR(f32x4))ixg.sb_hi, (GPTR(uint32_t))ixg.keys,
+                     (GPTR(uint32_t))ixg.inv, ixg.n, ixg.nchunks, ixg.ox, ixg.oy, ixg.oz, ixg.inv_cell};
+  GPTR(float) txyz = (GPTR(float))ccands[cand].xyz;
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = states[cand].Tf[i];
 
   const uint32_t wave_base = (blockIdx.x * 4 + w) * (64 * CS);
-  if (wave_base >= n_src) return;  // whole wave idle (no barriers are used below)
+  if (wave_base >= n_src) return;
+  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  uint32_t n_cand_chunks = 0;  // whole wave idle (no barriers are used below)
 
   float px[CS], py[CS], pz[CS], best[CS];
-  uint32_t orig[CS], bch[CS];
+  uint32_t orig[CS], bch[CS];  // bch: index of the 16-target sub-block holding the minimum
   bool valid[CS], tie[CS];
   float wlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, whi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
 #pragma unroll
@@ -169,7 +207,7 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
       if (j < ix.n) {
         best[s] = dist2(px[s], py[s], pz[s], txyz[3 * (size_t)j], txyz[3 * (size_t)j + 1],
                         txyz[3 * (size_t)j + 2]);
-        bch[s] = ix.inv[j] / CH;
+        bch[s] = ix.inv[j] / SB;
       } else {
         const uint32_t key = morton_key(px[s], py[s], pz[s], ix.ox, ix.oy, ix.oz, ix.inv_cell);
         uint32_t lo = 0, hi = ix.n;  // lower_bound over the sorted keys
@@ -184,7 +222,7 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
           const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
           if (dd < best[s]) {
             best[s] = dd;
-            bch[s] = (uint32_t)jj / CH;
+            bch[s] = (uint32_t)jj / SB;
           }
         }
       }
@@ -198,7 +236,7 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
     return m;
   };
   float wmax = wave_max_best();
-  unsigned long long n_processed = 0;
+  unsigned long long n_processed = 0, n_sub = 0;
 
   // ---- sweep: 64 chunk boxes per ballot -----------------------------------------------------
   for (uint32_t c0 = 0; c0 < ix.nchunks; c0 += 64) {
@@ -220,6 +258,7 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
       // the wave's bound may have tightened since the ballot
       if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
       const uint32_t c = c0 + b;
+      n_cand_chunks++;
       f32x4 lo, hi;
       lo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.x), b));
       lo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.y), b));
@@ -244,37 +283,51 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      float m[CS];
+      bool changed = false;
+      for (int b0 = 0; b0 < CH; b0 += SB) {
+        const uint32_t blk = (c * CH + b0) / SB;
+        if (blk * SB >= ix.n) break;
+        {  // second-level test: does any point of the wave still need this sub-block?
+          const f32x4 slo = ix.sb_lo[blk], shi = ix.sb_hi[blk];
+          bool need_sb = false;
 #pragma unroll
-      for (int s = 0; s < CS; ++s) m[s] = 3.402823466e+38f;
-#pragma unroll 8
-      for (int t = 0; t < CH; t += 2) {
-        const f32x4 q0 = stage[t];
-        const f32x4 q1 = stage[t + 1];
+          for (int s = 0; s < CS; ++s)
+            need_sb |= valid[s] && (box_lb(px[s], py[s], pz[s], slo, shi) <= best[s]);
+          if (!__any(need_sb)) continue;
+          n_sub++;
+        }
+        float m[CS];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) m[s] = 3.402823466e+38f;
+#pragma unroll
+        for (int t = b0; t < b0 + SB; t += 2) {
+          const f32x4 q0 = stage[t];
+          const f32x4 q1 = stage[t + 1];
+#pragma unroll
+          for (int s = 0; s < CS; ++s) {
+            const float d0 = dist2(px[s], py[s], pz[s], q0.x, q0.y, q0.z);
+            const float d1 = dist2(px[s], py[s], pz[s], q1.x, q1.y, q1.z);
+            m[s] = fminf(fminf(m[s], d0), d1);
+          }
+        }
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
-          const float d0 = dist2(px[s], py[s], pz[s], q0.x, q0.y, q0.z);
-          const float d1 = dist2(px[s], py[s], pz[s], q1.x, q1.y, q1.z);
-          m[s] = fminf(fminf(m[s], d0), d1);
+          if (m[s] < best[s]) {
+            best[s] = m[s];
+            bch[s] = blk;
+            tie[s] = false;
+            changed = true;
+          } else if (m[s] == best[s] && blk != bch[s]) {
+            tie[s] = true;  // an equally near point elsewhere: resolved by original index below
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();  // all reads done before the slice is overwritten
-      bool changed = false;
-#pragma unroll
-      for (int s = 0; s < CS; ++s) {
-        if (m[s] < best[s]) {
-          best[s] = m[s];
-          bch[s] = c;
-          tie[s] = false;
-          changed = true;
-        } else if (m[s] == best[s] && c != bch[s]) {
-          tie[s] = true;  // an equally near point in another chunk: resolve by original index below
-        }
-      }
       if (__any(changed)) wmax = wave_max_best();
     }
   }
-  if (stat_chunks && lane == 0) atomicAdd(stat_chunks, n_processed);
+  (void)n_processed;
+  if (stat_chunks && lane == 0) atomicAdd(stat_chunks, n_sub * (unsigned long long)(64 * CS * SB));
 
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
 #pragma unroll
@@ -282,12 +335,9 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
     if (!valid[s]) continue;
     uint32_t bj = 0xFFFFFFFFu;
     if (ix.n) {
-      const uint32_t cbeg = tie[s] ? 0 : bch[s];
-      const uint32_t cend = tie[s] ? ix.nchunks : bch[s] + 1;
-      for (uint32_t c = cbeg; c < cend; ++c) {
-        if (tie[s] && box_lb(px[s], py[s], pz[s], ix.box_lo[c], ix.box_hi[c]) > best[s]) continue;
-        const uint32_t j0 = c * CH;
-        const uint32_t j1 = (j0 + CH) < ix.n ? (j0 + CH) : ix.n;
+      if (!tie[s]) {
+        const uint32_t j0 = bch[s] * SB;
+        const uint32_t j1 = (j0 + SB) < ix.n ? (j0 + SB) : ix.n;
         for (uint32_t j = j0; j < j1; ++j) {
           const f32x4 t = ix.pts[j];
           if (dist2(px[s], py[s], pz[s], t.x, t.y, t.z) == best[s]) {
@@ -295,10 +345,31 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
             bj = o < bj ? o : bj;
           }
         }
+      } else {  // rare: every chunk that can hold a point at the minimum distance
+        for (uint32_t c = 0; c < ix.nchunks; ++c) {
+          const f32x4 clo = ix.box_lo[c], chi = ix.box_hi[c];
+          if (box_lb(px[s], py[s], pz[s], clo, chi) > best[s]) continue;
+          const uint32_t j0 = c * CH;
+          const uint32_t j1 = (j0 + CH) < ix.n ? (j0 + CH) : ix.n;
+          for (uint32_t j = j0; j < j1; ++j) {
+            const f32x4 t = ix.pts[j];
+            if (dist2(px[s], py[s], pz[s], t.x, t.y, t.z) == best[s]) {
+              const uint32_t o = __float_as_uint(t.w);
+              bj = o < bj ? o : bj;
+            }
+          }
+        }
       }
     }
     corr[(size_t)cand * ld + orig[s]] = bj;
     d2out[(size_t)cand * ld + orig[s]] = best[s];
+  }
+  if (trace && lane == 0) {
+    const size_t wid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
+    trace[4 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+    trace[4 * wid + 1] = n_cand_chunks;
+    trace[4 * wid + 2] = (uint32_t)n_processed;
+    trace[4 * wid + 3] = (uint32_t)n_sub;
   }
 }
 

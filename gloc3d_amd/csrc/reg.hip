@@ -36,10 +36,14 @@ struct gloc_reg {
   DevBuf partials;
   DevBuf ccands;                          // CulledCand[]
   DevBuf sort_tmp, sort_keys, sort_vals, sort_perm;  // scan indexing scratch
-  DevBuf counters;                        // [0] = chunks evaluated by nn_culled_kernel
+  DevBuf counters;                        // [0] = pairs evaluated by nn_culled_kernel
   std::vector<CandState> h_states;
   std::vector<CandDesc> h_cands;
   int nn_mode = 0;                        // 0 culled (default), 1 exhaustive
+  bool trace_on = false;                  // dev only: per-wave trace of the culled kernel
+  DevBuf trace;
+  size_t trace_waves = 0;
+  int nn_src_per_lane = 2;                // culled kernel: source points per lane (1, 2, 4)
   uint64_t nn_launches = 0;
   Profiler prof;
 };
@@ -67,14 +71,18 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   DevScan s;
   s.n = n;
   const size_t nch = (n + CH - 1) / CH;
-  const size_t n1 = std::max<size_t>(n, 1), c1 = std::max<size_t>(nch, 1);
-  // layout: pts4 | box_lo | box_hi | xyz | keys | inv   (16-byte aligned parts first)
-  const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1) + sizeof(float) * 3 * n1 + sizeof(uint32_t) * 2 * n1;
+  const size_t nsb = (n + SB - 1) / SB;
+  const size_t n1 = std::max<size_t>(n, 1), c1 = std::max<size_t>(nch, 1), b1 = std::max<size_t>(nsb, 1);
+  // layout: pts4 | box_lo | box_hi | sb_lo | sb_hi | xyz | keys | inv   (16-byte aligned parts first)
+  const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1 + 2 * b1) + sizeof(float) * 3 * n1 +
+                       sizeof(uint32_t) * 2 * n1;
   GLOC_HIP(hipMalloc(&s.block, bytes));
   f32x4* p4 = reinterpret_cast<f32x4*>(s.block);
   f32x4* lo = p4 + n1;
   f32x4* hi = lo + c1;
-  s.xyz = reinterpret_cast<float*>(hi + c1);
+  f32x4* slo = hi + c1;
+  f32x4* shi = slo + b1;
+  s.xyz = reinterpret_cast<float*>(shi + b1);
   uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * n1);
   uint32_t* inv = keys + n1;
   int rc = upload_packed(h, pts, n, stride, s.xyz);
@@ -92,7 +100,8 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
     }
   const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
   const float cell = std::max(0.25f, ext / 1023.0f);
-  s.idx = ScanIndexDev{p4, lo, hi, keys, inv, (uint32_t)n, (uint32_t)nch, mn[0], mn[1], mn[2], 1.0f / cell};
+  s.idx = ScanIndexDev{p4, lo, hi, slo, shi, keys, inv, (uint32_t)n, (uint32_t)nch,
+                       mn[0], mn[1], mn[2], 1.0f / cell};
   if (n) {
     hipStream_t st = h->stream;
     auto fail = [&](int code) { free_scan(s); return code; };
@@ -115,6 +124,8 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
     hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.xyz,
                        h->sort_perm.as<uint32_t>(), (uint32_t)n, p4, inv);
     hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, st, p4, (uint32_t)n, lo, hi);
+    hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, p4,
+                       (uint32_t)n, (uint32_t)nsb, slo, shi);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
       set_err("scan indexing failed: %s", hipGetErrorString(hipGetLastError()));
       return fail(GLOC_ERR_HIP);
@@ -124,7 +135,7 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   return GLOC_OK;
 }
 
-void init_state(CandState& st, const float* T16) {
+void init_state(CandState& st, const float* T16, uint32_t ransac_iters = 0) {
   memset(&st, 0, sizeof(st));
   static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const float* T = T16 ? T16 : I16;
@@ -137,6 +148,7 @@ void init_state(CandState& st, const float* T16) {
     st.Td[9 + i] = (double)T[4 * i + 3];
   }
   st.best_h = 0xFFFFFFFFu;
+  st.niters = ransac_iters;
 }
 
 int launch_nn(gloc_reg* h, const DevScan& src, int n_cand, size_t ld, bool warm) {
@@ -149,13 +161,25 @@ int launch_nn(gloc_reg* h, const DevScan& src, int n_cand, size_t ld, bool warm)
                        h->cands.as<CandDesc>(), h->states.as<CandState>(), h->corr.as<uint32_t>(),
                        h->d2.as<float>(), ld);
   } else {
-    dim3 grid((n_src + 256 * CS - 1) / (256 * CS), (unsigned)n_cand);
-    hipLaunchKernelGGL(nn_culled_kernel, grid, dim3(256), 0, h->stream, src.idx.pts, n_src,
-                       h->ccands.as<CulledCand>(), h->states.as<CandState>(),
-                       warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr,
-                       h->corr.as<uint32_t>(), h->d2.as<float>(), ld,
-                       h->prof.enabled ? h->counters.as<unsigned long long>()
-                                       : (unsigned long long*)nullptr);
+    const int cs = h->nn_src_per_lane;
+    dim3 grid((n_src + 256 * cs - 1) / (256 * cs), (unsigned)n_cand);
+    if (h->trace_on) {
+      h->trace_waves = (size_t)grid.x * grid.y * 4;
+      if (h->trace.ensure(h->trace_waves * 16, h->stream)) return GLOC_ERR_NOMEM;
+      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 16, h->stream));
+    }
+#define LAUNCH_CULLED(CS_)                                                                       \
+  hipLaunchKernelGGL(nn_culled_kernel<CS_>, grid, dim3(256), 0, h->stream, src.idx.pts, n_src,   \
+                     h->ccands.as<CulledCand>(), h->states.as<CandState>(),                      \
+                     warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr,                   \
+                     h->corr.as<uint32_t>(), h->d2.as<float>(), ld,                              \
+                     h->prof.enabled ? h->counters.as<unsigned long long>()                      \
+                                     : (unsigned long long*)nullptr,                             \
+                     h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
+    if (cs == 1) LAUNCH_CULLED(1);
+    else if (cs == 2) LAUNCH_CULLED(2);
+    else LAUNCH_CULLED(4);
+#undef LAUNCH_CULLED
   }
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;
@@ -177,7 +201,8 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
   const size_t ld = ((size_t)n_src + 63) & ~(size_t)63;
   hipStream_t s = h->stream;
   h->h_states.resize(n_cand);
-  for (int c = 0; c < n_cand; ++c) init_state(h->h_states[c], init_T ? init_T + 16 * c : nullptr);
+  for (int c = 0; c < n_cand; ++c)
+    init_state(h->h_states[c], init_T ? init_T + 16 * c : nullptr, prm->ransac_iters);
   GLOC_TRY(h->cands.ensure(sizeof(CandDesc) * n_cand, s));
   GLOC_TRY(h->ccands.ensure(sizeof(CulledCand) * n_cand, s));
   if (!h->counters.p) {
@@ -225,15 +250,34 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
     GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)H * n_cand, s));
     const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
     {
+      // phase A: the first 256 hypotheses; phase B: the rest, skipped per candidate once the
+      // adaptive iteration count has been reached (then its blocks exit at once)
       ProfScope ps(h->prof, "ransac_score", s);
-      dim3 grid((H + 255) / 256, (n_src + SC_CHUNK - 1) / SC_CHUNK, n_cand);
-      hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
-                         n_src, H, h->Rt.as<float>(), h->valid.as<uint32_t>(), thr2,
+      const uint32_t HA = std::min<uint32_t>(H, 256);
+      const unsigned cchunks = (n_src + SC_CHUNK - 1) / SC_CHUNK;
+      hipLaunchKernelGGL(ransac_score_kernel, dim3((HA + 255) / 256, cchunks, n_cand), dim3(256), 0, s,
+                         h->pairs.as<f32x4>(), ld, n_src, H, 0u, h->Rt.as<float>(),
+                         h->valid.as<uint32_t>(), thr2, (const CandState*)nullptr,
                          h->inliers.as<uint32_t>());
-      GLOC_HIP(hipGetLastError());
-      hipLaunchKernelGGL(ransac_best_kernel, dim3(n_cand), dim3(256), 0, s,
-                         h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
-                         n_src, prm->min_inlier_ratio, h->states.as<CandState>());
+      if (H > HA) {
+        hipLaunchKernelGGL(ransac_scan_kernel<false>, dim3(n_cand), dim3(64), 0, s,
+                           h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
+                           0u, HA, n_src, prm->ransac_confidence, prm->min_inlier_ratio,
+                           h->states.as<CandState>());
+        hipLaunchKernelGGL(ransac_score_kernel, dim3((H - HA + 255) / 256, cchunks, n_cand), dim3(256),
+                           0, s, h->pairs.as<f32x4>(), ld, n_src, H, HA, h->Rt.as<float>(),
+                           h->valid.as<uint32_t>(), thr2, h->states.as<CandState>(),
+                           h->inliers.as<uint32_t>());
+        hipLaunchKernelGGL(ransac_scan_kernel<true>, dim3(n_cand), dim3(64), 0, s,
+                           h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
+                           HA, H, n_src, prm->ransac_confidence, prm->min_inlier_ratio,
+                           h->states.as<CandState>());
+      } else {
+        hipLaunchKernelGGL(ransac_scan_kernel<true>, dim3(n_cand), dim3(64), 0, s,
+                           h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
+                           0u, HA, n_src, prm->ransac_confidence, prm->min_inlier_ratio,
+                           h->states.as<CandState>());
+      }
       GLOC_HIP(hipGetLastError());
     }
     {
@@ -250,7 +294,7 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
         hipLaunchKernelGGL(sumd2_kernel, dim3(n_cand), dim3(256), 0, s, h->d2.as<float>(), ld,
                            n_src, n_cand, h->states.as<CandState>());
       }
-      hipLaunchKernelGGL(solve_kernel<1>, dim3((n_cand + 63) / 64), dim3(64), 0, s,
+      hipLaunchKernelGGL(solve_kernel<1>, dim3(n_cand), dim3(64), 0, s,
                          h->partials.as<double>(), nblocks, n_cand, h->states.as<CandState>());
       GLOC_HIP(hipGetLastError());
     }
@@ -269,7 +313,7 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
     }
     {
       ProfScope ps(h->prof, "solve", s);
-      hipLaunchKernelGGL(solve_kernel<0>, dim3((n_cand + 63) / 64), dim3(64), 0, s,
+      hipLaunchKernelGGL(solve_kernel<0>, dim3(n_cand), dim3(64), 0, s,
                          h->partials.as<double>(), nblocks, n_cand, h->states.as<CandState>());
       GLOC_HIP(hipGetLastError());
     }
@@ -313,6 +357,8 @@ void gloc_reg_default_params(gloc_reg_params* p) {
   p->icp_iters = 30;  // registration/global_registration.cpp:242
   p->max_corr_dist = 0.f;
   p->seed = 1234;
+  p->ransac_confidence = 0.99f;  // cv::estimateAffinePartial2D's default, used by the reference
+  p->reserved_ = 0;
 }
 
 int gloc_reg_create(int device, gloc_reg** out) {
@@ -382,6 +428,11 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
     GLOC_REQUIRE(value == GLOC_REG_NN_CULLED || value == GLOC_REG_NN_EXHAUSTIVE, GLOC_ERR_INVALID,
                  "bad nn mode %lld", (long long)value);
     h->nn_mode = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {
+    GLOC_REQUIRE(value == 1 || value == 2 || value == 4, GLOC_ERR_INVALID, "must be 1, 2 or 4");
+    h->nn_src_per_lane = (int)value;
     return GLOC_OK;
   }
   set_err("unknown option %d", option);
@@ -541,8 +592,9 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   GLOC_HIP(hipGetLastError());
   dim3 grid((n_hyp + 255) / 256, (unsigned)((n + SC_CHUNK - 1) / SC_CHUNK), 1);
   hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
-                     (uint32_t)n, n_hyp, h->Rt.as<float>(), h->valid.as<uint32_t>(),
-                     inlier_thresh * inlier_thresh, h->inliers.as<uint32_t>());
+                     (uint32_t)n, n_hyp, 0u, h->Rt.as<float>(), h->valid.as<uint32_t>(),
+                     inlier_thresh * inlier_thresh, (const CandState*)nullptr,
+                     h->inliers.as<uint32_t>());
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipMemcpyAsync(out_Rt, h->Rt.p, sizeof(float) * 12 * (size_t)n_hyp,
                           hipMemcpyDeviceToHost, s));
@@ -554,7 +606,7 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   return GLOC_OK;
 }
 
-int gloc_reg_nn_stats(gloc_reg* h, uint64_t* chunks_evaluated, uint64_t* launches) {
+int gloc_reg_nn_stats(gloc_reg* h, uint64_t* pairs_evaluated, uint64_t* launches) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   GLOC_HIP(hipSetDevice(h->device));
   unsigned long long c = 0;
@@ -562,8 +614,22 @@ int gloc_reg_nn_stats(gloc_reg* h, uint64_t* chunks_evaluated, uint64_t* launche
     GLOC_HIP(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     GLOC_HIP(hipStreamSynchronize(h->stream));
   }
-  if (chunks_evaluated) *chunks_evaluated = c;
+  if (pairs_evaluated) *pairs_evaluated = c;
   if (launches) *launches = h->nn_launches;
+  return GLOC_OK;
+}
+
+// Developer aid (not part of include/gloc3d.h): per-wave trace of the LAST culled 1-NN launch.
+int gloc_reg_debug_trace(gloc_reg* h, int enable, uint32_t* out, size_t cap_waves, size_t* n_waves) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  h->trace_on = enable != 0;
+  if (n_waves) *n_waves = h->trace_waves;
+  if (out && h->trace.p) {
+    const size_t n = std::min(cap_waves, h->trace_waves);
+    GLOC_HIP(hipMemcpyAsync(out, h->trace.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+  }
   return GLOC_OK;
 }
 

@@ -36,8 +36,8 @@ struct CandState {
   uint32_t best_h, best_inl;
   int ok, frozen;
   double sum_d2;      // of the last S1 pass
-  uint32_t n_pairs;
-  uint32_t pad_;
+  uint32_t niters;    // RANSAC: iterations still allowed (adaptive stop), starts at ransac_iters
+  int ransac_done;
 };
 
 __device__ __forceinline__ void xform(const float* __restrict__ T, float x, float y, float z,
@@ -329,13 +329,16 @@ constexpr int SC_STAGE = 256;
 
 __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restrict__ pairs,
                                                            size_t ld, uint32_t n, uint32_t n_hyp,
+                                                           uint32_t h_begin,
                                                            const float* __restrict__ Rt,
                                                            const uint32_t* __restrict__ valid,
                                                            float thr2,
+                                                           const CandState* __restrict__ states,
                                                            uint32_t* __restrict__ inliers) {
   __shared__ f32x4 sp[2 * SC_STAGE];
   const int cand = blockIdx.z;
-  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
+  const uint32_t h = h_begin + blockIdx.x * 256 + threadIdx.x;
   const bool hv = h < n_hyp && valid[(size_t)cand * n_hyp + h];
   float T[12];
 #pragma unroll
@@ -365,45 +368,90 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);
 }
 
-// K5c.  best = max inliers, tie -> smallest h.  One work-group per candidate.
-__global__ __launch_bounds__(256) void ransac_best_kernel(const uint32_t* __restrict__ inliers,
-                                                          const uint32_t* __restrict__ valid,
-                                                          const float* __restrict__ Rt,
-                                                          uint32_t n_hyp, uint32_t n,
-                                                          float min_inlier_ratio,
-                                                          CandState* __restrict__ states) {
-  __shared__ unsigned long long best_sh[256];
+// Iterations after which a 3-point RANSAC reaches `conf` with inlier ratio inl/n: smallest k with
+// (1 - w^3)^k <= 1 - conf by repeated multiplication (no libm, so CPU and GPU agree), capped.
+__device__ inline uint32_t ransac_needed_iters(uint32_t inl, uint32_t n, float conf,
+                                               uint32_t max_iters) {
+  const double w = (double)inl / (double)n;
+  const double q = 1.0 - (w * w) * w;
+  const double target = 1.0 - (double)conf;
+  double pw = 1.0;
+  uint32_t k = 0;
+  while (pw > target && k < max_iters) {
+    pw = pw * q;
+    k++;
+  }
+  return k;
+}
+
+// K5c.  The sequential RANSAC rule over hypotheses [h0, h1): best = first hypothesis with strictly
+// more inliers than all before it; every new best may lower the iteration count (OpenCV's adaptive
+// stop, which the reference runs with its default confidence); hypotheses at or beyond the count
+// are never considered.  One wave per candidate: 64 hypotheses per step, records found with a
+// prefix maximum and handled in order.  FINAL: also publish ok / best (R,t).
+template <bool FINAL>
+__global__ __launch_bounds__(64) void ransac_scan_kernel(const uint32_t* __restrict__ inliers,
+                                                         const uint32_t* __restrict__ valid,
+                                                         const float* __restrict__ Rt,
+                                                         uint32_t n_hyp, uint32_t h0, uint32_t h1,
+                                                         uint32_t n, float conf,
+                                                         float min_inlier_ratio,
+                                                         CandState* __restrict__ states) {
   const int cand = blockIdx.x;
-  unsigned long long best = 0;  // (inliers << 32) | (0xFFFFFFFF - h): larger is better
-  for (uint32_t h = threadIdx.x; h < n_hyp; h += 256) {
-    if (!valid[(size_t)cand * n_hyp + h]) continue;
-    const uint32_t inl = inliers[(size_t)cand * n_hyp + h];
-    if (inl == 0) continue;
-    const unsigned long long key = ((unsigned long long)inl << 32) | (0xFFFFFFFFu - h);
-    best = key > best ? key : best;
+  const int lane = threadIdx.x;
+  CandState& st = states[cand];
+  uint32_t niters = st.niters, best_inl = st.best_inl, best_h = st.best_h;
+  int done = st.ransac_done;
+  const bool adaptive = conf > 0.f && conf < 1.f;
+  for (uint32_t base = h0; base < h1 && !done; base += 64) {
+    if (base >= niters) {
+      done = 1;
+      break;
+    }
+    const uint32_t h = base + lane;
+    uint32_t inl = 0;
+    if (h < h1 && valid[(size_t)cand * n_hyp + h]) inl = inliers[(size_t)cand * n_hyp + h];
+    // exclusive prefix maximum over the lanes, seeded with the best so far
+    uint32_t pm = inl;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(pm, o);
+      if (lane >= o) pm = pm > t ? pm : t;
+    }
+    uint32_t before = __shfl_up(pm, 1);
+    if (lane == 0) before = 0;
+    before = before > best_inl ? before : best_inl;
+    unsigned long long rec = __ballot(inl > before);
+    while (rec) {
+      const int b = __ffsll((long long)rec) - 1;
+      rec &= rec - 1;
+      const uint32_t hh = base + b;
+      if (hh >= niters) {
+        done = 1;
+        break;
+      }
+      best_inl = (uint32_t)__builtin_amdgcn_readlane((int)inl, b);
+      best_h = hh;
+      if (adaptive) {
+        const uint32_t need = ransac_needed_iters(best_inl, n, conf, n_hyp);
+        niters = need < niters ? need : niters;
+      }
+    }
   }
-  best_sh[threadIdx.x] = best;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o && best_sh[threadIdx.x + o] > best_sh[threadIdx.x])
-      best_sh[threadIdx.x] = best_sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    CandState& st = states[cand];
-    const unsigned long long b = best_sh[0];
-    if (b == 0) {
-      st.best_h = 0xFFFFFFFFu;
-      st.best_inl = 0;
-      st.ok = 0;
-    } else {
-      const uint32_t h = 0xFFFFFFFFu - (uint32_t)b;
-      st.best_h = h;
-      st.best_inl = (uint32_t)(b >> 32);
-      uint32_t min_inl = (uint32_t)(min_inlier_ratio * (float)n);
-      if (min_inl < 3) min_inl = 3;
-      st.ok = st.best_inl >= min_inl;
-      for (int i = 0; i < 12; ++i) st.bestRt[i] = Rt[((size_t)cand * n_hyp + h) * 12 + i];
+  if (!done && h1 >= niters) done = 1;
+  if (lane == 0) {
+    st.niters = niters;
+    st.best_inl = best_inl;
+    st.best_h = best_h;
+    st.ransac_done = done;
+    if (FINAL) {
+      if (best_h == 0xFFFFFFFFu) {
+        st.ok = 0;
+      } else {
+        uint32_t min_inl = (uint32_t)(min_inlier_ratio * (float)n);
+        if (min_inl < 3) min_inl = 3;
+        st.ok = best_inl >= min_inl;
+        for (int i = 0; i < 12; ++i) st.bestRt[i] = Rt[((size_t)cand * n_hyp + best_h) * 12 + i];
+      }
     }
   }
 }
@@ -480,19 +528,24 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
   }
 }
 
-// K6b.  One thread per candidate: reduce the partials in block order, Kabsch, compose.
+// K6b.  One wave per candidate: lanes 0..16 each reduce one moment over the blocks in block order
+// (deterministic), lane 0 then solves Kabsch and composes.
 // MODE 0 (ICP step): T <- dT * T.   MODE 1 (RANSAC refit): T <- T_r * T0, falling back to the
 // un-refitted best hypothesis when fewer than 3 inliers, or to T0 when no hypothesis was valid.
 template <int MODE>
-__global__ void solve_kernel(const double* __restrict__ partials, int nblocks, int n_cand,
-                             CandState* __restrict__ states) {
-  const int cand = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ partials, int nblocks,
+                                                   int n_cand, CandState* __restrict__ states) {
+  const int cand = blockIdx.x;
+  const int lane = threadIdx.x;
   if (cand >= n_cand) return;
-  CandState& st = states[cand];
+  double acc = 0.0;
+  if (lane < ACC_NV)
+    for (int b = 0; b < nblocks; ++b) acc += partials[((size_t)cand * nblocks + b) * ACC_NV + lane];
   double v[ACC_NV];
-  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
-  for (int b = 0; b < nblocks; ++b)
-    for (int k = 0; k < ACC_NV; ++k) v[k] += partials[((size_t)cand * nblocks + b) * ACC_NV + k];
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) v[k] = __shfl(acc, k);
+  if (lane != 0) return;
+  CandState& st = states[cand];
   double Rd[9], td[3];
   bool have = false;
   if (MODE == 0) {

@@ -141,9 +141,14 @@ typedef struct gloc_reg_params {
   uint32_t icp_iters;     /* 30 (global_registration.cpp:242) */
   float max_corr_dist;    /* <= 0: no correspondence rejection (PCL default) */
   uint64_t seed;          /* RANSAC sampling seed */
+  float ransac_confidence; /* 0.99: adaptive stop as in OpenCV's RANSAC, which the reference calls with
+                             its default confidence (loop_detector.cpp:256-257): ransac_iters is the
+                             cap, hypotheses beyond the iteration count that reaches this confidence
+                             for the best inlier ratio so far are not considered.  <= 0 or >= 1: off */
+  uint32_t reserved_;
 } gloc_reg_params;
 
-/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234). */
+/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99). */
 void gloc_reg_default_params(gloc_reg_params* p);
 
 int gloc_reg_create(int device, gloc_reg** out);
@@ -153,7 +158,8 @@ int gloc_reg_synchronize(gloc_reg* h);
 int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
 enum {
   GLOC_REG_OPT_PROFILE = 1, /* 1: bracket every kernel with HIP events (gloc_reg_profile) */
-  GLOC_REG_OPT_NN_MODE = 2  /* how S1 (exact 1-NN) is searched; the result is identical */
+  GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
+  GLOC_REG_OPT_NN_SRC_PER_LANE = 3 /* culled search tuning: source points per lane (1, 2 or 4) */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Morton-sorted scans, chunk boxes, skip what cannot win */
@@ -203,9 +209,9 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
  * "transform"), as gloc_knn_profile. */
 int gloc_reg_profile(gloc_reg* h, const char* kernel, double* total_ms, uint64_t* launches);
 int gloc_reg_profile_reset(gloc_reg* h);
-/* With profiling on: 128-target chunks evaluated by the culled 1-NN kernel (each against the 256
- * source points of one wave) and 1-NN launches since the last gloc_reg_profile_reset. */
-int gloc_reg_nn_stats(gloc_reg* h, uint64_t* chunks_evaluated, uint64_t* launches);
+/* With profiling on: (source, target) pairs evaluated by the culled 1-NN kernel and the number of
+ * 1-NN launches since the last gloc_reg_profile_reset. */
+int gloc_reg_nn_stats(gloc_reg* h, uint64_t* pairs_evaluated, uint64_t* launches);
 
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).

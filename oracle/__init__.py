@@ -31,6 +31,8 @@ class RegParams(C.Structure):
         ("icp_iters", C.c_uint32),
         ("max_corr_dist", C.c_float),
         ("seed", C.c_uint64),
+        ("ransac_confidence", C.c_float),
+        ("reserved_", C.c_uint32),
     ]
 
 
@@ -188,10 +190,11 @@ def transform_points(T, xyz):
 
 
 def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
-            min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234):
+            min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99):
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
-    prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed)
+    prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
+                    ransac_confidence, 0)
     T = np.empty(16, np.float32)
     rmse, inl, hyp, ok = C.c_float(), C.c_uint32(), C.c_uint32(), C.c_int()
     if init_T is not None:

@@ -66,7 +66,13 @@ typedef struct oracle_reg_params {
   uint32_t icp_iters;       /* 30: registration/global_registration.cpp:242 */
   float max_corr_dist;      /* <=0: no rejection (PCL default) */
   uint64_t seed;
+  float ransac_confidence;  /* adaptive stop (OpenCV RANSAC default 0.99); <=0 or >=1: off */
+  uint32_t reserved_;
 } oracle_reg_params;
+
+/* Iterations after which a 3-point RANSAC reaches `conf` given `inl` of `n` inliers: the smallest k
+ * with (1 - w^3)^k <= 1 - conf, by repeated multiplication (no libm: CPU and GPU agree), capped. */
+uint32_t oracle_ransac_needed_iters(uint32_t inl, uint32_t n, float conf, uint32_t max_iters);
 
 /* p' = R p + t in fp32, fixed order ((r0*x + r1*y) + r2*z) + t, no contraction. */
 void oracle_transform_points(const float* T16, const float* xyz, size_t n, float* out_xyz);

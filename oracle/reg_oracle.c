@@ -366,6 +366,19 @@ uint32_t oracle_count_inliers(const float* src_xyz, const float* tgt_xyz, const 
   return cnt;
 }
 
+uint32_t oracle_ransac_needed_iters(uint32_t inl, uint32_t n, float conf, uint32_t max_iters) {
+  const double w = (double)inl / (double)n;
+  const double q = 1.0 - (w * w) * w;
+  const double target = 1.0 - (double)conf;
+  double pw = 1.0;
+  uint32_t k = 0;
+  while (pw > target && k < max_iters) {
+    pw = pw * q;
+    k++;
+  }
+  return k;
+}
+
 /* Kabsch over pairs (src_i, tgt_corr[i]) with optional gate d2(R0 src_i + t0, tgt) < gate2
  * (gate2 <= 0: all pairs).  Raw moments accumulated in fp64, sequentially. */
 static uint32_t kabsch_pairs(const float* src, const float* tgt, const uint32_t* corr, uint32_t n,
@@ -451,7 +464,12 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
     /* S1 under T0, S2 on (T0 p, q) pairs */
     MOVE_AND_MATCH();
     float bR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bt[3] = {0, 0, 0};
-    for (uint32_t h = 0; h < prm->ransac_iters; ++h) {
+    /* sequential RANSAC with OpenCV's adaptive iteration count (the reference calls
+     * cv::estimateAffinePartial2D with its default confidence 0.99, loop_detector.cpp:256-257):
+     * every improvement may lower the number of iterations still to run */
+    const int adaptive = prm->ransac_confidence > 0.0f && prm->ransac_confidence < 1.0f;
+    uint32_t niters = prm->ransac_iters;
+    for (uint32_t h = 0; h < niters; ++h) {
       float R[9], t[3];
       if (!oracle_ransac_hypothesis(moved, tgt_xyz, corr, n, prm->seed, cand_id, h, R, t)) continue;
       const uint32_t inl = oracle_count_inliers(moved, tgt_xyz, corr, n, R, t, prm->inlier_thresh);
@@ -460,6 +478,10 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
         best_h = h;
         memcpy(bR, R, sizeof(bR));
         memcpy(bt, t, sizeof(bt));
+        if (adaptive) {
+          const uint32_t need = oracle_ransac_needed_iters(inl, n, prm->ransac_confidence, prm->ransac_iters);
+          if (need < niters) niters = need;
+        }
       }
     }
     uint32_t min_inl = (uint32_t)(prm->min_inlier_ratio * (float)n);

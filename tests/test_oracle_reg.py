@@ -82,3 +82,13 @@ def test_pose_error_metric(oracle_mod):
     # ~180 degree flips are forgiven (global_localization.cpp:305)
     er, _ = oracle_mod.pose_error(a, synth.se3(10.0 + 179.0, (1, 2, 3)))
     assert abs(er - 1.0) < 1e-2
+
+
+def test_adaptive_ransac_iteration_rule(oracle_mod):
+    L = oracle_mod.lib()
+    L.oracle_ransac_needed_iters.restype = __import__("ctypes").c_uint32
+    f = lambda inl, n, conf, cap: L.oracle_ransac_needed_iters(inl, n, __import__("ctypes").c_float(conf), cap)
+    assert f(1000, 1000, 0.99, 3000) == 1                       # all inliers: one sample suffices
+    assert f(700, 1000, 0.99, 3000) == 11                       # log(0.01)/log(1-0.343) = 10.96
+    assert f(100, 1000, 0.99, 3000) == 3000                     # 4603 needed: capped
+    assert f(0, 1000, 0.99, 3000) == 3000

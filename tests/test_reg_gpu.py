@@ -84,14 +84,17 @@ def test_ransac_hypotheses_bit_exact(reg, oracle_mod, scans):
             assert L.oracle_count_inliers(s, t, corr, s.shape[0], R, tt, 0.6) == inl[h], h
 
 
-def test_batch_matches_oracle(reg, capi, oracle_mod, scans):
+@pytest.mark.parametrize("conf", [0.99, 0.0, 0.999999])
+def test_batch_matches_oracle(reg, capi, oracle_mod, scans, conf):
+    """conf 0.99: adaptive stop inside the first 256 hypotheses; 0: all 500 scored; 0.999999: the
+    stop lands in the second phase."""
     q = np.ascontiguousarray(scans["B"][::16])
     cands = [np.ascontiguousarray(scans["A"][::4]), np.ascontiguousarray(scans["A"][1::5]),
              np.ascontiguousarray(scans["C"][::4])]
-    prm = capi.default_reg_params(ransac_iters=500, icp_iters=10)
+    prm = capi.default_reg_params(ransac_iters=500, icp_iters=10, ransac_confidence=conf)
     g = reg.batch(q, cands, params=prm)
     for c, cd in enumerate(cands):
-        o = oracle_mod.reg_one(q, cd, cand_id=c, ransac_iters=500, icp_iters=10)
+        o = oracle_mod.reg_one(q, cd, cand_id=c, ransac_iters=500, icp_iters=10, ransac_confidence=conf)
         assert np.abs(g["T"][c][:3, 3] - o["T"][:3, 3]).max() < POSE_TOL_M
         assert _rot_angle(g["T"][c][:3, :3], o["T"][:3, :3]) < POSE_TOL_RAD
         assert g["inliers"][c] == o["inliers"] and bool(g["ok"][c]) == o["ok"]

@@ -59,11 +59,12 @@ prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20)
 import sys as _s
 mode = int(_s.argv[1]) if len(_s.argv) > 1 else 0
 reg.set_option(capi.REG_OPT_NN_MODE, mode)
+if len(_s.argv) > 2: reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, int(_s.argv[2]))
 reg.batch_ids(qid, cand_ids[:2], params=capi.default_reg_params(ransac_iters=100, icp_iters=1))
 reg.profile_reset()
 t0 = time.time(); g = reg.batch_ids(qid, cand_ids, params=prm); t1 = time.time()
 ch, nl = reg.nn_stats()
-print(f"nn mode {mode}: chunks evaluated {ch} over {nl} launches -> {ch*256*128/max(nl,1):.3e} pairs/launch evaluated")
+print(f"nn mode {mode}: {ch/max(nl,1):.3e} pairs/launch evaluated over {nl} launches")
 print(f"full-size 1x20 cands ({B.shape[0]} src pts, ~{A.shape[0]} tgt): wall {t1-t0:.3f}s -> {1/(t1-t0):.2f} q/s")
 for n in ["nn", "transform", "ransac_hyp", "ransac_score", "accum", "solve"]:
     ms, cnt = reg.profile(n)

@@ -3,6 +3,7 @@
 // main.py:317-324 (faiss.IndexFlatL2 add/search) of the reference.
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <new>
 
 #include "common.hpp"
@@ -23,6 +24,8 @@ struct gloc_knn {
   DevBuf dn_max;    // 1 x uint32 (bits of the largest row norm)
   DevBuf dist;      // exact: [nq][ld]; mfma: [splits][Qpad][ld]
   DevBuf keys;      // select output [nq][K]
+  DevBuf klists, klists2;  // per-chunk K-lists during selection
+  DevBuf exact;     // rerank: reference-order distances [nq][KC]
   DevBuf keys2;     // rerank output [nq][k]
   DevBuf qnorm;     // [nq]
   DevBuf flags;     // [nq] int
@@ -88,19 +91,49 @@ int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n
   return GLOC_OK;
 }
 
+// Per-query top-K of h->dist: chunked threshold selection + merge(s).  MODE as select_chunk_kernel.
+template <int MODE>
+int run_select(gloc_knn* h, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
+               int n_splits, uint64_t* d_keys_out) {
+  ProfScope ps(h->prof, "select", h->stream);
+  const int per_group = SEL_LIST / K;  // lists one merge can take
+  int E = (n_range + 256 * per_group - 1) / (256 * per_group);
+  E = std::max(E, 8);
+  E = std::min(E, std::max(1, SEL_LIST / K));
+  int nlists = (n_range + 256 * E - 1) / (256 * E);
+  GLOC_TRY(h->klists.ensure((size_t)nq * nlists * K * sizeof(uint64_t), h->stream));
+  uint64_t* cur = nlists == 1 ? d_keys_out : h->klists.as<uint64_t>();
+  hipLaunchKernelGGL(select_chunk_kernel<MODE>, dim3(nlists, nq), dim3(256), 0, h->stream,
+                     h->dist.as<float>(), ld, strideP, n_splits, h->qnorm.as<float>(),
+                     h->norms.as<float>(), first, n_range, K, E, cur);
+  GLOC_HIP(hipGetLastError());
+  bool flip = false;
+  while (nlists > 1) {
+    const int ngroups = (nlists + per_group - 1) / per_group;
+    uint64_t* nxt;
+    if (ngroups == 1) {
+      nxt = d_keys_out;
+    } else {
+      DevBuf& b = flip ? h->klists : h->klists2;
+      GLOC_TRY(b.ensure((size_t)nq * ngroups * K * sizeof(uint64_t), h->stream));
+      nxt = b.as<uint64_t>();
+    }
+    hipLaunchKernelGGL(select_merge_kernel, dim3(ngroups, nq), dim3(256), 0, h->stream, cur, nlists,
+                       per_group, K, nxt);
+    GLOC_HIP(hipGetLastError());
+    cur = nxt;
+    nlists = ngroups;
+    flip = !flip;
+  }
+  return GLOC_OK;
+}
+
 int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
               uint64_t* d_keys_out) {
   const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
   GLOC_TRY(h->dist.ensure((size_t)nq * ld * sizeof(float), h->stream));
   GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld));
-  {
-    ProfScope ps(h->prof, "select", h->stream);
-    hipLaunchKernelGGL(select_kernel<0>, dim3(nq), dim3(256), 0, h->stream, h->dist.as<float>(),
-                       ld, (size_t)0, 1, (const float*)nullptr, (const float*)nullptr, first,
-                       n_range, k, d_keys_out);
-    GLOC_HIP(hipGetLastError());
-  }
-  return GLOC_OK;
+  return run_select<0>(h, nq, k, first, n_range, ld, 0, 1, d_keys_out);
 }
 
 // ---- MFMA path -------------------------------------------------------------------------------
@@ -121,7 +154,7 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
     const int NT = nts[i], BN = 16 * NT * (4 / WQ);
     const long long ntiles = (n_range + BN - 1) / BN;
     for (int KS = 1; KS <= 16; KS <<= 1) {
-      if ((dim % (32 * KS)) != 0 && KS > 1) continue;
+      if ((dim % (64 * KS)) != 0 && KS > 1) continue;
       const int klen = (dim + KS - 1) / KS;
       if (klen < 128 && KS > 1) continue;
       const long long wgs = ntiles * qblocks * KS;
@@ -135,6 +168,12 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
       }
     }
   }
+  // developer override: GLOC3D_MFMA_PLAN="NT,KS"
+  if (const char* e = getenv("GLOC3D_MFMA_PLAN")) {
+    int nt = 0, ks = 0;
+    if (sscanf(e, "%d,%d", &nt, &ks) == 2 && nt > 0 && ks > 0)
+      best = MfmaPlan{WQ, nt, ks, BQ, 16 * nt * (4 / WQ)};
+  }
   return best;
 }
 
@@ -143,10 +182,16 @@ void launch_mfma_inst(gloc_knn* h, const MfmaPlan& p, const float* d_q, int nq, 
                       int n_range, size_t ld, size_t strideP) {
   dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ),
             (unsigned)p.KS);
-  const int kps = (((int)h->dim + p.KS - 1) / p.KS + 31) & ~31;
-  hipLaunchKernelGGL((dist_mfma_kernel<WQ, NT>), grid, dim3(256), 0, h->stream,
-                     h->rows.as<float>(), d_q, h->dist.as<float>(), (int)h->dim, first, n_range,
-                     nq, kps, ld, strideP);
+  const int kps = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+  static const int bk = getenv("GLOC3D_MFMA_BK") ? atoi(getenv("GLOC3D_MFMA_BK")) : 64;
+  if (bk == 32 || kps < 128)
+    hipLaunchKernelGGL((dist_mfma_kernel<WQ, NT, 8>), grid, dim3(256), 0, h->stream,
+                       h->rows.as<float>(), d_q, h->dist.as<float>(), (int)h->dim, first, n_range,
+                       nq, kps, ld, strideP);
+  else
+    hipLaunchKernelGGL((dist_mfma_kernel<WQ, NT, 16>), grid, dim3(256), 0, h->stream,
+                       h->rows.as<float>(), d_q, h->dist.as<float>(), (int)h->dim, first, n_range,
+                       nq, kps, ld, strideP);
 }
 
 int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
@@ -179,19 +224,25 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 #undef MF
     GLOC_HIP(hipGetLastError());
   }
+  GLOC_TRY(run_select<1>(h, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));
   {
-    ProfScope ps(h->prof, "select", h->stream);
-    hipLaunchKernelGGL(select_kernel<1>, dim3(nq), dim3(256), 0, h->stream, h->dist.as<float>(),
-                       ld, strideP, p.KS, h->qnorm.as<float>(), h->norms.as<float>(), first,
-                       n_range, KC, h->keys.as<uint64_t>());
-    GLOC_HIP(hipGetLastError());
-  }
-  {
+    // rounding bound of the coarse distance against the reference-order distance:
+    //   reference chain          (D/4 + 4) u d2
+    //   MFMA chains of <= 64 fma, nch partial sums, KS split sums, norms (D/64 + 6), 3 final ops
     ProfScope ps(h->prof, "rerank", h->stream);
-    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(64), 0, h->stream, h->rows.as<float>(), d_q,
-                       (int)h->dim, h->keys.as<uint64_t>(), KC, k, n_range,
-                       h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), d_keys_out,
-                       h->flags.as<int>());
+    const float u = 5.9604645e-8f;
+    const int kps = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+    const float eps_rel_d = 1.05f * u * (float)(h->dim / 4 + 4);
+    const float eps_rel_n = 1.05f * u * (float)(64 + (kps + 63) / 64 + p.KS + h->dim / 64 + 6 + 3 + 4);
+    GLOC_TRY(h->exact.ensure((size_t)nq * KC * sizeof(float), h->stream));
+    hipLaunchKernelGGL(rerank_dist_kernel, dim3((KC + RR - 1) / RR, nq), dim3(64), 0, h->stream,
+                       h->rows.as<float>(), d_q, (int)h->dim, h->keys.as<uint64_t>(), KC, k,
+                       h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n,
+                       h->exact.as<float>());
+    hipLaunchKernelGGL(rerank_final_kernel, dim3(nq), dim3(64), 0, h->stream,
+                       h->keys.as<uint64_t>(), h->exact.as<float>(), KC, k, n_range,
+                       h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n,
+                       d_keys_out, h->flags.as<int>());
     GLOC_HIP(hipGetLastError());
   }
   h->stats.last_n_tile = (uint32_t)p.BN;
@@ -298,6 +349,9 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->dn_max.release();
   h->dist.release();
   h->keys.release();
+  h->klists.release();
+  h->klists2.release();
+  h->exact.release();
   h->keys2.release();
   h->qnorm.release();
   h->flags.release();

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict
 // WQ waves along the queries (16 each), 4/WQ along the rows, NT 16-row tiles per wave.
 // LDS image per K-step of 32: [kq = k/4][row][4 floats], rows 0..BQ-1 queries, BQ.. db rows,
 // one 16-B slot of padding per kq plane (conflict-free ds_write_b128, <=2-way ds_read_b128).
-template <int WQ, int NT>
+template <int WQ, int NT, int KQ /* K-step = 4*KQ floats: 8 -> 32, 16 -> 64 */>
 __global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict__ db,
                                                         const float* __restrict__ queries,
                                                         float* __restrict__ P, int dim,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict_
   constexpr int BN = 16 * NT * WN;
   constexpr int ROWS = BQ + BN;
   constexpr int PLANE = ROWS + 1;  // float4 slots per kq plane
-  constexpr int KQ = 8;            // BK = 32
+  constexpr int BK = 4 * KQ;
   constexpr int NL = (ROWS * KQ + 255) / 256;
   __shared__ f32x4 lds[2 * KQ * PLANE];
 
@@ -194,77 +194,114 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict_
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
 
-  // per-thread load slots: slot -> (row, kq); 8 consecutive threads read one 128-B row segment
-  const float* src[NL];
-  int dst[NL];
-  bool ok[NL];
+  // per-thread load slots: slot -> (row, kq); KQ consecutive threads read one 16*KQ-byte row segment
+  const float* src[NL];  // never null: rows outside the tile read row 0 and are masked to zero
+  int dst[NL], kq4[NL];
+  bool ok[NL], rowv[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int slot = tid + i * 256;
-    const int row = slot >> 3, kq = slot & 7;
+    const int row = slot / KQ, kq = slot % KQ;
     ok[i] = slot < ROWS * KQ;
     dst[i] = kq * PLANE + row;
-    src[i] = nullptr;
+    kq4[i] = kq * 4;
+    src[i] = db + first_row * dim;
+    rowv[i] = false;
     if (ok[i]) {
       if (row < BQ) {
         const int qq = q0 + row;
-        if (qq < nq) src[i] = queries + (size_t)qq * dim + kq * 4;
+        if (qq < nq) {
+          src[i] = queries + (size_t)qq * dim;
+          rowv[i] = true;
+        }
       } else {
         const int jj = n0 + (row - BQ);
-        if (jj < n_range) src[i] = db + (first_row + (size_t)jj) * dim + kq * 4;
+        if (jj < n_range) {
+          src[i] = db + (first_row + (size_t)jj) * dim;
+          rowv[i] = true;
+        }
       }
     }
   }
-  f32x4 pre[NL];
-  auto gload = [&](int k) {
+  // Two register sets: the global loads of K-steps s+1 and s+2 are in flight while step s is
+  // multiplied, so a load has two MFMA phases to land (one phase was measured to leave the kernel
+  // bound by bytes in flight: 2.0 TB/s at one wave per SIMD).
+  f32x4 preA[NL], preB[NL];
+  // Unconditional loads (addresses clamped into the row, result masked): straight-line code lets
+  // the compiler wait with a COUNTED vmcnt instead of draining both register sets.
+  auto gload = [&](f32x4* pre, int k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int kk = k + (dst[i] / PLANE) * 4;  // = k + kq*4
-      if (src[i] && kk < kend) {
-        const f4u v = *reinterpret_cast<const f4u*>(src[i] + k);
-        pre[i] = f32x4{v.x, v.y, v.z, v.w};
-      } else {
-        pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      const int kk = k + kq4[i];
+      const int kc = kk < dim - 4 ? kk : dim - 4;
+      const f4u v = *reinterpret_cast<const f4u*>(src[i] + kc);
+      const bool use = rowv[i] && kk < kend;
+      pre[i] = use ? f32x4{v.x, v.y, v.z, v.w} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const f32x4* pre, int buf) {
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       if (ok[i]) lds[buf * KQ * PLANE + dst[i]] = pre[i];
   };
 
-  f32x4 acc[NT];
+  // acc: chain of at most 64 fused multiply-adds; tot: sum of those partial chains.  Keeping the
+  // chains short is what makes the rounding bound of the coarse distance tight.
+  f32x4 acc[NT], tot[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  gload(kbeg);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int a_row = wq * 16 + (lane & 15);
   const int b_row0 = BQ + wn * NT * 16 + (lane & 15);
-  for (int k = kbeg; k < kend; k += 32) {
-    const bool more = (k + 32) < kend;
-    if (more) gload(k + 32);
+  auto compute = [&](int buf, int k) {
     const f32x4* L = lds + buf * KQ * PLANE;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < KQ / 4; ++sub) {
       const int kq = sub * 4 + (lane >> 4);
       const f32x4 a = L[kq * PLANE + a_row];
+      f32x4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = L[kq * PLANE + b_row0 + t * 16];
+      // k-slot outer, tile inner: consecutive MFMAs hit different accumulators (the 16x16x4 form
+      // has a 40-cycle dependent latency against a 32-cycle issue interval)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+    if (BK >= 64 || ((k - kbeg) & 32) || (k + BK) >= kend) {  // every 64 k and at the end: flush
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f32x4 b = L[kq * PLANE + b_row0 + t * 16];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+        tot[t] += acc[t];
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (more) {
-      lstore(buf ^ 1);
+  };
+
+  gload(preA, kbeg);
+  lstore(preA, 0);
+  gload(preA, kbeg + BK);      // step 1 (zeros beyond kend)
+  gload(preB, kbeg + 2 * BK);  // step 2
+  __syncthreads();
+  for (int k = kbeg; k < kend; k += 2 * BK) {
+    // even step: data in buffer 0; preA holds step+1, preB step+2
+    compute(0, k);
+    if (k + BK < kend) {
+      lstore(preA, 1);
+      gload(preA, k + 3 * BK);
       __syncthreads();
-      buf ^= 1;
+      compute(1, k + BK);
+      if (k + 2 * BK < kend) {
+        lstore(preB, 0);
+        gload(preB, k + 4 * BK);
+        __syncthreads();
+      }
     }
   }
   // C/D map of the 16x16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -276,19 +313,25 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qq = q0 + wq * 16 + (lane >> 4) * 4 + r;
-        Pz[(size_t)qq * ldP + j] = acc[t][r];  // rows q >= nq land in the padded part of P
+        Pz[(size_t)qq * ldP + j] = tot[t][r];  // rows q >= nq land in the padded part of P
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 (top-k part): per-query top-K of a distance row, LDS-staged.  One work-group per query.
-// Elements pass a running threshold tau into an LDS buffer; when the buffer passes half full it
-// is bitonic-sorted, cut to K, and tau tightened.  Output: K keys (ordered d, row index) ascending.
+// K1 (top-k part): per-query top-K of a distance row, LDS-staged, in two kernels.
+//
+// select_chunk_kernel: grid (chunks, nq), 256 threads, E elements per thread (chunk = 256 E).
+//   pass A  each thread's minimum -> the K-th smallest of the 256 minima is an upper bound tau of
+//           the chunk's K-th smallest (K distinct elements are <= it);
+//   pass B  elements <= tau are appended to an LDS list (at most E*K of them: only the K threads
+//           whose minimum is <= tau contribute), which is bitonic-sorted and cut to K.
+// select_merge_kernel: one work-group per query sorts the chunks' K-lists (<= 2048 keys) in LDS.
+// Keys are (ordered(d) << 32 | row): one integer order = (distance, row).
 // MODE 0: dist holds final distances.  MODE 1: dist holds MFMA partial dots; the coarse distance
 // (qn + dn[j]) - 2 * sum_splits P is formed here.
-constexpr int SEL_CAP = 1024;
+constexpr int SEL_LIST = 2048;
 
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* buf, int n /* pow2 */, int tid,
                                                  int nthreads) {
@@ -311,82 +354,140 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* buf, int n /* pow2 */
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ dist, size_t ld,
-                                                     size_t strideP, int n_splits,
-                                                     const float* __restrict__ qn,
-                                                     const float* __restrict__ dn,
-                                                     size_t first_row, int n_range, int K,
-                                                     uint64_t* __restrict__ out_keys) {
-  __shared__ uint64_t buf[SEL_CAP];
-  __shared__ int cnt;
-  __shared__ uint64_t tau;
-  const int tid = threadIdx.x;
-  const int q = blockIdx.x;
-  if (tid == 0) {
-    cnt = 0;
-    tau = KEY_SENTINEL;
+__device__ __forceinline__ uint64_t select_key(const float* __restrict__ row, size_t strideP,
+                                               int n_splits, float qnv,
+                                               const float* __restrict__ dn, size_t first_row,
+                                               int j) {
+  float d;
+  if (MODE == 1) {
+    float dot = row[j];
+    for (int s = 1; s < n_splits; ++s) dot += row[(size_t)s * strideP + j];
+    d = (qnv + dn[first_row + (size_t)j]) - 2.f * dot;
+  } else {
+    d = row[j];
   }
-  __syncthreads();
+  return make_key(d, (uint32_t)(first_row + (size_t)j));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void select_chunk_kernel(
+    const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits,
+    const float* __restrict__ qn, const float* __restrict__ dn, size_t first_row, int n_range,
+    int K, int E, uint64_t* __restrict__ out_keys /* [nq][chunks][K] */) {
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ int cnt;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int j0 = chunk * 256 * E;
   const float* row = dist + (size_t)q * ld;
   const float qnv = (MODE == 1) ? qn[q] : 0.f;
-  for (int base = 0; base < n_range; base += 512) {
-    const uint64_t t = tau;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = base + u * 256 + tid;
-      if (j < n_range) {
-        float d;
-        if (MODE == 1) {
-          float dot = row[j];
-          for (int s = 1; s < n_splits; ++s) dot += row[(size_t)s * strideP + j];
-          d = (qnv + dn[first_row + (size_t)j]) - 2.f * dot;
-        } else {
-          d = row[j];
-        }
-        const uint64_t key = make_key(d, (uint32_t)(first_row + (size_t)j));
-        if (key < t) {
-          const int pos = atomicAdd(&cnt, 1);
-          buf[pos] = key;  // cnt <= 512 before the round, <= 512 added: never exceeds SEL_CAP
-        }
-      }
-    }
-    __syncthreads();
-    const int c = cnt;
-    if (c > 512) {
-      for (int i = c + tid; i < SEL_CAP; i += 256) buf[i] = KEY_SENTINEL;
-      bitonic_sort_lds(buf, SEL_CAP, tid, 256);
-      if (tid == 0) {
-        cnt = K;
-        tau = buf[K - 1];
-      }
-      __syncthreads();
+  // pass A: thread minima
+  uint64_t mn = KEY_SENTINEL;
+  for (int e = 0; e < E; ++e) {
+    const int j = j0 + e * 256 + tid;
+    if (j < n_range) {
+      const uint64_t key = select_key<MODE>(row, strideP, n_splits, qnv, dn, first_row, j);
+      mn = key < mn ? key : mn;
     }
   }
-  const int c = cnt;
+  buf[tid] = mn;
+  if (tid == 0) cnt = 0;
+  bitonic_sort_lds(buf, 256, tid, 256);
+  const uint64_t tau = (K <= 256) ? buf[K - 1] : KEY_SENTINEL;
+  __syncthreads();
+  // pass B: everything <= tau (the same keys are recomputed: identical bits)
+  for (int e = 0; e < E; ++e) {
+    const int j = j0 + e * 256 + tid;
+    if (j < n_range) {
+      const uint64_t key = select_key<MODE>(row, strideP, n_splits, qnv, dn, first_row, j);
+      if (key <= tau && key != KEY_SENTINEL) {
+        const int pos = atomicAdd(&cnt, 1);
+        if (pos < SEL_LIST) buf[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  const int c = cnt < SEL_LIST ? cnt : SEL_LIST;
   int n2 = 64;
   while (n2 < c) n2 <<= 1;
   for (int i = c + tid; i < n2; i += 256) buf[i] = KEY_SENTINEL;
   bitonic_sort_lds(buf, n2, tid, 256);
-  for (int i = tid; i < K; i += 256) out_keys[(size_t)q * K + i] = (i < c) ? buf[i] : KEY_SENTINEL;
+  uint64_t* o = out_keys + ((size_t)q * nchunks + chunk) * K;
+  for (int i = tid; i < K; i += 256) o[i] = (i < c) ? buf[i] : KEY_SENTINEL;
+}
+
+// in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
+__global__ __launch_bounds__(256) void select_merge_kernel(const uint64_t* __restrict__ in_keys,
+                                                           int nlists, int per_group, int K,
+                                                           uint64_t* __restrict__ out_keys) {
+  __shared__ uint64_t buf[SEL_LIST];
+  const int tid = threadIdx.x, q = blockIdx.y, g = blockIdx.x, ngroups = gridDim.x;
+  const int l0 = g * per_group;
+  const int nl = (nlists - l0) < per_group ? (nlists - l0) : per_group;
+  const int total = nl * K;  // <= SEL_LIST (host guarantees)
+  int n2 = 64;
+  while (n2 < total) n2 <<= 1;
+  const uint64_t* in = in_keys + ((size_t)q * nlists + l0) * K;
+  for (int i = tid; i < n2; i += 256) buf[i] = i < total ? in[i] : KEY_SENTINEL;
+  bitonic_sort_lds(buf, n2, tid, 256);
+  uint64_t* o = out_keys + ((size_t)q * ngroups + g) * K;
+  for (int i = tid; i < K; i += 256) o[i] = (i < total) ? buf[i] : KEY_SENTINEL;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1b: exact re-rank of the MFMA path's candidates + completeness check.  One wave per query
-// (work-group = 1 wave so that exact_pairs_wave's barriers are wave-local).
-//   theta    = coarse_d[k-1] + 2 eps,  eps = 4.5 (dim+2) 2^-24 (qn + dn_max)  (DESIGN.md bound)
-//   m        = candidates with coarse_d <= theta (a prefix); those get reference-order distances
+// K1b: exact re-rank of the MFMA path's candidates + completeness check.
+//   theta    = coarse_d[k-1] + 2 eps   (eps: rounding bound of coarse vs reference-order distance,
+//              eps_rel_d * max(coarse_d[k-1], 0) + eps_rel_n * (qn + dn_max))
+//   m        = candidates with coarse_d <= theta (a prefix): those get reference-order distances
 //   complete = fewer candidates than KC exist, or coarse_d[KC-1] > theta
-// Output: k keys (exact d2, row) ascending; flags[q] = 1 if the candidate set may be incomplete.
-__global__ __launch_bounds__(64) void rerank_kernel(const float* __restrict__ db,
-                                                    const float* __restrict__ queries, int dim,
-                                                    const uint64_t* __restrict__ cand, int KC,
-                                                    int k, int n_range,
-                                                    const float* __restrict__ qn,
-                                                    const uint32_t* __restrict__ dn_max_bits,
-                                                    uint64_t* __restrict__ out_keys,
-                                                    int* __restrict__ flags) {
+// rerank_dist_kernel: grid (ceil(KC/RR), nq), one wave per RR candidates of one query.
+// rerank_final_kernel: one wave per query ranks the exact keys and raises flags[q] when the
+// candidate set may be incomplete (the host then redoes that query on the exact path).
+constexpr int RR = 4;  // candidates per wave in rerank_dist_kernel
+
+__device__ __forceinline__ float rerank_theta(float dk, float qnv, float dn_max, float eps_rel_d,
+                                              float eps_rel_n) {
+  const float eps = eps_rel_d * fmaxf(dk, 0.f) + eps_rel_n * (qnv + dn_max);
+  return dk + 2.f * eps;
+}
+
+__global__ __launch_bounds__(64) void rerank_dist_kernel(
+    const float* __restrict__ db, const float* __restrict__ queries, int dim,
+    const uint64_t* __restrict__ cand, int KC, int k, const float* __restrict__ qn,
+    const uint32_t* __restrict__ dn_max_bits, float eps_rel_d, float eps_rel_n,
+    float* __restrict__ exact /* [nq][KC] */) {
   __shared__ __attribute__((aligned(16))) float S[64 * S_PITCH];
-  __shared__ uint32_t rows_sh[64];
+  const int lane = threadIdx.x;
+  const int q = blockIdx.y, p0 = blockIdx.x * RR;
+  const uint64_t key = (lane < KC) ? cand[(size_t)q * KC + lane] : KEY_SENTINEL;
+  const bool valid = key != KEY_SENTINEL;
+  const float dco = ord2f((uint32_t)(key >> 32));
+  const int n_valid = __popcll(__ballot(valid));
+  const int kk = k < n_valid ? k : n_valid;
+  if (kk == 0) return;
+  const float theta = rerank_theta(__shfl(dco, kk - 1), qn[q], __uint_as_float(*dn_max_bits),
+                                   eps_rel_d, eps_rel_n);
+  const int m = __popcll(__ballot(valid && dco <= theta));
+  if (p0 >= m) return;  // wave-uniform
+  const int rw = (m - p0) < RR ? (m - p0) : RR;
+  uint32_t rows[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) rows[r] = (uint32_t)__shfl((int)(uint32_t)key, (p0 + r) & 63);
+  auto row_of = [&](int r) -> long long {
+    if (r >= rw) return -1;
+    uint32_t v = rows[0];
+#pragma unroll
+    for (int i = 1; i < RR; ++i) v = (r == i) ? rows[i] : v;
+    return (long long)v;
+  };
+  const float d2 = exact_pairs_wave<1>(db, queries + (size_t)q * dim, dim, RR, row_of, 1, S);
+  if (lane < rw) exact[(size_t)q * KC + p0 + lane] = d2;
+}
+
+__global__ __launch_bounds__(64) void rerank_final_kernel(
+    const uint64_t* __restrict__ cand, const float* __restrict__ exact, int KC, int k, int n_range,
+    const float* __restrict__ qn, const uint32_t* __restrict__ dn_max_bits, float eps_rel_d,
+    float eps_rel_n, uint64_t* __restrict__ out_keys, int* __restrict__ flags) {
   const int lane = threadIdx.x;
   const int q = blockIdx.x;
   const uint64_t key = (lane < KC) ? cand[(size_t)q * KC + lane] : KEY_SENTINEL;
@@ -398,25 +499,13 @@ __global__ __launch_bounds__(64) void rerank_kernel(const float* __restrict__ db
   int m = 0;
   bool complete = true;
   if (kk > 0) {
-    const float dk = __shfl(dco, kk - 1);
-    const float eps = 4.5f * (float)(dim + 2) * 5.9604645e-8f *
-                      (qn[q] + __uint_as_float(*dn_max_bits)) * 1.01f;
-    const float theta = dk + 2.f * eps;
+    const float theta = rerank_theta(__shfl(dco, kk - 1), qn[q], __uint_as_float(*dn_max_bits),
+                                     eps_rel_d, eps_rel_n);
     m = __popcll(__ballot(valid && dco <= theta));
-    if (n_valid == KC && n_range > KC) {
-      const float dlast = __shfl(dco, KC - 1);
-      complete = dlast > theta;
-    }
+    if (n_valid == KC && n_range > KC) complete = __shfl(dco, KC - 1) > theta;
   }
-  rows_sh[lane] = idx;
-  __syncthreads();
-  auto row_of = [&](int r) -> long long { return r < m ? (long long)rows_sh[r] : -1; };
-  const int RW = (m + 3) & ~3;
-  float d2 = 0.f;
-  if (m > 0) d2 = exact_pairs_wave<1>(db, queries + (size_t)q * dim, dim, RW, row_of, 1, S);
-  const uint64_t ek = (lane < m) ? make_key(d2, idx) : KEY_SENTINEL;
-  // rank by counting (keys are distinct: distinct rows)
-  int rank = 0;
+  const uint64_t ek = (lane < m) ? make_key(exact[(size_t)q * KC + lane], idx) : KEY_SENTINEL;
+  int rank = 0;  // keys are distinct (distinct rows)
   for (int i = 0; i < 64; ++i) {
     const uint64_t o = __shfl(ek, i);
     rank += (o < ek) ? 1 : 0;

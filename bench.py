@@ -215,9 +215,13 @@ def main():
         eval_pairs = float(pairs_eval) / max(nn_launches, 1)
     achieved = FLOP_PER_PAIR * eval_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
     kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_culled_kernel"
+    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), same workload
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_nn_culled.json")
+    if args.nn_mode == "culled" and world == 1 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
                 "pairs_evaluated_per_launch": eval_pairs, "pairs_exhaustive_per_launch": all_pairs,
                 "exhaustive_equivalent_tflops": FLOP_PER_PAIR * all_pairs / avg_launch_s / 1e12
                 if avg_launch_s > 0 else 0.0,

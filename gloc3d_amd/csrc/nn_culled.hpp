@@ -56,7 +56,30 @@ __device__ __forceinline__ uint32_t morton_key(float x, float y, float z, float 
   const float fx = fminf(fmaxf((x - ox) * inv_cell, 0.f), 1023.f);
   const float fy = fminf(fmaxf((y - oy) * inv_cell, 0.f), 1023.f);
   const float fz = fminf(fmaxf((z - oz) * inv_cell, 0.f), 1023.f);
-  return spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+  // Hilbert curve (Skilling's transpose form) rather than Morton: no long jumps between
+  // consecutive cells, so the 128-point chunks and 16-point sub-blocks get tighter boxes.
+  uint32_t X[3] = {(uint32_t)fx, (uint32_t)fy, (uint32_t)fz};
+  const uint32_t M = 1u << 9;
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
 }
 
 __global__ void morton_keys_kernel(const float* __restrict__ xyz, uint32_t n, float ox, float oy,

@@ -262,13 +262,20 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
   unsigned long long n_processed = 0, n_sub = 0;
 
   // ---- sweep: 64 chunk boxes per ballot -----------------------------------------------------
+  f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};  // next batch's boxes, in flight
+  if ((uint32_t)lane < ix.nchunks) {
+    nlo = ix.box_lo[lane];
+    nhi = ix.box_hi[lane];
+  }
   for (uint32_t c0 = 0; c0 < ix.nchunks; c0 += 64) {
     const uint32_t cl = c0 + lane;
-    f32x4 blo = {0.f, 0.f, 0.f, 0.f}, bhi = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 blo = nlo, bhi = nhi;
+    if (cl + 64 < ix.nchunks) {  // loads of the following batch overlap this batch's work
+      nlo = ix.box_lo[cl + 64];
+      nhi = ix.box_hi[cl + 64];
+    }
     float lbw = 3.402823466e+38f;
     if (cl < ix.nchunks) {
-      blo = ix.box_lo[cl];
-      bhi = ix.box_hi[cl];
       const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
       const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
       const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
@@ -303,6 +310,15 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
         if (j < ix.n) v = ix.pts[j];
         stage[u * 64 + lane] = v;
       }
+      // the 8 sub-block boxes: lanes 0..7 load one each (issued together with the staging loads)
+      f32x4 sbl = {0.f, 0.f, 0.f, 0.f}, sbh = {0.f, 0.f, 0.f, 0.f};
+      {
+        const uint32_t blk_l = c * (CH / SB) + (lane & 7);
+        if (blk_l * SB < ix.n) {
+          sbl = ix.sb_lo[blk_l];
+          sbh = ix.sb_hi[blk_l];
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -311,7 +327,14 @@ __global__ __launch_bounds__(256) void nn_culled_kernel(
         const uint32_t blk = (c * CH + b0) / SB;
         if (blk * SB >= ix.n) break;
         {  // second-level test: does any point of the wave still need this sub-block?
-          const f32x4 slo = ix.sb_lo[blk], shi = ix.sb_hi[blk];
+          const int bi = b0 / SB;
+          f32x4 slo, shi;
+          slo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbl.x), bi));
+          slo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbl.y), bi));
+          slo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbl.z), bi));
+          shi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbh.x), bi));
+          shi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbh.y), bi));
+          shi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbh.z), bi));
           bool need_sb = false;
 #pragma unroll
           for (int s = 0; s < CS; ++s)

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(64) void ransac_scan_kernel(const uint32_t* __restr
       best_inl = (uint32_t)__builtin_amdgcn_readlane((int)inl, b);
       best_h = hh;
       if (adaptive) {
-        const uint32_t need = ransac_needed_iters(best_inl, n, conf, n_hyp);
+        // only min(need, niters) matters: stop counting at the current budget
+        const uint32_t need = ransac_needed_iters(best_inl, n, conf, niters);
         niters = need < niters ? need : niters;
       }
     }

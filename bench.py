@@ -9,11 +9,13 @@ region starts:  descriptor top-20 (gloc_knn_search_device) -> the 20 retrieved c
 batched RANSAC(3000) + ICP(20) registration (gloc_reg_batch_ids) -> lowest-rank successful candidate.
 
 N = 1  (BASELINE.json configs[3], the configuration the metric is quoted on):
-        KITTI-00-sized database, 4541 places x 4096-D, ~124k-point scans.
-N > 1  (configs[4] + [3]): 1M x 4096 database interleave-sharded over the N ranks, per-shard top-k
-        all-gathered over RCCL/xGMI and merged on every rank; candidates registered on the ranks that
-        own their scans, results combined with one all-reduce.  Total work per step is fixed
-        ("strong" scaling).
+        KITTI-00-sized database, 4541 places x 4096-D, ~124k-point scans, one query per step.
+N > 1  the same database, interleave-sharded over the N ranks; a step handles N queries (one per
+        rank): their descriptors are searched on every shard, the per-shard top-k lists all-gathered
+        over RCCL/xGMI and merged on every rank; rank r then registers query r's 20 candidates against
+        its replica of the scan store, and the N result tables are all-gathered.  Per-GPU work is
+        fixed as N grows ("weak" scaling).  --places 1000000 gives BASELINE.json configs[4]'s sharded
+        database; --mode latency shards ONE query's candidates over the ranks instead.
 
 Prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel (K4 point-NN,
 HIP-event timed inside the timed region on the stream it runs on) and the `cpu_baseline` object
@@ -33,7 +35,6 @@ sys.path.insert(0, ROOT)
 DIM = 4096
 TOP_K = 20
 N_PLACES_1GPU = 4541          # KITTI odometry 00 (dataset/kitti_i2i.py:46 of the reference)
-N_PLACES_SHARDED = 1_000_000  # BASELINE.json configs[4]
 SCAN_POOL = 24                # distinct synthetic scans; place g carries scan g % SCAN_POOL
 QUERY_POOL = 4
 RANSAC_ITERS = 3000           # registration/loop_detector.cpp:257 (cap; adaptive stop at the
@@ -93,7 +94,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--places", type=int, default=0, help="override the database size")
+    ap.add_argument("--places", type=int, default=N_PLACES_1GPU,
+                    help="database size (1000000 = BASELINE.json configs[4], sharded over the ranks)")
+    ap.add_argument("--mode", choices=["throughput", "latency"], default="throughput",
+                    help="N > 1: one query per rank per step (weak scaling) or one query per step "
+                         "with its candidates sharded over the ranks (strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
@@ -125,7 +130,8 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
             comm_dev = torch.device("cpu")
 
-    n_places = args.places or (N_PLACES_1GPU if world == 1 else N_PLACES_SHARDED)
+    n_places = args.places
+    per_step = world if args.mode == "throughput" else 1   # queries per step
     n_steps, n_warm = args.steps, args.warmup
     t_setup = time.time()
 
@@ -151,7 +157,7 @@ def main():
     log(f"scans: {SCAN_POOL} pool + {QUERY_POOL} query scans, ~{mean_pts:.0f} pts each, resident")
 
     # queries: noisy copies of database places (replicated on every rank)
-    total = n_steps + n_warm
+    total = (n_steps + n_warm) * per_step
     q_rows = (np.arange(total, dtype=np.int64) * 977 + 211) % n_places
     queries = torch.from_numpy(synth.queries_near(DB_SEED, q_rows, DIM)).to(dev)
 
@@ -164,19 +170,32 @@ def main():
         g = np.asarray(local_rows, np.int64) * world + rank
         return base_register(q_id, [pool_ids[int(x) % SCAN_POOL] for x in g], ranks)
 
+    def register_all(q_id, global_places, ranks):
+        # every rank holds the whole scan pool: place g carries pool scan g % SCAN_POOL
+        return base_register(q_id, [pool_ids[int(g) % SCAN_POOL] for g in global_places], ranks)
+
     sreg = sharded.ShardedRegistrar(rank, world, local_register, comm_device=comm_dev)
+    qreg = sharded.QueryParallelRegistrar(rank, world, register_all, comm_device=comm_dev)
     pairs_per_launch = []
 
     def step(i):
-        idx, d2 = knn.search(queries[i:i + 1], TOP_K)
-        cand = idx[0].cpu().numpy()                       # global place ids, retrieval order
-        table = sreg.register(q_ids[i % QUERY_POOL], cand, dev)
-        sel = sreg.select_first_ok(table)
+        q0 = i * per_step
+        idx, d2 = knn.search(queries[q0:q0 + per_step], TOP_K)
+        cand = idx.cpu().numpy()                          # [per_step, 20] global place ids, retrieval order
+        if args.mode == "throughput":
+            my = q0 + rank
+            tables = qreg.register(q_ids[my % QUERY_POOL], cand, dev)          # [world, 20, 19]
+            sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
+            mine = cand[rank][cand[rank] >= 0]
+            nq = qscans[my % QUERY_POOL].shape[0]
+        else:
+            table = sreg.register(q_ids[q0 % QUERY_POOL], cand[0], dev)
+            sel = [sreg.select_first_ok(table)]
+            mine = cand[0][(cand[0] >= 0) & (cand[0] % world == rank)]
+            nq = qscans[q0 % QUERY_POOL].shape[0]
         if i >= n_warm:
-            mine = cand[(cand >= 0) & (cand % world == rank)]
-            nq = qscans[i % QUERY_POOL].shape[0]
             pairs_per_launch.append(float(nq) * float(sum(pool[int(g) % SCAN_POOL].shape[0] for g in mine)))
-        return cand, sel, table
+        return cand, sel
 
     def fence():
         torch.cuda.synchronize()
@@ -186,15 +205,15 @@ def main():
 
     log(f"setup {time.time() - t_setup:.1f} s; warmup {n_warm}, timing {n_steps} steps")
     for i in range(n_warm):
-        cand, sel, _ = step(i)
-        assert cand[0] == q_rows[i], f"retrieval sanity: top-1 {cand[0]} != query place {q_rows[i]}"
+        cand, sel = step(i)
+        assert (cand[:, 0] == q_rows[i * per_step:(i + 1) * per_step]).all(), "retrieval sanity: top-1 != query place"
     fence()
     reg.profile_reset()
     t0 = time.time()
     sels = []
-    for i in range(n_warm, total):
-        cand, sel, table = step(i)
-        sels.append(sel)
+    for i in range(n_warm, n_warm + n_steps):
+        cand, sel = step(i)
+        sels.extend(sel)
     fence()
     elapsed = time.time() - t0
     if world > 1:
@@ -231,19 +250,23 @@ def main():
 
     out = {
         "metric": "localization queries/sec (kNN+top-20 reg), KITTI-00-sized DB",
-        "value": n_steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": n_steps,
+        "value": n_steps * per_step / elapsed, "unit": "queries/s", "n_gpus": world, "steps": n_steps,
         "warmup": n_warm, "ms_per_step": elapsed / n_steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("cfgD: KITTI-00-sized DB " if world == 1 else "cfgE+D: sharded DB ")
-                               + f"{n_places}x{DIM} fp32, 1 query/step -> top-{TOP_K} -> {TOP_K} candidate "
-                                 f"scans (~{mean_pts:.0f} pts) x (RANSAC {RANSAC_ITERS} + ICP {ICP_ITERS})",
+        "scaling": "weak" if args.mode == "throughput" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfgD: KITTI-00-sized DB {n_places}x{DIM} fp32, {per_step} quer"
+                               f"{'y' if per_step == 1 else 'ies'}/step -> top-{TOP_K} -> {TOP_K} candidate "
+                               f"scans (~{mean_pts:.0f} pts) x (RANSAC {RANSAC_ITERS} + ICP {ICP_ITERS})",
+                   "queries_per_step": per_step,
                    "places": n_places, "dim": DIM, "top_k": TOP_K, "points_per_scan": int(mean_pts),
                    "ransac_iters": RANSAC_ITERS, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
                    "nn_mode": args.nn_mode, "ransac_confidence": float(params.ransac_confidence),
-                   "parallelism": "1 gpu" if world == 1 else
-                   f"db rows + candidates interleave-sharded over {world} ranks; all-gather top-k, all-reduce poses"},
+                   "parallelism": "1 gpu" if world == 1 else (
+                       f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "
+                       + ("one query per rank registered locally, result tables all-gathered"
+                          if args.mode == "throughput" else
+                          "one query, candidates sharded over the ranks, all-reduce of poses"))},
         "roofline": roofline,
-        "stage_ms_per_step": {k_: v / n_steps for k_, v in stage_ms.items()},
+        "stage_ms_per_step_rank0": {k_: v / n_steps for k_, v in stage_ms.items()},
         "selected_candidate_rank": sels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

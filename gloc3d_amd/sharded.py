@@ -99,6 +99,36 @@ class ShardedRegistrar:
         return int(ok[0, 0]) if ok.numel() else -1
 
 
+class QueryParallelRegistrar:
+    """Throughput mode: a step handles G queries, one per rank.  Retrieval is still sharded (the
+    database rows are interleaved over the ranks, per-shard top-k all-gathered and merged); query r's
+    20 candidates are then registered entirely by rank r against its replica of the scan store, so
+    every registration launch keeps its full batch of candidates, and the G result tables are
+    all-gathered.  Per-GPU work is fixed as G grows (weak scaling)."""
+
+    def __init__(self, rank, world, local_register_all, group=None, comm_device=None):
+        self.rank, self.world, self.group, self.comm_device = rank, world, group, comm_device
+        # (query handle, global place ids [n], retrieval ranks [n]) -> float32 [n, RESULT_COLS]
+        self.local_register_all = local_register_all
+
+    def register(self, my_query, cand_global_all, device):
+        """cand_global_all: [G, n] global place ids (replicated).  Returns [G, n, RESULT_COLS]."""
+        cand = np.asarray(cand_global_all, dtype=np.int64)
+        n = cand.shape[1]
+        mine = cand[self.rank]
+        table = torch.zeros((n, RESULT_COLS), dtype=torch.float32, device=device)
+        ok_rows = np.nonzero(mine >= 0)[0]
+        if ok_rows.size:
+            res = self.local_register_all(my_query, mine[ok_rows], ok_rows.astype(np.uint32))
+            table[torch.as_tensor(ok_rows, device=device)] = torch.as_tensor(res, device=device)
+        if self.world == 1:
+            return table[None]
+        t = table.to(self.comm_device) if self.comm_device else table
+        out = torch.empty((self.world * n, RESULT_COLS), dtype=torch.float32, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.to(device).view(self.world, n, RESULT_COLS)
+
+
 # ---- HIP-backed defaults ------------------------------------------------------------------------
 
 def hip_local_search(index):

@@ -67,8 +67,18 @@ def _worker(rank, world, port, n_places, dim, out_dir):
     sreg = sharded.ShardedRegistrar(rank, world, local_register)
     table = sreg.register(0, gi[0].numpy(), torch.device("cpu"))
     sel = sreg.select_first_ok(table)
+    # throughput mode: query r registered entirely by rank r, tables all-gathered
+    def register_all(query, places, ranks):
+        out = np.zeros((len(places), sharded.RESULT_COLS), np.float32)
+        out[:, 16] = query
+        out[:, 17] = places
+        out[:, 18] = (np.asarray(ranks) % 2).astype(np.float32)
+        return out
+
+    qreg = sharded.QueryParallelRegistrar(rank, world, register_all)
+    tables = qreg.register(100 + rank, gi[:world].numpy(), torch.device("cpu"))
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), gi=gi.numpy(), gd=gd.numpy(), table=table.numpy(),
-             sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64))
+             sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64), tables=tables.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,6 +106,12 @@ def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
         assert sorted(o["mine"].tolist()) == sorted((cand[cand % world == r] // world).tolist())
     expect = [c for c in range(20) if c >= 3 and cand[c] % 2 == 0]
     assert outs[0]["sel"] == (expect[0] if expect else -1)
+    # query-parallel mode: table r was produced by rank r for query r, replicated everywhere
+    for o in outs:
+        tb = o["tables"]
+        assert tb.shape == (world, 20, sharded.RESULT_COLS) and (tb == outs[0]["tables"]).all()
+        for r in range(world):
+            assert (tb[r, :, 16] == 100 + r).all() and (tb[r, :, 17] == oi[r].astype(np.float32)).all()
 
 
 def test_sharding_arithmetic():

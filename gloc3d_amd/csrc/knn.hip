@@ -152,20 +152,20 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
   const int qblocks = (nq + BQ - 1) / BQ;
   for (int i = 0; i < n_nts; ++i) {
     const int NT = nts[i], BN = 16 * NT * (4 / WQ);
-    const long long ntiles = (n_range + BN - 1) / BN;
-    for (int KS = 1; KS <= 16; KS <<= 1) {
-      if ((dim % (64 * KS)) != 0 && KS > 1) continue;
-      const int klen = (dim + KS - 1) / KS;
-      if (klen < 128 && KS > 1) continue;
-      const long long wgs = ntiles * qblocks * KS;
-      const long long rounds = (wgs + 255) / 256;
-      // per-WG time ~ klen * (MFMA issue for BN rows + staging of BQ+BN rows); + split overhead
-      const double per_wg = (double)klen * ((double)BN * 1.0 + (double)(BQ + BN) * 0.35);
-      const double cost = (double)rounds * per_wg + 4000.0 * KS + (wgs < 128 ? 1e5 : 0);
-      if (cost < best_cost) {
-        best_cost = cost;
-        best = MfmaPlan{WQ, NT, KS, BQ, BN};
-      }
+    const long long tiles = (long long)((n_range + BN - 1) / BN) * qblocks;
+    // split K only when the tiles alone cannot give every CU a work-group (the partial sums cost
+    // KS x Q x N x 8 B of extra traffic and a longer rounding chain)
+    int KS = 1;
+    while (tiles * KS < 200 && KS < 16 && (dim % (64 * KS * 2)) == 0 && dim / (KS * 2) >= 128) KS *= 2;
+    const int klen = (dim + KS - 1) / KS;
+    const long long wgs = tiles * KS;
+    const long long rounds = (wgs + 255) / 256;
+    // per-WG time ~ klen * (MFMA issue for BN rows + staging of BQ+BN rows)
+    const double per_wg = (double)klen * ((double)BN * 1.0 + (double)(BQ + BN) * 0.35);
+    const double cost = (double)rounds * per_wg * (1.0 + 0.03 * (KS - 1)) + (wgs < 128 ? 1e7 : 0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = MfmaPlan{WQ, NT, KS, BQ, BN};
     }
   }
   // developer override: GLOC3D_MFMA_PLAN="NT,KS"

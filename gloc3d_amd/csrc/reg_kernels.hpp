@@ -540,8 +540,18 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ pa
   const int lane = threadIdx.x;
   if (cand >= n_cand) return;
   double acc = 0.0;
-  if (lane < ACC_NV)
-    for (int b = 0; b < nblocks; ++b) acc += partials[((size_t)cand * nblocks + b) * ACC_NV + lane];
+  if (lane < ACC_NV) {
+    const double* pp = partials + (size_t)cand * nblocks * ACC_NV + lane;
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {  // eight independent loads in flight, summed in block order
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = pp[(size_t)(b + u) * ACC_NV];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v8[u];
+    }
+    for (; b < nblocks; ++b) acc += pp[(size_t)b * ACC_NV];
+  }
   double v[ACC_NV];
 #pragma unroll
   for (int k = 0; k < ACC_NV; ++k) v[k] = __shfl(acc, k);

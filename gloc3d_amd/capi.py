@@ -85,6 +85,13 @@ _PROTOS = [
     ("gloc_reg_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_reg_profile_reset", _i, [_vp]),
     ("gloc_reg_nn_stats", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    ("gloc_vlad_create", _i, [_i, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    ("gloc_vlad_destroy", _i, [_vp]),
+    ("gloc_vlad_set_stream", _i, [_vp, _vp]),
+    ("gloc_vlad_forward", _i, [_vp, _vp, _sz, _sz, _vp]),
+    ("gloc_vlad_forward_device", _i, [_vp, _vp, _sz, _sz, _vp]),
+    ("gloc_vlad_set_profile", _i, [_vp, _i]),
+    ("gloc_vlad_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz, _u64]),
     ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _u64, _vp]),
 ]
@@ -364,3 +371,50 @@ class Registrar:
 def reg_select_first_ok(ok):
     a = np.ascontiguousarray(ok, np.int32)
     return lib().gloc_reg_select_first_ok(_np_ptr(a), a.shape[0])
+
+
+class NetVladFC:
+    """NetVLAD-FC pooling head (model/netvlad_fc.py NetVLAD.forward without gating)."""
+
+    def __init__(self, conv_w, centroids, fc_w, conv_b=None, normalize_input=True, device=0):
+        cw = np.ascontiguousarray(conv_w, np.float32)
+        ce = np.ascontiguousarray(centroids, np.float32)
+        fw = np.ascontiguousarray(fc_w, np.float32)
+        cb = None if conv_b is None else np.ascontiguousarray(conv_b, np.float32)
+        self.K, self.C = cw.shape
+        self.out_dim = fw.shape[1]
+        assert ce.shape == (self.K, self.C) and fw.shape[0] == self.K * self.C
+        self._h = C.c_void_p()
+        check(lib().gloc_vlad_create(device, self.C, self.K, self.out_dim, _np_ptr(cw),
+                                     None if cb is None else _np_ptr(cb), _np_ptr(ce), _np_ptr(fw),
+                                     1 if normalize_input else 0, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_vlad_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, feat):
+        x = np.ascontiguousarray(feat, np.float32)
+        n = x.shape[0]
+        x = x.reshape(n, self.C, -1)
+        out = np.empty((n, self.out_dim), np.float32)
+        check(lib().gloc_vlad_forward(self._h, _np_ptr(x), n, x.shape[2], _np_ptr(out)))
+        return out
+
+    def forward_device(self, feat_ptr, n, hw, out_ptr):
+        check(lib().gloc_vlad_forward_device(self._h, C.c_void_p(feat_ptr), n, hw, C.c_void_p(out_ptr)))
+
+    def set_profile(self, on=True):
+        check(lib().gloc_vlad_set_profile(self._h, 1 if on else 0))
+
+    def profile(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gloc_vlad_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

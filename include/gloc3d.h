@@ -213,6 +213,26 @@ int gloc_reg_profile_reset(gloc_reg* h);
  * 1-NN launches since the last gloc_reg_profile_reset. */
 int gloc_reg_nn_stats(gloc_reg* h, uint64_t* pairs_evaluated, uint64_t* launches);
 
+/* ============================ NetVLAD-FC pooling head ("next" row N2) ===================== *
+ * Replaces NetVLAD.forward of the reference (model/netvlad_fc.py:73-109, built without gating at
+ * main.py:594) -- the tail of the TorchScript module RpyPCLoopDetector::get_place_feature runs
+ * (registration/loop_detector.cpp:152-163): per-position L2 normalisation, 1x1-conv soft assignment,
+ * residual aggregation to `clusters` x `dim`, intra-normalisation, L2, FC to `out_dim`.
+ * conv_w [clusters][dim], conv_b [clusters] or NULL (vladv2), centroids [clusters][dim],
+ * fc_w [clusters*dim][out_dim] (hidden1_weights), all row-major fp32, copied to the device.
+ * feat: n feature maps in NCHW order, [n][dim][hw]; out: [n][out_dim].  fp32 throughout. */
+typedef struct gloc_vlad gloc_vlad;
+int gloc_vlad_create(int device, size_t dim, size_t clusters, size_t out_dim, const float* conv_w,
+                     const float* conv_b, const float* centroids, const float* fc_w,
+                     int normalize_input, gloc_vlad** out);
+int gloc_vlad_destroy(gloc_vlad* h);
+int gloc_vlad_set_stream(gloc_vlad* h, void* hip_stream);
+int gloc_vlad_forward(gloc_vlad* h, const float* feat, size_t n, size_t hw, float* out);
+int gloc_vlad_forward_device(gloc_vlad* h, const float* d_feat, size_t n, size_t hw, float* d_out);
+int gloc_vlad_set_profile(gloc_vlad* h, int enable);
+/* kernel families: "vlad_tile", "vlad_cluster", "vlad_fc" */
+int gloc_vlad_profile(gloc_vlad* h, const char* kernel, double* total_ms, uint64_t* launches);
+
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).
  * kind 0: iid N(0,1)/sqrt(dim); kind 1: anchored trajectory (stride 16, noise 0.05).

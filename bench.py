@@ -81,7 +81,20 @@ def cpu_baseline(pool, qscans, n_places):
     oracle.reg_one(qscans[0], pool[3], cand_id=0, ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
     t_cand = time.time() - t0
     per_query = t_knn + TOP_K * t_cand
-    return {"value": 1.0 / per_query, "unit": "queries/s", "cores": 1, "kind": "port",
+    extra = {}
+    if oracle.have_ref():
+        # the same nearest-neighbour pass on the REFERENCE's vendored nanoflann kd-tree (oracle/_ref),
+        # and what the query would cost with it in place of the oracle's grid search
+        t0 = time.time()
+        oracle.ref_nn3(qscans[0], pool[3])
+        t_ref = time.time() - t0
+        t0 = time.time()
+        oracle.nn3(qscans[0], pool[3], grid=True)
+        t_port = time.time() - t0
+        passes = 1 + ICP_ITERS
+        extra = {"nn_pass_s_port_grid": t_port, "nn_pass_s_reference_kdtree": t_ref,
+                 "value_with_reference_nn": 1.0 / (t_knn + TOP_K * max(t_cand - passes * (t_port - t_ref), 0.0))}
+    return {**extra, "value": 1.0 / per_query, "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": f"1 query: kNN over {n_places}x{DIM} ({t_knn*1e3:.0f} ms) + RANSAC{RANSAC_ITERS}"
                       f"+ICP{ICP_ITERS} registration of 1 of its {TOP_K} candidates "
                       f"({t_cand:.1f} s, ~124k-pt scans), extrapolated x{TOP_K} candidates",

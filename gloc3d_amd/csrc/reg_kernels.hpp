@@ -166,9 +166,13 @@ __global__ void gather_pairs_kernel(const float* __restrict__ src, uint32_t n_sr
   float x, y, z;
   xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], x, y, z);
   const uint32_t j = corr[(size_t)cand * ld + i];
-  const float* t = cands[cand].tgt + 3 * (size_t)j;
+  f32x4 q = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // no correspondence (empty target): never an inlier
+  if (j < cands[cand].n_tgt) {
+    const float* t = cands[cand].tgt + 3 * (size_t)j;
+    q = f32x4{t[0], t[1], t[2], 0.f};
+  }
   pairs[((size_t)cand * ld + i) * 2 + 0] = f32x4{x, y, z, 0.f};
-  pairs[((size_t)cand * ld + i) * 2 + 1] = f32x4{t[0], t[1], t[2], 0.f};
+  pairs[((size_t)cand * ld + i) * 2 + 1] = q;
 }
 
 // ---- fp64 3x3 helpers: the same operation sequence as oracle/reg_oracle.c --------------------
@@ -293,6 +297,7 @@ __global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, ui
     const f32x4 qv = pairs[((size_t)cand * ld + sidx[k]) * 2 + 1];
     p[k][0] = (double)pv.x; p[k][1] = (double)pv.y; p[k][2] = (double)pv.z;
     q[k][0] = (double)qv.x; q[k][1] = (double)qv.y; q[k][2] = (double)qv.z;
+    if (qv.x >= 0.5f * NN_FAR) return;  // sampled a point without correspondence (empty target scan)
   }
   double a[3], b[3], c[3];
   for (int i = 0; i < 3; ++i) {
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
     if (MODE == 0) {
       xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], px, py, pz);
       const uint32_t j = corr[(size_t)cand * ld + i];
+      if (j >= cands[cand].n_tgt) continue;  // no correspondence (empty target scan)
       const float* t = cands[cand].tgt + 3 * (size_t)j;
       qx = t[0]; qy = t[1]; qz = t[2];
       const float d2 = d2in[(size_t)cand * ld + i];
@@ -611,7 +617,10 @@ __global__ void sumd2_kernel(const float* __restrict__ d2in, size_t ld, uint32_t
   __shared__ double red[256];
   const int cand = blockIdx.x;
   double s = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) s += (double)d2in[(size_t)cand * ld + i];
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const float d = d2in[(size_t)cand * ld + i];
+    if (d < 3.0e38f) s += (double)d;  // FLT_MAX marks "no correspondence"
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {

@@ -171,3 +171,19 @@ def test_full_size_properties(capi):
         cat = sorted(zip(np.concatenate([a[1][r], b[1][r]]).tolist(), np.concatenate([a[0][r], b[0][r]]).tolist()))
         assert [c[1] for c in cat[:k]] == idx[r].tolist()
     ix.close()
+
+
+def test_many_queries_and_empty_add(capi, oracle_mod):
+    """More queries than one workspace block (1024) and add() of zero rows."""
+    from gloc3d_amd import synth
+    db = synth.descriptors_iid(61, 0, 700, 32)
+    q = synth.descriptors_iid(62, 0, 1500, 32)
+    ix = capi.KnnIndex(32)
+    ix.add(db[:0])
+    ix.add(db)
+    for algo in (1, 2):
+        ix.set_option(capi.KNN_OPT_ALGO, algo)
+        idx, d2 = ix.search(q, 9)
+        oi, od = oracle_mod.knn_search(db, q, 9, threads=4)
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    ix.close()

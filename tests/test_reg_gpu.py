@@ -172,3 +172,16 @@ def test_degenerate_inputs(reg, capi):
     line = np.stack([np.linspace(0, 10, 200), np.zeros(200), np.zeros(200)], 1).astype(np.float32)
     g = reg.batch(line, [line], params=prm)           # collinear: every hypothesis degenerate
     assert g["inliers"][0] == 0 and not g["ok"][0] and np.isfinite(g["T"]).all()
+
+
+def test_empty_scans(reg, capi):
+    prm = capi.default_reg_params(ransac_iters=50, icp_iters=2)
+    pts = np.random.default_rng(0).uniform(-5, 5, (300, 3)).astype(np.float32)
+    empty = np.zeros((0, 3), np.float32)
+    g = reg.batch(pts, [empty, pts], params=prm)          # an empty candidate next to a real one
+    assert np.allclose(g["T"][0], np.eye(4)) and not g["ok"][0] and g["inliers"][0] == 0
+    assert g["ok"][1] and np.abs(g["T"][1] - np.eye(4)).max() < 1e-5
+    g = reg.batch(empty, [pts], params=prm)               # an empty query
+    assert np.allclose(g["T"][0], np.eye(4)) and not g["ok"][0]
+    idx, d2 = reg.nn(pts[:5], empty)
+    assert (idx == np.iinfo(np.uint32).max).all()

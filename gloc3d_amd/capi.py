@@ -59,6 +59,8 @@ _PROTOS = [
     ("gloc_knn_size", _i, [_vp, C.POINTER(_sz)]),
     ("gloc_knn_dim", _i, [_vp, C.POINTER(_sz)]),
     ("gloc_knn_device_rows", _i, [_vp, C.POINTER(_vp)]),
+    ("gloc_knn_save", _i, [_vp, C.c_char_p]),
+    ("gloc_knn_load", _i, [_vp, C.c_char_p]),
     ("gloc_knn_search", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     ("gloc_knn_search_device", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _u64, _vp, _vp]),
     ("gloc_topk_merge_device", _i, [_i, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
@@ -199,6 +201,12 @@ class KnnIndex:
 
     def add_synthetic(self, kind, seed, first_row, n, row_stride=1):
         check(lib().gloc_knn_add_synthetic(self._h, kind, seed, first_row, n, row_stride))
+
+    def save(self, path):
+        check(lib().gloc_knn_save(self._h, str(path).encode()))
+
+    def load(self, path):
+        check(lib().gloc_knn_load(self._h, str(path).encode()))
 
     def device_rows(self):
         p = C.c_void_p()

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <vector>
 #include <new>
 
 #include "common.hpp"
@@ -487,6 +488,63 @@ int gloc_knn_device_rows(const gloc_knn* h, const float** d_rows) {
   GLOC_REQUIRE(h && d_rows, GLOC_ERR_INVALID, "null argument");
   *d_rows = h->rows.as<float>();
   return GLOC_OK;
+}
+
+int gloc_knn_save(gloc_knn* h, const char* path) {
+  GLOC_REQUIRE(h && path, GLOC_ERR_INVALID, "null argument");
+  GLOC_HIP(hipSetDevice(h->device));
+  FILE* f = fopen(path, "wb");
+  GLOC_REQUIRE(f, GLOC_ERR_INVALID, "cannot open %s for writing", path);
+  const uint32_t hdr[2] = {(uint32_t)h->n, (uint32_t)h->dim};
+  bool ok = fwrite("GLOCDESC", 1, 8, f) == 8 && fwrite(hdr, 4, 2, f) == 2;
+  std::vector<float> buf;
+  const size_t chunk = std::max<size_t>(1, (64u << 20) / (h->dim * sizeof(float)));  // 64 MiB pieces
+  for (size_t r = 0; ok && r < h->n; r += chunk) {
+    const size_t cnt = std::min(chunk, h->n - r);
+    buf.resize(cnt * h->dim);
+    if (hipMemcpyAsync(buf.data(), h->rows.as<float>() + r * h->dim, buf.size() * sizeof(float),
+                       hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      ok = false;
+    else
+      ok = fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+  }
+  ok = (fclose(f) == 0) && ok;
+  GLOC_REQUIRE(ok, GLOC_ERR_STATE, "writing %s failed", path);
+  return GLOC_OK;
+}
+
+int gloc_knn_load(gloc_knn* h, const char* path) {
+  GLOC_REQUIRE(h && path, GLOC_ERR_INVALID, "null argument");
+  FILE* f = fopen(path, "rb");
+  GLOC_REQUIRE(f, GLOC_ERR_INVALID, "cannot open %s", path);
+  char magic[8];
+  uint32_t hdr[2] = {0, 0};
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "GLOCDESC", 8) != 0 || fread(hdr, 4, 2, f) != 2) {
+    fclose(f);
+    set_err("%s is not a GLOCDESC file", path);
+    return GLOC_ERR_INVALID;
+  }
+  if (hdr[1] != h->dim) {
+    fclose(f);
+    set_err("%s holds %u-D rows, the index is %zu-D", path, hdr[1], h->dim);
+    return GLOC_ERR_INVALID;
+  }
+  std::vector<float> buf;
+  const size_t chunk = std::max<size_t>(1, (64u << 20) / (h->dim * sizeof(float)));
+  int rc = GLOC_OK;
+  for (size_t r = 0; rc == GLOC_OK && r < hdr[0]; r += chunk) {
+    const size_t cnt = std::min<size_t>(chunk, hdr[0] - r);
+    buf.resize(cnt * h->dim);
+    if (fread(buf.data(), sizeof(float), buf.size(), f) != buf.size()) {
+      set_err("%s is truncated", path);
+      rc = GLOC_ERR_INVALID;
+    } else {
+      rc = gloc_knn_add(h, buf.data(), cnt);
+    }
+  }
+  fclose(f);
+  return rc;
 }
 
 int gloc_knn_search_device(gloc_knn* h, const float* d_queries, size_t nq, size_t k,

@@ -87,6 +87,14 @@ int gloc_knn_dim(const gloc_knn* h, size_t* dim);
 /* Device pointer of the resident row-major database (valid until the next add/reserve/clear). */
 int gloc_knn_device_rows(const gloc_knn* h, const float** d_rows);
 
+/* Persist / restore the database ("next" row N4; the reference keeps its descriptor database in
+ * memory only and rebuilds it from the scans on every start, global_localization.cpp:419-449).
+ * File: "GLOCDESC", u32 rows, u32 dim, then rows x dim little-endian fp32 -- the same format the
+ * drop-in global_localization command line reads in place of the TorchScript model.
+ * load APPENDS the file's rows (dim must match). */
+int gloc_knn_save(gloc_knn* h, const char* path);
+int gloc_knn_load(gloc_knn* h, const char* path);
+
 /* Top-k over rows [first_row, last_row) for nq queries (host buffers).  last_row is clamped to the
  * database size; pass SIZE_MAX for "all".  The row window expresses the SLAM-mode exclusion of the
  * newest frames (db_features_.begin() .. end()-num_exclude_recent_, loop_detector.cpp:66-72).

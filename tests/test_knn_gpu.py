@@ -187,3 +187,27 @@ def test_many_queries_and_empty_add(capi, oracle_mod):
         oi, od = oracle_mod.knn_search(db, q, 9, threads=4)
         assert (idx == oi).all() and (bits(d2) == bits(od)).all()
     ix.close()
+
+
+def test_save_load_round_trip(capi, oracle_mod, tmp_path):
+    from gloc3d_amd import gloc_io, synth
+    db = synth.descriptors_traj(71, 0, 900, 48)
+    q = synth.queries_near(71, [5, 444, 899], 48)
+    a = capi.KnnIndex(48)
+    a.add(db)
+    a.save(tmp_path / "db.desc")
+    a.close()
+    assert (gloc_io.read_descriptors(tmp_path / "db.desc") == db).all()  # the CLI's descriptor format
+    b = capi.KnnIndex(48)
+    b.load(tmp_path / "db.desc")
+    assert len(b) == 900
+    idx, d2 = b.search(q, 20)
+    oi, od = oracle_mod.knn_search(db, q, 20)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    c = capi.KnnIndex(32)
+    with pytest.raises(capi.GlocError):
+        c.load(tmp_path / "db.desc")       # dimension mismatch
+    with pytest.raises(capi.GlocError):
+        c.load(tmp_path / "missing.desc")
+    b.close()
+    c.close()

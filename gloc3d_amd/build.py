@@ -15,7 +15,8 @@ LIB = os.path.join(LIBDIR, "libgloc3d.so")
 SOURCES = ["common.hip", "knn.hip", "reg.hip", "vlad.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact kernels must reproduce the reference's un-fused fp32 arithmetic
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+EXTRA = os.environ.get("GLOC3D_EXTRA_FLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 

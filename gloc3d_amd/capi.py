@@ -41,6 +41,25 @@ class RegParams(C.Structure):
                 ("ransac_confidence", C.c_float), ("reserved_", C.c_uint32)]
 
 
+class BevParams(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("max_range", C.c_float), ("out_width", C.c_uint32),
+                ("out_height", C.c_uint32), ("format", C.c_uint32), ("pad_bgr", C.c_uint8 * 3),
+                ("reserved_", C.c_uint8)]
+
+
+class BevInfo(C.Structure):
+    _fields_ = [("min_ix", C.c_int32), ("min_iy", C.c_int32), ("max_ix", C.c_int32),
+                ("max_iy", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("n_returns", C.c_uint32), ("empty", C.c_uint32), ("ox", C.c_double),
+                ("oy", C.c_double), ("resolution", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+BEV_U8_HWC3, BEV_F32_CHW = 0, 1
+
+
 # every symbol include/gloc3d.h declares: (name, restype, argtypes)
 _vp, _sz, _u64, _i, _u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32
 _PROTOS = [
@@ -94,6 +113,16 @@ _PROTOS = [
     ("gloc_vlad_forward_device", _i, [_vp, _vp, _sz, _sz, _vp]),
     ("gloc_vlad_set_profile", _i, [_vp, _i]),
     ("gloc_vlad_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("gloc_bev_default_params", _i, [_vp]),
+    ("gloc_bev_create", _i, [_i, C.POINTER(_vp)]),
+    ("gloc_bev_destroy", _i, [_vp]),
+    ("gloc_bev_set_stream", _i, [_vp, _vp]),
+    ("gloc_bev_synchronize", _i, [_vp]),
+    ("gloc_bev_project", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    ("gloc_bev_project_batch_device", _i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    ("gloc_bev_raw_image", _i, [_vp, _sz, _vp, _sz]),
+    ("gloc_bev_set_profile", _i, [_vp, _i]),
+    ("gloc_bev_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz, _u64]),
     ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _u64, _vp]),
 ]
@@ -425,4 +454,85 @@ class NetVladFC:
     def profile(self, kernel):
         ms, n = C.c_double(), C.c_uint64()
         check(lib().gloc_vlad_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def default_bev_params(**over):
+    p = BevParams()
+    check(lib().gloc_bev_default_params(C.byref(p)))
+    for k, v in over.items():
+        if k == "pad_bgr":
+            for i in range(3):
+                p.pad_bgr[i] = v[i]
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class BevProjector:
+    """BEV occupancy projection (RpyPCLoopDetector::get_projected_grid + crop_pad_occupancy,
+    registration/loop_detector.cpp:83-106,122-151)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().gloc_bev_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_bev_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _out_array(p, n_scans=None):
+        shape = (p.out_height, p.out_width, 3) if p.format == BEV_U8_HWC3 else (3, p.out_height, p.out_width)
+        if n_scans is not None:
+            shape = (n_scans,) + shape
+        return np.empty(shape, np.uint8 if p.format == BEV_U8_HWC3 else np.float32)
+
+    def project(self, points, params=None):
+        """points [n, 3 or more] float32 -> (image, info dict)."""
+        p = params or default_bev_params()
+        pts = np.ascontiguousarray(points, np.float32)
+        if pts.ndim != 2:
+            pts = pts.reshape(-1, 3)
+        out, info = self._out_array(p), BevInfo()
+        check(lib().gloc_bev_project(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1], C.byref(p),
+                                     _np_ptr(out), C.byref(info)))
+        return out, info.as_dict()
+
+    def project_batch_device(self, xyz_ptr, offsets, stride_floats, out_ptr, params=None, want_info=True):
+        """Device buffers: scans back to back at xyz_ptr, host `offsets` (n_scans + 1, in points)."""
+        p = params or default_bev_params()
+        off = np.ascontiguousarray(offsets, np.uint64)
+        n = off.shape[0] - 1
+        infos = (BevInfo * n)() if want_info else None
+        check(lib().gloc_bev_project_batch_device(self._h, C.c_void_p(xyz_ptr), _np_ptr(off), n, stride_floats,
+                                                  C.byref(p), C.c_void_p(out_ptr),
+                                                  C.cast(infos, C.c_void_p) if want_info else None))
+        return [i.as_dict() for i in infos] if want_info else None
+
+    def raw_image(self, info, scan=0):
+        """The uncropped [height, width] u8 image (occupancy_grid) of a scan of the last projection."""
+        out = np.empty((info["height"], info["width"]), np.uint8)
+        check(lib().gloc_bev_raw_image(self._h, scan, _np_ptr(out), out.size))
+        return out
+
+    def set_stream(self, stream_ptr):
+        check(lib().gloc_bev_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        check(lib().gloc_bev_synchronize(self._h))
+
+    def set_profile(self, on=True):
+        check(lib().gloc_bev_set_profile(self._h, 1 if on else 0))
+
+    def profile(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gloc_bev_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value

@@ -1,7 +1,8 @@
 // loop_detector.hpp -- host-side mirror of the reference's RpyPCLoopDetector
 // (registration/loop_detector.h:41-119) for the hot path: same method names, argument meaning and
 // guards, over the C ABI (include/gloc3d.h).  Differences, all forced by scope:
-//   * the descriptor comes from the caller (the CNN + BEV projection are upstream of the hot path);
+//   * the descriptor comes from the caller (the CNN backbone is upstream of the hot path);
+//     get_projected_grid / get_place_input are the BEV projection in front of it;
 //   * match() is the 3-D registration (RANSAC-SVD + ICP) of north_star, not the 2-D SURF match.
 // Not thread-safe; single caller thread, like the reference.
 #pragma once
@@ -17,7 +18,7 @@ namespace gloc_host {
 
 class RpyPCLoopDetector {
  public:
-  explicit RpyPCLoopDetector(size_t k_dim = 512, int device = 0) : k_dim_(k_dim) {
+  explicit RpyPCLoopDetector(size_t k_dim = 512, int device = 0) : k_dim_(k_dim), device_(device) {
     if (gloc_knn_create(device, k_dim_, &knn_) != GLOC_OK) throw std::runtime_error(gloc_last_error());
     if (gloc_reg_create(device, &reg_) != GLOC_OK) {
       std::string e = gloc_last_error();
@@ -27,6 +28,7 @@ class RpyPCLoopDetector {
     gloc_reg_default_params(&reg_params_);
   }
   ~RpyPCLoopDetector() {
+    gloc_bev_destroy(bev_);
     gloc_reg_destroy(reg_);
     gloc_knn_destroy(knn_);
   }
@@ -106,6 +108,37 @@ class RpyPCLoopDetector {
     return r;
   }
 
+  // get_projected_grid (loop_detector.cpp:122-135): the occupancy image ([height][width] u8, 0 =
+  // occupied column) of one scan and xy_res = (ox, oy, resolution).
+  struct Grid {
+    std::vector<uint8_t> image;
+    uint32_t width = 0, height = 0;
+    double ox = 0, oy = 0, resolution = 0;
+  };
+  Grid get_projected_grid(const float* scan_xyzi, size_t n_pts) {
+    gloc_bev_params p = bev_params();
+    std::vector<uint8_t> scratch((size_t)p.out_width * p.out_height * 3);
+    gloc_bev_info info;
+    check(gloc_bev_project(projector(), scan_xyzi, n_pts, 4, &p, scratch.data(), &info));
+    if (info.empty) throw std::runtime_error("no point of the scan lies within range");  // the reference aborts
+    Grid g;
+    g.width = info.width; g.height = info.height;
+    g.ox = info.ox; g.oy = info.oy; g.resolution = info.resolution;
+    g.image.resize((size_t)g.width * g.height);
+    check(gloc_bev_raw_image(projector(), 0, g.image.data(), g.image.size()));
+    return g;
+  }
+
+  // The tensor get_place_feature feeds the descriptor network (loop_detector.cpp:137-151):
+  // [3][768][768] f32 in {0, 1} (crop_pad_occupancy, / 255, NHWC -> NCHW).
+  std::vector<float> get_place_input(const float* scan_xyzi, size_t n_pts, gloc_bev_info* info = nullptr) {
+    gloc_bev_params p = bev_params();
+    p.format = GLOC_BEV_F32_CHW;
+    std::vector<float> chw((size_t)3 * p.out_width * p.out_height);
+    check(gloc_bev_project(projector(), scan_xyzi, n_pts, 4, &p, chw.data(), info));
+    return chw;
+  }
+
   gloc_reg_params& registration_params() { return reg_params_; }
   size_t size() const { return db_size_; }
   size_t top_k() const { return top_k_; }
@@ -113,6 +146,17 @@ class RpyPCLoopDetector {
  private:
   void check(int rc) {
     if (rc != GLOC_OK) throw std::runtime_error(gloc_last_error());
+  }
+  gloc_bev* projector() {  // created on first use
+    if (!bev_) check(gloc_bev_create(device_, &bev_));
+    return bev_;
+  }
+  gloc_bev_params bev_params() const {
+    gloc_bev_params p;
+    gloc_bev_default_params(&p);
+    p.resolution = high_resolution_;
+    p.max_range = high_resolution_max_range_;
+    return p;
   }
   void query(const float* q, size_t first, size_t last, std::vector<size_t>& idx, std::vector<float>& d2) {
     std::vector<uint64_t> i64(top_k_);
@@ -128,9 +172,13 @@ class RpyPCLoopDetector {
   const size_t tree_making_period_ = 30;   // :100
   size_t tree_making_period_counter_ = 0;  // :101
   const float loop_metric_dist_th_ = 0.8f; // :103
+  const float high_resolution_max_range_ = 100.f;  // :115
+  const float high_resolution_ = 0.2f;             // :116
   size_t db_size_ = 0, searchable_end_ = 0;
   gloc_knn* knn_ = nullptr;
   gloc_reg* reg_ = nullptr;
+  gloc_bev* bev_ = nullptr;
+  int device_ = 0;
   gloc_reg_params reg_params_{};
   std::vector<uint32_t> db_scan_ids_, query_scan_ids_;
 };

@@ -1,7 +1,8 @@
 """Python mirror of the reference's RpyPCLoopDetector + GlocEvaluator for the hot path
 (registration/loop_detector.h:41-119, registration/global_localization.cpp:202-574): same method
-names, guards and constants, over the C ABI.  Descriptors come from the caller (the CNN and the BEV
-projection are upstream of the hot path); match() is the 3-D RANSAC-SVD + ICP registration.
+names, guards and constants, over the C ABI.  Descriptors come from the caller (the CNN backbone is
+upstream of the hot path); get_projected_grid / get_place_input are the BEV projection in front of
+it and match() is the 3-D RANSAC-SVD + ICP registration.
 """
 import numpy as np
 
@@ -24,10 +25,40 @@ class RpyPCLoopDetector:
         self._db_scan_ids = []
         self._last_descriptor = None
         self.reg_params = capi.default_reg_params()
+        self.high_resolution_max_range_ = 100.0  # loop_detector.h:115
+        self.high_resolution_ = 0.2              # :116
+        self._bev = None                         # created on first use
+        self._device = device
 
     def close(self):
         self._index.close()
         self._reg.close()
+        if self._bev is not None:
+            self._bev.close()
+
+    def _projector(self):
+        if self._bev is None:
+            self._bev = capi.BevProjector(self._device)
+        return self._bev
+
+    def _bev_params(self, **over):
+        return capi.default_bev_params(resolution=self.high_resolution_,
+                                       max_range=self.high_resolution_max_range_, **over)
+
+    def get_projected_grid(self, q_pc):
+        """loop_detector.cpp:122-135: (occupancy image [H,W] u8, xy_res = (ox, oy, resolution))."""
+        bev = self._projector()
+        _, info = bev.project(q_pc, self._bev_params())
+        if info["empty"]:
+            raise ValueError("no point of the scan lies within range")  # the reference aborts in cv::Mat
+        return bev.raw_image(info), (info["ox"], info["oy"], info["resolution"])
+
+    def get_place_input(self, q_pc, width=768, height=768):
+        """The tensor get_place_feature feeds the descriptor network (loop_detector.cpp:137-151):
+        crop_pad_occupancy to width x height, /255, NHWC -> NCHW.  Returns ([1,3,H,W] f32, xy_res)."""
+        chw, info = self._projector().project(
+            q_pc, self._bev_params(out_width=width, out_height=height, format=capi.BEV_F32_CHW))
+        return chw[None], (info["ox"], info["oy"], info["resolution"])
 
     def __len__(self):
         return len(self._db_scan_ids)

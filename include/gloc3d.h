@@ -241,6 +241,60 @@ int gloc_vlad_set_profile(gloc_vlad* h, int enable);
 /* kernel families: "vlad_tile", "vlad_cluster", "vlad_fc" */
 int gloc_vlad_profile(gloc_vlad* h, const char* kernel, double* total_ms, uint64_t* launches);
 
+/* ============================ BEV occupancy projection ("next" row N1) ==================== *
+ * Replaces RpyPCLoopDetector::get_projected_grid + crop_pad_occupancy + the tensor packing of
+ * get_place_feature (registration/loop_detector.cpp:83-106,122-151): one scan inserted into a fresh
+ * Submap3D (3d/submap_3d.cpp:162-177, 3d/range_data_inserter_3d.cpp:27-78) and x-ray projected
+ * (ProjectToCvMat, 3d/submap_3d.cpp:238-326), then centred-cropped / padded to the network's input
+ * size.  Output is byte-identical to the reference's: a pixel is 0 where the column holds two or
+ * more distinct hit voxels, else 255; the padding is (255, 0, 0) (cv::Mat::ones sets channel 0
+ * only).  Scans are independent: a batch is n_scans scans back to back with host offsets. */
+typedef struct gloc_bev gloc_bev;
+
+enum {
+  GLOC_BEV_U8_HWC3 = 0, /* [out_height][out_width][3] u8: crop_pad_occupancy's cv::Mat (CV_8UC3) */
+  GLOC_BEV_F32_CHW = 1  /* [3][out_height][out_width] f32 in {0,1}: the module's input tensor */
+};
+
+typedef struct gloc_bev_params {
+  float resolution;    /* 0.2 m: high_resolution_, loop_detector.h:116 */
+  float max_range;     /* 100 m: loop_detector.cpp:113 and high_resolution_max_range_, loop_detector.h:115 */
+  uint32_t out_width;  /* 768: loop_detector.cpp:142 */
+  uint32_t out_height; /* 768: loop_detector.cpp:143 */
+  uint32_t format;     /* GLOC_BEV_* */
+  uint8_t pad_bgr[3];  /* 255, 0, 0: loop_detector.cpp:84 */
+  uint8_t reserved_;
+} gloc_bev_params;
+
+typedef struct gloc_bev_info {
+  int32_t min_ix, min_iy, max_ix, max_iy; /* voxel-index box of the occupied columns */
+  uint32_t width, height;                 /* size of the uncropped image (occupancy_grid) */
+  uint32_t n_returns;                     /* points kept by both range tests */
+  uint32_t empty;                         /* 1: no point kept (the reference aborts); image = padding */
+  double ox, oy, resolution;              /* xy_res: min index * resolution, loop_detector.cpp:133 */
+} gloc_bev_info;
+
+int gloc_bev_default_params(gloc_bev_params* p);
+int gloc_bev_create(int device, gloc_bev** out);
+int gloc_bev_destroy(gloc_bev* h);
+int gloc_bev_set_stream(gloc_bev* h, void* hip_stream);
+int gloc_bev_synchronize(gloc_bev* h);
+/* One scan, host buffers: xyz = n points, stride_floats apart (3 packed, 4 for x y z i). */
+int gloc_bev_project(gloc_bev* h, const float* xyz, size_t n, size_t stride_floats,
+                     const gloc_bev_params* p, void* out_image, gloc_bev_info* info);
+/* n_scans scans, device buffers: scan i = points [offsets[i], offsets[i+1]) of d_xyz (offsets on
+ * the host, in points); d_out_images holds n_scans images back to back.  infos (host, n_scans) may
+ * be NULL, in which case the call does not synchronise. */
+int gloc_bev_project_batch_device(gloc_bev* h, const float* d_xyz, const uint64_t* offsets,
+                                  size_t n_scans, size_t stride_floats, const gloc_bev_params* p,
+                                  void* d_out_images, gloc_bev_info* infos);
+/* The uncropped single-channel image of scan `scan` of the last projection (the occupancy_grid
+ * get_place_feature hands back, loop_detector.cpp:139-140): [height][width] u8 into `out`. */
+int gloc_bev_raw_image(gloc_bev* h, size_t scan, uint8_t* out, size_t capacity);
+int gloc_bev_set_profile(gloc_bev* h, int enable);
+/* kernel families: "bev_clear", "bev_mark", "bev_flag", "bev_image" */
+int gloc_bev_profile(gloc_bev* h, const char* kernel, double* total_ms, uint64_t* launches);
+
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).
  * kind 0: iid N(0,1)/sqrt(dim); kind 1: anchored trajectory (stride 16, noise 0.05).

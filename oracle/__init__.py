@@ -36,6 +36,14 @@ class RegParams(C.Structure):
     ]
 
 
+class BevInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("min_ix", "min_iy", "min_iz", "max_ix", "max_iy", "max_iz")] + [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("ox", C.c_double), ("oy", C.c_double), ("resolution", C.c_double),
+        ("n_returns", C.c_uint32), ("n_cells_known", C.c_uint32),
+        ("n_cells_obstructed", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
 def build(ref=True, quiet=True):
     """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
     out = subprocess.DEVNULL if quiet else None
@@ -84,6 +92,13 @@ def lib():
         L.oracle_rng_gauss.restype = C.c_float
         L.oracle_rng_gauss.argtypes = [C.c_uint64, C.c_uint64]
         L.oracle_synth_iid.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, _f32p]
+        L.oracle_bev_project.restype = C.c_int
+        L.oracle_bev_project.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+                                         C.POINTER(C.c_void_p), C.POINTER(BevInfo)]
+        L.oracle_bev_crop_pad.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_void_p]
+        L.oracle_bev_to_chw_f32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -214,3 +229,32 @@ def pose_error(T_gt, T_est):
     er, ep = C.c_float(), C.c_float()
     lib().oracle_pose_error(a, b, C.byref(er), C.byref(ep))
     return er.value, ep.value
+
+
+def bev_project(points, resolution=0.2, max_range=100.0):
+    """get_projected_grid: returns (raw image [H,W] u8 or None when empty, info dict)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    stride = pts.shape[1] if pts.ndim == 2 else 3
+    img_p, info = C.c_void_p(), BevInfo()
+    rc = lib().oracle_bev_project(pts.ctypes.data, pts.shape[0], stride, resolution, max_range,
+                                  C.byref(img_p), C.byref(info))
+    d = {n: getattr(info, n) for n, _ in BevInfo._fields_ if n != "reserved_"}
+    if rc:
+        return None, d
+    img = np.ctypeslib.as_array(C.cast(img_p, C.POINTER(C.c_uint8)), (info.height, info.width)).copy()
+    lib().oracle_free(img_p)
+    return img, d
+
+
+def bev_crop_pad(img, out_w=768, out_h=768):
+    src = np.ascontiguousarray(img, np.uint8)
+    dst = np.empty((out_h, out_w, 3), np.uint8)
+    lib().oracle_bev_crop_pad(src.ctypes.data, src.shape[1], src.shape[0], out_w, out_h, dst.ctypes.data)
+    return dst
+
+
+def bev_to_chw_f32(hwc3):
+    src = np.ascontiguousarray(hwc3, np.uint8)
+    out = np.empty((3, src.shape[0], src.shape[1]), np.float32)
+    lib().oracle_bev_to_chw_f32(src.ctypes.data, src.shape[1], src.shape[0], out.ctypes.data)
+    return out

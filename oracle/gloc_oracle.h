@@ -16,6 +16,10 @@
  *     registration/global_registration.cpp:237-248, registration/loop_detector.cpp:256-257) and
  *     holds no test or fixture for it.  The semantics are those of SURVEY.md Appendix B; known-answer
  *     tests use synthetic scan pairs with a constructed SE(3).
+ *   - BEV occupancy projection (oracle_bev_*, "next" row N1): PARITY UNPINNED.  The reference's
+ *     implementation (registration/3d/, a Cartographer subset) needs Eigen, glog, OpenCV and PCL,
+ *     absent here, and the reference holds no fixture for it; bev_oracle.c restates the source
+ *     step by step (hits, free-space misses, odds tables, projection, crop/pad).
  *
  * All fp32 arithmetic here is compiled with -ffp-contract=off (see Makefile): the reference builds
  * Release/C++14 with no arch flags (registration/CMakeLists.txt:5-7), i.e. no FMA contraction.
@@ -116,6 +120,27 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
  * 180-degree forgiveness, err_pos in metres). */
 void oracle_pose_error(const float* T_gt16, const float* T_est16, float* err_rot_deg,
                        float* err_pos);
+
+/* ---- BEV occupancy projection ("next" row N1; bev_oracle.c) --------------------------------- */
+
+typedef struct oracle_bev_info {
+  int32_t min_ix, min_iy, min_iz, max_ix, max_iy, max_iz; /* voxel-index box of obstructed cells */
+  uint32_t width, height;                                 /* raw image size */
+  double ox, oy, resolution;                              /* xy_res of get_projected_grid */
+  uint32_t n_returns, n_cells_known, n_cells_obstructed, reserved_;
+} oracle_bev_info;
+
+/* get_projected_grid (registration/loop_detector.cpp:122-135): one scan into a fresh submap, then
+ * the x-ray projection.  *out_img is malloc'd [height][width] u8 (0 = occupied column, 255 = not);
+ * release with oracle_free.  Returns 1 (and no image) when no cell is obstructed. */
+int oracle_bev_project(const float* xyz, size_t n, size_t stride_floats, float resolution,
+                       float max_range, uint8_t** out_img, oracle_bev_info* info);
+/* crop_pad_occupancy (loop_detector.cpp:83-106) -> [out_h][out_w][3] u8. */
+void oracle_bev_crop_pad(const uint8_t* src, uint32_t src_w, uint32_t src_h, uint32_t out_w,
+                         uint32_t out_h, uint8_t* dst_hwc3);
+/* The network input of get_place_feature (loop_detector.cpp:146-151): [3][h][w] f32 = u8 / 255. */
+void oracle_bev_to_chw_f32(const uint8_t* hwc3, uint32_t w, uint32_t h, float* out_chw);
+void oracle_free(void* p);
 
 /* ---- deterministic synthetic inputs (shared definition with gloc3d_amd/synth.py) ----------- */
 uint64_t oracle_rng_key(uint64_t seed, uint64_t stream);

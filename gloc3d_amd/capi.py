@@ -16,8 +16,8 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
              5: "GLOC_ERR_STATE"}
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
-REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE = 1, 2, 3
-REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
+REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_HEAVY_PERMILLE = 1, 2, 3, 4
+REG_NN_CULLED, REG_NN_EXHAUSTIVE, REG_NN_CULLED_BROADCAST = 0, 1, 2
 SIZE_MAX = C.c_size_t(-1).value
 
 

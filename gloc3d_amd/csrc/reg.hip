@@ -23,6 +23,8 @@ struct DevScan {
   float* xyz = nullptr;
   size_t n = 0;
   ScanIndexDev idx{};
+  uint32_t* order = nullptr;  // source groups of 64 * order_cs sorted points, widest first (launch order)
+  mutable int order_cs = 0;   // 0: not built yet
 };
 
 struct gloc_reg {
@@ -39,11 +41,12 @@ struct gloc_reg {
   DevBuf counters;                        // [0] = pairs evaluated by nn_culled_kernel
   std::vector<CandState> h_states;
   std::vector<CandDesc> h_cands;
-  int nn_mode = 0;                        // 0 culled (default), 1 exhaustive
+  int nn_mode = 0;                        // 0 culled + compacted (default), 1 exhaustive, 2 culled + broadcast
   bool trace_on = false;                  // dev only: per-wave trace of the culled kernel
   DevBuf trace;
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;                // culled kernel: source points per lane (1, 2, 4)
+  float nn_heavy_frac = 1.0f;             // share of a candidate's work-groups launched candidate-fastest, widest first
   uint64_t nn_launches = 0;
   Profiler prof;
 };
@@ -73,9 +76,10 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   const size_t nch = (n + CH - 1) / CH;
   const size_t nsb = (n + SB - 1) / SB;
   const size_t n1 = std::max<size_t>(n, 1), c1 = std::max<size_t>(nch, 1), b1 = std::max<size_t>(nsb, 1);
-  // layout: pts4 | box_lo | box_hi | sb_lo | sb_hi | xyz | keys | inv   (16-byte aligned parts first)
+  // layout: pts4 | box_lo | box_hi | sb_lo | sb_hi | xyz | keys | inv | order   (16-byte aligned parts first)
+  const size_t g1 = (n1 + 63) / 64;
   const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1 + 2 * b1) + sizeof(float) * 3 * n1 +
-                       sizeof(uint32_t) * 2 * n1;
+                       sizeof(uint32_t) * (2 * n1 + g1);
   GLOC_HIP(hipMalloc(&s.block, bytes));
   f32x4* p4 = reinterpret_cast<f32x4*>(s.block);
   f32x4* lo = p4 + n1;
@@ -85,6 +89,7 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   s.xyz = reinterpret_cast<float*>(shi + b1);
   uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * n1);
   uint32_t* inv = keys + n1;
+  s.order = inv + n1;
   int rc = upload_packed(h, pts, n, stride, s.xyz);
   if (rc != GLOC_OK) {
     free_scan(s);
@@ -135,6 +140,30 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   return GLOC_OK;
 }
 
+// Launch order of a source scan for the culled search: groups of 64*cs sorted points, widest first.
+int build_order(gloc_reg* h, const DevScan& s, int cs) {
+  if (s.order_cs == cs || s.n == 0) return GLOC_OK;
+  hipStream_t st = h->stream;
+  const uint32_t group = 64u * (uint32_t)cs;
+  const uint32_t ng = (uint32_t)((s.n + group - 1) / group);
+  GLOC_TRY(h->sort_keys.ensure(sizeof(float) * ng, st));
+  GLOC_TRY(h->sort_vals.ensure(sizeof(uint32_t) * ng, st));
+  GLOC_TRY(h->sort_perm.ensure(sizeof(float) * ng, st));
+  hipLaunchKernelGGL(group_extent_kernel, dim3((ng + 3) / 4), dim3(256), 0, st, s.idx.pts, (uint32_t)s.n, group,
+                     ng, h->sort_keys.as<float>(), h->sort_vals.as<uint32_t>());
+  size_t tmp_bytes = 0;
+  GLOC_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, h->sort_keys.as<float>(),
+                                                        h->sort_perm.as<float>(), h->sort_vals.as<uint32_t>(),
+                                                        s.order, (int)ng, 0, 32, st));
+  GLOC_TRY(h->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), st));
+  GLOC_HIP(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp.p, tmp_bytes, h->sort_keys.as<float>(),
+                                                        h->sort_perm.as<float>(), h->sort_vals.as<uint32_t>(),
+                                                        s.order, (int)ng, 0, 32, st));
+  GLOC_HIP(hipGetLastError());
+  s.order_cs = cs;
+  return GLOC_OK;
+}
+
 void init_state(CandState& st, const float* T16, uint32_t ransac_iters = 0) {
   memset(&st, 0, sizeof(st));
   static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -169,16 +198,37 @@ int launch_nn(gloc_reg* h, const DevScan& src, int n_cand, size_t ld, bool warm)
       GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 16, h->stream));
     }
 #define LAUNCH_CULLED(CS_)                                                                       \
-  hipLaunchKernelGGL(nn_culled_kernel<CS_>, grid, dim3(256), 0, h->stream, src.idx.pts, n_src,   \
+  hipLaunchKernelGGL(KERNEL_<CS_>, grid, dim3(256), 0, h->stream, src.idx.pts, n_src,            \
                      h->ccands.as<CulledCand>(), h->states.as<CandState>(),                      \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr,                   \
                      h->corr.as<uint32_t>(), h->d2.as<float>(), ld,                              \
                      h->prof.enabled ? h->counters.as<unsigned long long>()                      \
                                      : (unsigned long long*)nullptr,                             \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
-    if (cs == 1) LAUNCH_CULLED(1);
-    else if (cs == 2) LAUNCH_CULLED(2);
-    else LAUNCH_CULLED(4);
+    if (h->nn_mode == 2) {
+#define KERNEL_ nn_culled_kernel
+      if (cs == 1) LAUNCH_CULLED(1);
+      else if (cs == 2) LAUNCH_CULLED(2);
+      else LAUNCH_CULLED(4);
+#undef KERNEL_
+    } else {
+      GLOC_TRY(build_order(h, src, cs));
+      const uint32_t n_groups = (n_src + 64 * cs - 1) / (64 * cs), n_wg = (n_groups + 3) / 4;
+      const uint32_t heavy = std::min<uint32_t>(n_wg, (uint32_t)(n_wg * h->nn_heavy_frac + 0.5f));
+#define LAUNCH_COMPACT(CS_)                                                                         \
+  hipLaunchKernelGGL(nn_compact_kernel<CS_>, dim3(n_wg * (unsigned)n_cand), dim3(256), 0, h->stream, \
+                     src.idx.pts, n_src, h->ccands.as<CulledCand>(), h->states.as<CandState>(),    \
+                     warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr,                      \
+                     h->corr.as<uint32_t>(), h->d2.as<float>(), ld, src.order, n_groups,            \
+                     (uint32_t)n_cand, heavy,                                                       \
+                     h->prof.enabled ? h->counters.as<unsigned long long>()                         \
+                                     : (unsigned long long*)nullptr,                                \
+                     h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
+      if (cs == 1) LAUNCH_COMPACT(1);
+      else if (cs == 2) LAUNCH_COMPACT(2);
+      else LAUNCH_COMPACT(4);
+#undef LAUNCH_COMPACT
+    }
 #undef LAUNCH_CULLED
   }
   GLOC_HIP(hipGetLastError());
@@ -425,7 +475,8 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_MODE) {
-    GLOC_REQUIRE(value == GLOC_REG_NN_CULLED || value == GLOC_REG_NN_EXHAUSTIVE, GLOC_ERR_INVALID,
+    GLOC_REQUIRE(value == GLOC_REG_NN_CULLED || value == GLOC_REG_NN_EXHAUSTIVE ||
+                     value == GLOC_REG_NN_CULLED_BROADCAST, GLOC_ERR_INVALID,
                  "bad nn mode %lld", (long long)value);
     h->nn_mode = (int)value;
     return GLOC_OK;
@@ -433,6 +484,11 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {
     GLOC_REQUIRE(value == 1 || value == 2 || value == 4, GLOC_ERR_INVALID, "must be 1, 2 or 4");
     h->nn_src_per_lane = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_HEAVY_PERMILLE) {
+    GLOC_REQUIRE(value >= 0 && value <= 1000, GLOC_ERR_INVALID, "must be in [0, 1000]");
+    h->nn_heavy_frac = (float)value / 1000.0f;
     return GLOC_OK;
   }
   set_err("unknown option %d", option);

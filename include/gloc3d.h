@@ -167,11 +167,14 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
 enum {
   GLOC_REG_OPT_PROFILE = 1, /* 1: bracket every kernel with HIP events (gloc_reg_profile) */
   GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
-  GLOC_REG_OPT_NN_SRC_PER_LANE = 3 /* culled search tuning: source points per lane (1, 2 or 4) */
+  GLOC_REG_OPT_NN_SRC_PER_LANE = 3, /* culled search tuning: source points per lane (1, 2 or 4) */
+  GLOC_REG_OPT_NN_HEAVY_PERMILLE = 4 /* culled search tuning: share (0..1000 permille) of each candidate's
+                                        work-groups, widest sources first, launched ahead of the rest */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Morton-sorted scans, chunk boxes, skip what cannot win */
-  GLOC_REG_NN_EXHAUSTIVE = 1 /* every (source, target) pair */
+  GLOC_REG_NN_EXHAUSTIVE = 1, /* every (source, target) pair */
+  GLOC_REG_NN_CULLED_BROADCAST = 2 /* the culled search with whole-wave evaluation (kept for comparison) */
 };
 
 /* Scan store: keep database scans resident in HBM (x,y,z packed fp32, n points).  Returns an id

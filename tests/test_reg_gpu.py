@@ -27,12 +27,12 @@ def scans():
     return dict(A=np.ascontiguousarray(A), B=np.ascontiguousarray(B), C=np.ascontiguousarray(C_), T=T)
 
 
-@pytest.fixture(scope="module", params=["culled", "exhaustive"])
+@pytest.fixture(scope="module", params=["culled", "exhaustive", "culled_broadcast"])
 def reg(capi, request):
-    """Every registration test runs on both 1-NN search modes: the results must not differ."""
+    """Every registration test runs on all 1-NN search modes: the results must not differ."""
     r = capi.Registrar()
-    r.set_option(capi.REG_OPT_NN_MODE,
-                 capi.REG_NN_CULLED if request.param == "culled" else capi.REG_NN_EXHAUSTIVE)
+    r.set_option(capi.REG_OPT_NN_MODE, dict(culled=capi.REG_NN_CULLED, exhaustive=capi.REG_NN_EXHAUSTIVE,
+                                            culled_broadcast=capi.REG_NN_CULLED_BROADCAST)[request.param])
     yield r
     r.close()
 
@@ -149,19 +149,25 @@ def test_scan_store_ids_equal_host_buffers(reg, capi, scans):
 
 
 def test_culled_equals_exhaustive_full_size(capi, scans):
-    """Full-size scans, warm-started ICP passes included: both search modes, bit for bit."""
+    """Full-size scans, warm-started ICP passes included: all search modes (and every sources-per-lane
+    setting of the culled ones), bit for bit."""
     outs = []
-    for mode in (capi.REG_NN_CULLED, capi.REG_NN_EXHAUSTIVE):
+    configs = [(capi.REG_NN_EXHAUSTIVE, 2)] + [(m, cs) for m in (capi.REG_NN_CULLED, capi.REG_NN_CULLED_BROADCAST)
+                                               for cs in (1, 2, 4)]
+    for mode, cs in configs:
         r = capi.Registrar()
         r.set_option(capi.REG_OPT_NN_MODE, mode)
+        r.set_option(capi.REG_OPT_NN_SRC_PER_LANE, cs)
         prm = capi.default_reg_params(ransac_iters=300, icp_iters=14)  # late passes carry most points
-        outs.append(r.batch(scans["B"], [scans["A"], scans["C"]], params=prm))
-        outs.append(r.nn(scans["B"], scans["A"], scans["T"].astype(np.float32)))
+        outs.append((r.batch(scans["B"], [scans["A"], scans["C"]], params=prm),
+                     r.nn(scans["B"], scans["A"], scans["T"].astype(np.float32))))
         r.close()
-    assert (bits(outs[0]["T"]) == bits(outs[2]["T"])).all()
-    assert (outs[0]["inliers"] == outs[2]["inliers"]).all()
-    assert (bits(outs[0]["rmse"]) == bits(outs[2]["rmse"])).all()
-    assert (outs[1][0] == outs[3][0]).all() and (bits(outs[1][1]) == bits(outs[3][1])).all()
+    ref_b, ref_nn = outs[0]
+    for (b, nn), cfg in zip(outs[1:], configs[1:]):
+        assert (bits(b["T"]) == bits(ref_b["T"])).all(), cfg
+        assert (b["inliers"] == ref_b["inliers"]).all(), cfg
+        assert (bits(b["rmse"]) == bits(ref_b["rmse"])).all(), cfg
+        assert (nn[0] == ref_nn[0]).all() and (bits(nn[1]) == bits(ref_nn[1])).all(), cfg
 
 
 def test_degenerate_inputs(reg, capi):

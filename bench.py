@@ -246,9 +246,9 @@ def main():
     else:  # culled: pairs the kernel actually evaluated (its own counter)
         eval_pairs = float(pairs_eval) / max(nn_launches, 1)
     achieved = FLOP_PER_PAIR * eval_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-    kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_culled_kernel"
+    kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_compact_kernel"
     traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), same workload
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_nn_culled.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_nn_compact.json")
     if args.nn_mode == "culled" and world == 1 and os.path.exists(pmc):
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved,

@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="throughput mode: queries in flight per GPU (one registration handle, HIP stream and "
+                         "host thread each); a step handles gpus x inflight queries")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
                     help="1-NN search of the registration (identical results)")
@@ -144,7 +147,8 @@ def main():
             comm_dev = torch.device("cpu")
 
     n_places = args.places
-    per_step = world if args.mode == "throughput" else 1   # queries per step
+    inflight = max(1, args.inflight) if args.mode == "throughput" else 1
+    per_step = world * inflight if args.mode == "throughput" else 1   # queries per step
     n_steps, n_warm = args.steps, args.warmup
     t_setup = time.time()
 
@@ -157,14 +161,19 @@ def main():
     log(f"database: {n_places} x {DIM} ({n_local} rows on rank 0), generated on device")
 
     pool, qscans = build_scans(SCAN_POOL, QUERY_POOL)
-    reg = capi.Registrar(device=local_rank)
-    reg.set_option(capi.REG_OPT_PROFILE, 1)
-    reg.set_option(capi.REG_OPT_NN_MODE,
-                   capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
-    if args.nn_src_per_lane:
-        reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
-    pool_ids = [reg.scan_upload(p) for p in pool]
-    q_ids = [reg.scan_upload(q) for q in qscans]
+    # one registration handle (own HIP stream, own scan store) per query in flight
+    regs, pool_ids_k, q_ids_k = [], [], []
+    for _ in range(inflight):
+        r_ = capi.Registrar(device=local_rank)
+        r_.set_option(capi.REG_OPT_PROFILE, 1)
+        r_.set_option(capi.REG_OPT_NN_MODE,
+                      capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
+        if args.nn_src_per_lane:
+            r_.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
+        pool_ids_k.append([r_.scan_upload(p) for p in pool])
+        q_ids_k.append([r_.scan_upload(q) for q in qscans])
+        regs.append(r_)
+    reg, pool_ids, q_ids = regs[0], pool_ids_k[0], q_ids_k[0]
     params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
     mean_pts = float(np.mean([p.shape[0] for p in pool]))
     log(f"scans: {SCAN_POOL} pool + {QUERY_POOL} query scans, ~{mean_pts:.0f} pts each, resident")
@@ -183,12 +192,20 @@ def main():
         g = np.asarray(local_rows, np.int64) * world + rank
         return base_register(q_id, [pool_ids[int(x) % SCAN_POOL] for x in g], ranks)
 
-    def register_all(q_id, global_places, ranks):
-        # every rank holds the whole scan pool: place g carries pool scan g % SCAN_POOL
-        return base_register(q_id, [pool_ids[int(g) % SCAN_POOL] for g in global_places], ranks)
+    def make_register_all(k):
+        reg_k = sharded.hip_local_register(regs[k], params)
+
+        def fn(q_id, global_places, ranks):
+            # every rank holds the whole scan pool: place g carries pool scan g % SCAN_POOL
+            return reg_k(q_id, [pool_ids_k[k][int(g) % SCAN_POOL] for g in global_places], ranks)
+        return fn
+
+    register_all_k = [make_register_all(k) for k in range(inflight)]
+    from concurrent.futures import ThreadPoolExecutor
+    executor = ThreadPoolExecutor(max_workers=inflight)
 
     sreg = sharded.ShardedRegistrar(rank, world, local_register, comm_device=comm_dev)
-    qreg = sharded.QueryParallelRegistrar(rank, world, register_all, comm_device=comm_dev)
+    qreg = sharded.QueryParallelRegistrar(rank, world, register_all_k[0], comm_device=comm_dev)
     pairs_per_launch = []
 
     def step(i):
@@ -196,11 +213,17 @@ def main():
         idx, d2 = knn.search(queries[q0:q0 + per_step], TOP_K)
         cand = idx.cpu().numpy()                          # [per_step, 20] global place ids, retrieval order
         if args.mode == "throughput":
-            my = q0 + rank
-            tables = qreg.register(q_ids[my % QUERY_POOL], cand, dev)          # [world, 20, 19]
+            mys = [q0 + rank * inflight + k for k in range(inflight)]
+            tables = qreg.register_many([q_ids_k[k][mys[k] % QUERY_POOL] for k in range(inflight)], cand, dev,
+                                        register_all_k, executor)              # [world*inflight, 20, 19]
             sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
-            mine = cand[rank][cand[rank] >= 0]
-            nq = qscans[my % QUERY_POOL].shape[0]
+            if i >= n_warm:
+                for k in range(inflight):
+                    mine = cand[rank * inflight + k]
+                    nq = qscans[mys[k] % QUERY_POOL].shape[0]
+                    pairs_per_launch.append(float(nq) * float(sum(pool[int(g) % SCAN_POOL].shape[0]
+                                                                    for g in mine[mine >= 0])))
+            return cand, sel
         else:
             table = sreg.register(q_ids[q0 % QUERY_POOL], cand[0], dev)
             sel = [sreg.select_first_ok(table)]
@@ -221,7 +244,8 @@ def main():
         cand, sel = step(i)
         assert (cand[:, 0] == q_rows[i * per_step:(i + 1) * per_step]).all(), "retrieval sanity: top-1 != query place"
     fence()
-    reg.profile_reset()
+    for r_ in regs:
+        r_.profile_reset()
     t0 = time.time()
     sels = []
     for i in range(n_warm, n_warm + n_steps):
@@ -235,10 +259,12 @@ def main():
         elapsed = float(t.item())
 
     # ---- roofline of the dominant kernel (K4 point-NN), from the HIP events of the timed region --
-    nn_ms, nn_launches = reg.profile("nn")
-    stage_ms = {n: reg.profile(n)[0] for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve", "transform")}
+    nn_ms = sum(r_.profile("nn")[0] for r_ in regs)
+    nn_launches = sum(r_.profile("nn")[1] for r_ in regs)
+    stage_ms = {n: sum(r_.profile(n)[0] for r_ in regs)
+                for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve", "transform")}
     passes = 1 + ICP_ITERS
-    pairs_eval, _ = reg.nn_stats()
+    pairs_eval = sum(r_.nn_stats()[0] for r_ in regs)
     all_pairs = float(np.mean(pairs_per_launch)) if pairs_per_launch else 0.0   # exhaustive pair count
     avg_launch_s = (nn_ms / max(nn_launches, 1)) * 1e-3
     if args.nn_mode == "exhaustive":
@@ -259,7 +285,10 @@ def main():
                 if avg_launch_s > 0 else 0.0,
                 "note": f"{FLOP_PER_PAIR} flop/pair x {eval_pairs:.3e} pairs EVALUATED per launch (rank 0; "
                         f"the exhaustive count is {all_pairs:.3e}) / {avg_launch_s*1e3:.3f} ms avg over "
-                        f"{nn_launches} launches; fp32 peak (vector = MFMA) {PEAK_FP32_TFLOPS} TF"}
+                        f"{nn_launches} launches; fp32 peak (vector = MFMA) {PEAK_FP32_TFLOPS} TF"
+                        + (f"; durations are HIP-event spans with {inflight} queries in flight: launches of "
+                           f"different queries overlap on the GPU, so a span is longer than the kernel run alone"
+                           if inflight > 1 else "")}
 
     out = {
         "metric": "localization queries/sec (kNN+top-20 reg), KITTI-00-sized DB",
@@ -269,11 +298,13 @@ def main():
         "config": {"workload": f"cfgD: KITTI-00-sized DB {n_places}x{DIM} fp32, {per_step} quer"
                                f"{'y' if per_step == 1 else 'ies'}/step -> top-{TOP_K} -> {TOP_K} candidate "
                                f"scans (~{mean_pts:.0f} pts) x (RANSAC {RANSAC_ITERS} + ICP {ICP_ITERS})",
-                   "queries_per_step": per_step,
+                   "queries_per_step": per_step, "queries_in_flight_per_gpu": inflight,
                    "places": n_places, "dim": DIM, "top_k": TOP_K, "points_per_scan": int(mean_pts),
                    "ransac_iters": RANSAC_ITERS, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
                    "nn_mode": args.nn_mode, "ransac_confidence": float(params.ransac_confidence),
-                   "parallelism": "1 gpu" if world == 1 else (
+                   "parallelism": (f"1 gpu, {inflight} queries in flight (one registration handle + HIP stream + "
+                                   f"host thread each)") if world == 1 else (
+                       f"{inflight} queries in flight per gpu; "
                        f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "
                        + ("one query per rank registered locally, result tables all-gathered"
                           if args.mode == "throughput" else

@@ -128,6 +128,33 @@ class QueryParallelRegistrar:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out.to(device).view(self.world, n, RESULT_COLS)
 
+    def register_many(self, my_queries, cand_global_all, device, registers, executor):
+        """K queries per rank in flight (K = len(registers)): a step handles G*K queries, rank r owning
+        rows r*K .. r*K+K-1 of cand_global_all [G*K, n].  registers[k] is the local_register_all of
+        the k-th registration handle (each handle has its own HIP stream and is driven by its own host
+        thread of `executor`, so one query's small kernels and launch gaps run under another's 1-NN
+        passes).  One all-gather of the K result tables.  Returns [G*K, n, RESULT_COLS]."""
+        cand = np.asarray(cand_global_all, dtype=np.int64)
+        K, n = len(registers), cand.shape[1]
+        assert cand.shape[0] == self.world * K and len(my_queries) == K
+
+        def one(k):
+            mine = cand[self.rank * K + k]
+            out = np.zeros((n, RESULT_COLS), np.float32)
+            rows = np.nonzero(mine >= 0)[0]
+            if rows.size:
+                out[rows] = registers[k](my_queries[k], mine[rows], rows.astype(np.uint32))
+            return out
+
+        tables = np.stack(list(executor.map(one, range(K)))) if K > 1 else one(0)[None]
+        t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
+        if self.world == 1:
+            return t.to(device).view(K, n, RESULT_COLS)
+        t = t.to(self.comm_device or device)
+        out = torch.empty((self.world * K * n, RESULT_COLS), dtype=torch.float32, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.to(device).view(self.world * K, n, RESULT_COLS)
+
 
 # ---- HIP-backed defaults ------------------------------------------------------------------------
 

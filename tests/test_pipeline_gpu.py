@@ -99,3 +99,30 @@ def test_command_lines(dataset):
     p = subprocess.run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
                         str(d / "valset.txt")], cwd=d, capture_output=True, text=True)
     assert p.returncode == 1 and "descriptor" in p.stderr
+
+
+def test_queries_in_flight_give_identical_results(capi):
+    """Three registration handles driven by three host threads (bench.py's throughput mode): every
+    query's result equals the one it gets alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gloc3d_amd import synth
+    w = synth.make_world(1001)
+    scans = [np.ascontiguousarray(synth.lidar_scan(w, synth.se3(1.5 * i, (0.4 * i, -0.2 * i, 0.02 * i)), seed=50 + i,
+                                                   n_az=500)[:, :3]) for i in range(5)]
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=4)
+    regs = [capi.Registrar() for _ in range(3)]
+    ids = [[r.scan_upload(s) for s in scans] for r in regs]
+    alone = [regs[0].batch_ids(ids[0][q], [ids[0][c] for c in range(5) if c != q], params=prm) for q in range(3)]
+
+    def work(k):
+        out = None
+        for _ in range(4):   # repeated, so the three streams really overlap
+            out = regs[k].batch_ids(ids[k][k], [ids[k][c] for c in range(5) if c != k], params=prm)
+        return out
+    with ThreadPoolExecutor(3) as ex:
+        together = list(ex.map(work, range(3)))
+    for a, b in zip(alone, together):
+        assert (a["T"].view(np.uint32) == b["T"].view(np.uint32)).all()
+        assert (a["inliers"] == b["inliers"]).all() and (a["ok"] == b["ok"]).all()
+    for r in regs:
+        r.close()

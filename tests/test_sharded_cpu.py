@@ -46,7 +46,7 @@ def _worker(rank, world, port, n_places, dim, out_dir):
         return torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(d2)
 
     knn = sharded.ShardedKnn(rank, world, local_search, _checker_merge)
-    q_rows = np.array([5, 40, n_places - 1, 17, 63])
+    q_rows = np.array([5, 40, n_places - 1, 17, 63, 99])
     q = torch.from_numpy(synth.queries_near(77, q_rows, dim))
     gi, gd = knn.search(q, 20)
 
@@ -77,8 +77,22 @@ def _worker(rank, world, port, n_places, dim, out_dir):
 
     qreg = sharded.QueryParallelRegistrar(rank, world, register_all)
     tables = qreg.register(100 + rank, gi[:world].numpy(), torch.device("cpu"))
+    # two queries in flight per rank: handle k tags its rows with 1000 * k
+    from concurrent.futures import ThreadPoolExecutor
+
+    def handle(k):
+        def fn(query, places, ranks):
+            out = register_all(query, places, ranks)
+            out[:, 0] = 1000 * k
+            return out
+        return fn
+
+    with ThreadPoolExecutor(2) as ex:
+        many = qreg.register_many([200 + 2 * rank, 201 + 2 * rank], gi[:2 * world].numpy(), torch.device("cpu"),
+                                  [handle(0), handle(1)], ex)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), gi=gi.numpy(), gd=gd.numpy(), table=table.numpy(),
-             sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64), tables=tables.numpy())
+             sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64), tables=tables.numpy(),
+             many=many.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,7 +106,7 @@ def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     # single-database truth
     db = synth.descriptors_traj(77, 0, n_places, dim)
-    q = synth.queries_near(77, np.array([5, 40, n_places - 1, 17, 63]), dim)
+    q = synth.queries_near(77, np.array([5, 40, n_places - 1, 17, 63, 99]), dim)
     oi, od = oracle_mod.knn_search(db, q, 20)
     for o in outs:                                   # replicated and equal to the 1-GPU result
         assert (o["gi"].astype(np.uint64) == oi).all()
@@ -112,6 +126,14 @@ def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
         assert tb.shape == (world, 20, sharded.RESULT_COLS) and (tb == outs[0]["tables"]).all()
         for r in range(world):
             assert (tb[r, :, 16] == 100 + r).all() and (tb[r, :, 17] == oi[r].astype(np.float32)).all()
+        # two in flight: row r*2+k was produced by rank r's handle k for query 200 + 2r + k
+        mn = o["many"]
+        assert mn.shape == (2 * world, 20, sharded.RESULT_COLS) and (mn == outs[0]["many"]).all()
+        for r in range(world):
+            for k in range(2):
+                row = mn[2 * r + k]
+                assert (row[:, 16] == 200 + 2 * r + k).all() and (row[:, 0] == 1000 * k).all()
+                assert (row[:, 17] == oi[2 * r + k].astype(np.float32)).all()
 
 
 def test_sharding_arithmetic():

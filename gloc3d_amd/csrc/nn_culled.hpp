@@ -38,6 +38,9 @@ struct ScanIndexDev {
   const uint32_t* inv;   // original index -> sorted position
   uint32_t n, nchunks;
   float ox, oy, oz, inv_cell;
+  const f32x4* sup_lo;   // per super-chunk of 64 chunks (8192 points)
+  const f32x4* sup_hi;
+  uint32_t nsup;
 };
 
 struct CulledCand {
@@ -128,6 +131,28 @@ __global__ __launch_bounds__(64) void chunk_boxes_kernel(const f32x4* __restrict
   if (lane == 0) {
     lo[c] = f32x4{mn[0], mn[1], mn[2], 0.f};
     hi[c] = f32x4{mx[0], mx[1], mx[2], 0.f};
+  }
+}
+
+// one wave per super-chunk: the union of 64 chunk boxes
+__global__ __launch_bounds__(64) void super_boxes_kernel(const f32x4* __restrict__ lo, const f32x4* __restrict__ hi,
+                                                         uint32_t nchunks, f32x4* __restrict__ slo,
+                                                         f32x4* __restrict__ shi) {
+  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  if (c < nchunks) {
+    const f32x4 a = lo[c], b = hi[c];
+    mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
+    mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+    }
+  if (threadIdx.x == 0) {
+    slo[blockIdx.x] = f32x4{mn[0], mn[1], mn[2], 0.f};
+    shi[blockIdx.x] = f32x4{mx[0], mx[1], mx[2], 0.f};
   }
 }
 
@@ -515,11 +540,14 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
     GPTR(uint32_t) keys; GPTR(uint32_t) inv;
     uint32_t n, nchunks;
     float ox, oy, oz, inv_cell;
+    GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
+    uint32_t nsup;
   };
   const ScanIndexDev ixg = ccands[cand].idx;
   const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
                      (GPTR(f32x4))ixg.sb_lo, (GPTR(f32x4))ixg.sb_hi, (GPTR(uint32_t))ixg.keys,
-                     (GPTR(uint32_t))ixg.inv, ixg.n, ixg.nchunks, ixg.ox, ixg.oy, ixg.oz, ixg.inv_cell};
+                     (GPTR(uint32_t))ixg.inv, ixg.n, ixg.nchunks, ixg.ox, ixg.oy, ixg.oz, ixg.inv_cell,
+                     (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup};
   GPTR(float) txyz = (GPTR(float))ccands[cand].xyz;
   float T[12];
 #pragma unroll
@@ -597,26 +625,44 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
   };
   float wmax = wave_max_best();
 
-  // ---- sweep: 64 chunk boxes per ballot -----------------------------------------------------
-  f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};  // next batch's boxes, in flight
-  if ((uint32_t)lane < ix.nchunks) {
-    nlo = ix.box_lo[lane];
-    nhi = ix.box_hi[lane];
-  }
-  for (uint32_t c0 = 0; c0 < ix.nchunks; c0 += 64) {
+  // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
+  auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
+    const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
+    const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
+    const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
+    return ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
+  };
+  for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
+    float lbs = 3.402823466e+38f;
+    if (s0 + lane < ix.nsup) {
+      const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
+      lbs = box_box_lb(ulo, uhi);
+    }
+    unsigned long long smask = __ballot(lbs <= wmax);
+    // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
+    f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
+    int cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cl = (s0 + cur) * 64 + lane;
+      if (cl < ix.nchunks) { nlo = ix.box_lo[cl]; nhi = ix.box_hi[cl]; }
+    }
+    while (cur >= 0) {
+    const uint32_t c0 = (s0 + cur) * 64;
+    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax;
     const uint32_t cl = c0 + lane;
     const f32x4 blo = nlo, bhi = nhi;
-    if (cl + 64 < ix.nchunks) {
-      nlo = ix.box_lo[cl + 64];
-      nhi = ix.box_hi[cl + 64];
+    cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cn = (s0 + cur) * 64 + lane;
+      if (cn < ix.nchunks) { nlo = ix.box_lo[cn]; nhi = ix.box_hi[cn]; }
     }
+    if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
     float lbw = 3.402823466e+38f;
-    if (cl < ix.nchunks) {
-      const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
-      const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
-      const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
-      lbw = ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
-    }
+    if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
     unsigned long long mask = __ballot(lbw <= wmax);
     while (mask) {
       const int b = __ffsll((long long)mask) - 1;
@@ -751,6 +797,7 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
       }
       if (__any(changed)) wmax = wave_max_best();
     }
+    }  // batches of this super-chunk group
   }
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs, n_items * (unsigned long long)SB);
 

@@ -76,9 +76,11 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   const size_t nch = (n + CH - 1) / CH;
   const size_t nsb = (n + SB - 1) / SB;
   const size_t n1 = std::max<size_t>(n, 1), c1 = std::max<size_t>(nch, 1), b1 = std::max<size_t>(nsb, 1);
-  // layout: pts4 | box_lo | box_hi | sb_lo | sb_hi | xyz | keys | inv | order   (16-byte aligned parts first)
+  // layout: pts4 | box_lo | box_hi | sb_lo | sb_hi | sup_lo | sup_hi | xyz | keys | inv | order
+  // (16-byte aligned parts first)
   const size_t g1 = (n1 + 63) / 64;
-  const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1 + 2 * b1) + sizeof(float) * 3 * n1 +
+  const size_t nsup = (nch + 63) / 64, u1 = std::max<size_t>(nsup, 1);
+  const size_t bytes = sizeof(f32x4) * (n1 + 2 * c1 + 2 * b1 + 2 * u1) + sizeof(float) * 3 * n1 +
                        sizeof(uint32_t) * (2 * n1 + g1);
   GLOC_HIP(hipMalloc(&s.block, bytes));
   f32x4* p4 = reinterpret_cast<f32x4*>(s.block);
@@ -86,7 +88,9 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   f32x4* hi = lo + c1;
   f32x4* slo = hi + c1;
   f32x4* shi = slo + b1;
-  s.xyz = reinterpret_cast<float*>(shi + b1);
+  f32x4* ulo = shi + b1;
+  f32x4* uhi = ulo + u1;
+  s.xyz = reinterpret_cast<float*>(uhi + u1);
   uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * n1);
   uint32_t* inv = keys + n1;
   s.order = inv + n1;
@@ -106,7 +110,7 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
   const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
   const float cell = std::max(0.25f, ext / 1023.0f);
   s.idx = ScanIndexDev{p4, lo, hi, slo, shi, keys, inv, (uint32_t)n, (uint32_t)nch,
-                       mn[0], mn[1], mn[2], 1.0f / cell};
+                       mn[0], mn[1], mn[2], 1.0f / cell, ulo, uhi, (uint32_t)nsup};
   if (n) {
     hipStream_t st = h->stream;
     auto fail = [&](int code) { free_scan(s); return code; };
@@ -131,6 +135,7 @@ int make_scan(gloc_reg* h, const float* pts, size_t n, size_t stride, DevScan* o
     hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, st, p4, (uint32_t)n, lo, hi);
     hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, p4,
                        (uint32_t)n, (uint32_t)nsb, slo, shi);
+    hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, st, lo, hi, (uint32_t)nch, ulo, uhi);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
       set_err("scan indexing failed: %s", hipGetErrorString(hipGetLastError()));
       return fail(GLOC_ERR_HIP);

@@ -58,6 +58,34 @@ def test_nn_ragged_with_transform(reg, oracle_mod, ns, nt):
     assert (idx == oi).all() and (bits(d2) == bits(od)).all()
 
 
+def test_nn_lattice_ties(reg, oracle_mod):
+    """Exact ties everywhere: lattice targets in shuffled order, sources on cell centres, edge and
+    face midpoints (2, 4 or 8 equidistant targets, usually in different sub-blocks and chunks):
+    the smallest ORIGINAL index must win, through the tie flag and the slow rescan."""
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(12), indexing="ij"), -1).reshape(-1, 3)
+    tgt = (g[rng.permutation(len(g))] * 0.5).astype(np.float32)            # 6912 points, spacing 0.5 (exact)
+    cells = g[(g[:, 0] < 23) & (g[:, 1] < 23) & (g[:, 2] < 11)].astype(np.float32) * 0.5
+    src = np.concatenate([cells + np.float32(0.25),                          # cell centres: 8-way ties
+                          cells + np.array([0.25, 0, 0], np.float32),        # edge midpoints: 2-way
+                          cells + np.array([0.25, 0.25, 0], np.float32),     # face centres: 4-way
+                          tgt[::7]]).astype(np.float32)                      # exact hits
+    src = src[rng.permutation(len(src))]
+    idx, d2 = reg.nn(src, tgt)
+    oi, od = oracle_mod.nn3(src, tgt)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    # the same clouds through a warm-started ICP run, against the exhaustive search
+    # (reg is one of the modes; the batch outputs must not depend on it)
+    from gloc3d_amd import capi as c
+    r = reg.batch(src[:4000], [tgt], params=c.default_reg_params(ransac_iters=0, icp_iters=3))
+    assert np.isfinite(r["T"]).all()
+    first = _LATTICE.setdefault("T", r["T"].copy())
+    assert (bits(first) == bits(r["T"])).all()
+
+
+_LATTICE = {}
+
+
 def test_nn_full_size_properties(reg, scans):
     A = scans["A"]
     idx, d2 = reg.nn(A, A)                      # idempotence: every point is its own neighbour

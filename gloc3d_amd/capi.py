@@ -60,6 +60,24 @@ class BevInfo(C.Structure):
 BEV_U8_HWC3, BEV_F32_CHW = 0, 1
 
 
+class GroundParams(C.Structure):
+    _fields_ = [("near_range2", C.c_float), ("knn", C.c_uint32), ("plane_thresh", C.c_float),
+                ("ransac_iters", C.c_uint32), ("ransac_conf", C.c_float), ("reserved_", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class GroundInfo(C.Structure):
+    _fields_ = [("n_near", C.c_uint32), ("hist", C.c_uint32 * 18), ("ground_bin", C.c_int32),
+                ("n_ground", C.c_uint32), ("best_hyp", C.c_uint32), ("inliers", C.c_uint32),
+                ("iters_used", C.c_uint32), ("plane", C.c_float * 4), ("found", C.c_int32)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["hist"] = np.array(list(self.hist), np.uint32)
+        d["plane"] = np.array(list(self.plane), np.float32)
+        return d
+
+
 # every symbol include/gloc3d.h declares: (name, restype, argtypes)
 _vp, _sz, _u64, _i, _u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32
 _PROTOS = [
@@ -123,6 +141,17 @@ _PROTOS = [
     ("gloc_bev_raw_image", _i, [_vp, _sz, _vp, _sz]),
     ("gloc_bev_set_profile", _i, [_vp, _i]),
     ("gloc_bev_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("gloc_ground_default_params", _i, [_vp]),
+    ("gloc_ground_create", _i, [_i, C.POINTER(_vp)]),
+    ("gloc_ground_destroy", _i, [_vp]),
+    ("gloc_ground_set_stream", _i, [_vp, _vp]),
+    ("gloc_ground_estimate", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    ("gloc_ground_estimate_device", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    ("gloc_ground_knn", _i, [_vp, _vp, _sz, _u32, _vp, _vp]),
+    ("gloc_ground_normals", _i, [_vp, _vp, _sz, _u32, _vp, _vp]),
+    ("gloc_ground_transform_from_plane", _i, [_vp, _vp]),
+    ("gloc_ground_set_profile", _i, [_vp, _i]),
+    ("gloc_ground_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_knn_add_synthetic", _i, [_vp, _i, _u64, _u64, _sz, _u64]),
     ("gloc_synth_fill_device", _i, [_i, _vp, _i, _u64, _u64, _sz, _sz, _u64, _vp]),
 ]
@@ -535,4 +564,77 @@ class BevProjector:
     def profile(self, kernel):
         ms, n = C.c_double(), C.c_uint64()
         check(lib().gloc_bev_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def default_ground_params(**over):
+    p = GroundParams()
+    check(lib().gloc_ground_default_params(C.byref(p)))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def ground_transform_from_plane(plane):
+    T = np.empty(16, np.float32)
+    check(lib().gloc_ground_transform_from_plane(_np_ptr(np.ascontiguousarray(plane, np.float32)), _np_ptr(T)))
+    return T.reshape(4, 4)
+
+
+class GroundEstimator:
+    """Ground pre-alignment (GroundEstimator::EsitmateGroundAndTransform,
+    registration/ground_estimator.cpp:196-228)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().gloc_ground_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_ground_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def estimate(self, points, params=None, want_cloud=False):
+        """points [n, 3 or more] float32 -> (T_l2g 4x4, info dict[, transformed cloud])."""
+        p = params or default_ground_params()
+        pts = np.ascontiguousarray(points, np.float32)
+        T, info = np.empty(16, np.float32), GroundInfo()
+        out = np.empty_like(pts) if want_cloud else None
+        check(lib().gloc_ground_estimate(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1], C.byref(p), _np_ptr(T),
+                                         C.byref(info), _np_ptr(out) if want_cloud else None))
+        return (T.reshape(4, 4), info.as_dict(), out) if want_cloud else (T.reshape(4, 4), info.as_dict())
+
+    def estimate_device(self, xyz_ptr, n, stride_floats, out_ptr=None, params=None):
+        p = params or default_ground_params()
+        T, info = np.empty(16, np.float32), GroundInfo()
+        check(lib().gloc_ground_estimate_device(self._h, C.c_void_p(xyz_ptr), n, stride_floats, C.byref(p), _np_ptr(T),
+                                                C.byref(info), C.c_void_p(out_ptr) if out_ptr else None))
+        return T.reshape(4, 4), info.as_dict()
+
+    def knn(self, xyz, k=10):
+        p = np.ascontiguousarray(xyz, np.float32)
+        idx = np.empty((p.shape[0], k), np.uint32)
+        d2 = np.empty((p.shape[0], k), np.float32)
+        check(lib().gloc_ground_knn(self._h, _np_ptr(p), p.shape[0], k, _np_ptr(idx), _np_ptr(d2)))
+        return idx, d2
+
+    def normals(self, xyz, k=10):
+        p = np.ascontiguousarray(xyz, np.float32)
+        nrm = np.empty((p.shape[0], 3), np.float32)
+        bins = np.empty(p.shape[0], np.uint8)
+        check(lib().gloc_ground_normals(self._h, _np_ptr(p), p.shape[0], k, _np_ptr(nrm), _np_ptr(bins)))
+        return nrm, bins
+
+    def set_profile(self, on=True):
+        check(lib().gloc_ground_set_profile(self._h, 1 if on else 0))
+
+    def profile(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gloc_ground_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value

@@ -7,13 +7,15 @@
 // mean +/- std, failed_detect_indices.txt and failed_registration_indices.txt in the CWD.
 // argv[3] is the descriptor file that stands in for the TorchScript model (the CNN is out of the
 // hot path's scope): "GLOCDESC" u32 n u32 dim, then db descriptors followed by query descriptors in
-// valset order.  A 4th argument selected ground alignment in the reference (:584-588); that
-// pre-step is not part of this build and is reported as ignored.
+// valset order.  A 4th argument selects ground alignment as in the reference (:584-588): every db
+// and query scan is pre-aligned by gloc_ground_estimate (:431-436, :495-499), registration runs on
+// the aligned clouds and the pose is carried back with Tdb_l2g^-1 * T * Tq_l2g (:527-541).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <memory>
+#include <stdexcept>
 
 #include "loop_detector.hpp"
 
@@ -30,6 +32,24 @@ struct GlocEvaluator {
   std::vector<std::vector<size_t>> queried_idx;
   std::vector<std::pair<size_t, Mat4>> located;  // {db idx, pose in db}
   double time_sum_match = 0, times_call_match = 0;
+  bool align_ground = false;
+  gloc_ground* ground = nullptr;
+  std::vector<Mat4> db_rpz_estimates;  // T_l2g per database scan (:393)
+
+  ~GlocEvaluator() { gloc_ground_destroy(ground); }
+
+  // EsitmateGroundAndTransform: the scan is replaced by its ground-aligned copy; returns T_l2g
+  Mat4 align(std::vector<float>& scan) {
+    if (!ground && gloc_ground_create(0, &ground) != GLOC_OK) throw std::runtime_error(gloc_last_error());
+    gloc_ground_params p;
+    gloc_ground_default_params(&p);
+    Mat4 T = identity4();
+    std::vector<float> out(scan.size());
+    if (gloc_ground_estimate(ground, scan.data(), scan.size() / 4, 4, &p, T.data(), nullptr, out.data()) != GLOC_OK)
+      throw std::runtime_error(gloc_last_error());
+    scan.swap(out);
+    return T;
+  }
 
   static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -37,14 +57,21 @@ struct GlocEvaluator {
 
   void construct_db() {  // :419-449
     det.reset(new RpyPCLoopDetector(dim));
-    double t_add = 0;
+    double t_add = 0, t_align = 0;
     for (size_t i = 0; i < vs.db_files.size(); ++i) {
       std::vector<float> scan = read_lidar_kitti(vs.db_files[i]);
       std::vector<float> d(desc.begin() + i * dim, desc.begin() + (i + 1) * dim);
+      if (align_ground) {
+        const double ta = now_ms();
+        db_rpz_estimates.push_back(align(scan));
+        t_align += now_ms() - ta;
+      }
       const double t0 = now_ms();
       det->add_keyframe(d, scan.data(), scan.size() / 4);
       t_add += now_ms() - t0;
     }
+    if (align_ground)
+      std::printf("time cost for align to ground: %f ms.\n", t_align / std::max<size_t>(1, vs.db_files.size()));
     std::printf("time cost for add_keyframe (upload + index): %f ms.\n", t_add / std::max<size_t>(1, vs.db_files.size()));
   }
 
@@ -63,12 +90,26 @@ struct GlocEvaluator {
       queried_idx.push_back(idx);
       if (idx.empty()) continue;
       std::vector<float> scan = read_lidar_kitti(vs.q_files[q]);
+      Mat4 Tq_l2g = identity4();
+      if (align_ground) Tq_l2g = align(scan);
       Mat4 pose = identity4();
+      // Without alignment the registration starts from the identity (sensor frames alike).  The same
+      // prior expressed between the ground frames is Tdb_l2g * Tq_l2g^-1; it also carries the half
+      // turn about z by which two T_l2g can differ (the first Euler angle is kept in [0, pi]).
+      std::vector<Mat4> init;
+      if (align_ground)
+        for (size_t c : idx) init.push_back(mul4(db_rpz_estimates[c], rigid_inverse(Tq_l2g)));
       const double t1 = now_ms();
-      const int r = det->match(scan.data(), scan.size() / 4, idx, pose);
+      const int r = det->match(scan.data(), scan.size() / 4, idx, pose, nullptr, nullptr,
+                               align_ground ? &init : nullptr);
       time_sum_match += now_ms() - t1;
       times_call_match += 1;
-      if (r >= 0) located[q] = {idx[(size_t)r], pose};
+      if (r >= 0) {
+        const size_t db_idx = idx[(size_t)r];
+        if (align_ground)  // back to the sensor frames: Tdb_l2g^-1 * T_qg_dbg * Tq_l2g (:541)
+          pose = mul4(rigid_inverse(db_rpz_estimates[db_idx]), mul4(pose, Tq_l2g));
+        located[q] = {db_idx, pose};
+      }
     }
     std::printf("Each query cost: %f ms.\n", t_det / std::max<size_t>(1, vs.q_files.size()));
   }
@@ -146,7 +187,7 @@ int main(int argc, char* argv[]) {
     return 2;
   }
   GlocEvaluator g;
-  if (argc == 5) std::printf("note: ground alignment (4th argument) is outside this build's scope; ignored\n");
+  g.align_ground = argc == 5;  // :584-588
   if (!read_valset(argv[1], g.vs) || !read_valset_pose(argv[2], g.poses_db_q)) return 1;
   std::printf("db_num and db_files: %zu\nq_num and q_files: %zu\nq_num and q_pos_index: %zu\n", g.vs.db_files.size(),
               g.vs.q_files.size(), g.vs.pos_idx.size());

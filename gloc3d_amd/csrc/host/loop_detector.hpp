@@ -80,24 +80,34 @@ class RpyPCLoopDetector {
 
   // Register a query scan against retrieved candidates in one batch; returns the rank of the first
   // successful candidate (global_localization.cpp:519-572) or -1, and its pose (query -> db).
+  // init_guess (optional): one initial pose (query -> db) per candidate, as icp_match_3d's
+  // initial_guess (global_registration.cpp:237-248); identity when absent.
   int match(const float* q_scan_xyzi, size_t n_pts, const std::vector<size_t>& db_indices,
-            Mat4& pose_in_db, std::vector<Mat4>* all_poses = nullptr, std::vector<int>* all_ok = nullptr) {
+            Mat4& pose_in_db, std::vector<Mat4>* all_poses = nullptr, std::vector<int>* all_ok = nullptr,
+            const std::vector<Mat4>* init_guess = nullptr) {
     uint32_t qid = 0;
     check(gloc_reg_scan_upload(reg_, q_scan_xyzi, n_pts, 4, &qid));  // kept until clear_queries()
     query_scan_ids_.push_back(qid);
-    return match_ids(qid, db_indices, pose_in_db, all_poses, all_ok);
+    return match_ids(qid, db_indices, pose_in_db, all_poses, all_ok, init_guess);
   }
 
   int match_ids(uint32_t q_scan_id, const std::vector<size_t>& db_indices, Mat4& pose_in_db,
-                std::vector<Mat4>* all_poses, std::vector<int>* all_ok) {
+                std::vector<Mat4>* all_poses, std::vector<int>* all_ok,
+                const std::vector<Mat4>* init_guess = nullptr) {
     const size_t n = db_indices.size();
     if (n == 0) return -1;
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = db_scan_ids_.at(db_indices[i]);
     std::vector<float> T(16 * n);
     std::vector<int> ok(n);
-    check(gloc_reg_batch_ids(reg_, q_scan_id, ids.data(), n, nullptr, nullptr, &reg_params_, T.data(),
-                             nullptr, nullptr, ok.data()));
+    std::vector<float> init;
+    if (init_guess) {
+      if (init_guess->size() != n) throw std::runtime_error("one initial guess per candidate expected");
+      init.resize(16 * n);
+      for (size_t i = 0; i < n; ++i) std::copy((*init_guess)[i].begin(), (*init_guess)[i].end(), init.begin() + 16 * i);
+    }
+    check(gloc_reg_batch_ids(reg_, q_scan_id, ids.data(), n, nullptr, init_guess ? init.data() : nullptr,
+                             &reg_params_, T.data(), nullptr, nullptr, ok.data()));
     if (all_poses) {
       all_poses->resize(n);
       for (size_t i = 0; i < n; ++i) std::copy(T.begin() + 16 * i, T.begin() + 16 * (i + 1), (*all_poses)[i].begin());

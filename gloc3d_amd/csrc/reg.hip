@@ -31,7 +31,6 @@ struct gloc_reg {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::vector<DevScan> scans;  // resident scan store
-  DevBuf tmp_src, tmp_tgt;     // host-pointer API staging
   DevBuf cands, states;        // CandDesc[], CandState[]
   DevBuf corr, d2, pairs;      // [cand][ld]
   DevBuf Rt, valid, inliers;   // RANSAC hypotheses
@@ -40,7 +39,6 @@ struct gloc_reg {
   DevBuf sort_tmp, sort_keys, sort_vals, sort_perm;  // scan indexing scratch
   DevBuf counters;                        // [0] = pairs evaluated by nn_culled_kernel
   std::vector<CandState> h_states;
-  std::vector<CandDesc> h_cands;
   int nn_mode = 0;                        // 0 culled + compacted (default), 1 exhaustive, 2 culled + broadcast
   bool trace_on = false;                  // dev only: per-wave trace of the culled kernel
   DevBuf trace;
@@ -449,7 +447,7 @@ int gloc_reg_destroy(gloc_reg* h) {
   (void)hipStreamSynchronize(h->stream);
   (void)gloc_reg_scan_clear(h);
   h->prof.destroy();
-  for (DevBuf* b : {&h->tmp_src, &h->tmp_tgt, &h->cands, &h->states, &h->corr, &h->d2, &h->pairs,
+  for (DevBuf* b : {&h->cands, &h->states, &h->corr, &h->d2, &h->pairs,
                     &h->Rt, &h->valid, &h->inliers, &h->partials, &h->ccands, &h->sort_tmp,
                     &h->sort_keys, &h->sort_vals, &h->sort_perm, &h->counters})
     b->release();

@@ -15,12 +15,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "math3.hpp"          // f32x4, xform, dist2, jacobi_eig3, cross3, mulhi_idx, NN_FAR
 #include "synth_kernels.hpp"  // mix64 / rng_key / rng_draw
 
 namespace gloc {
 namespace reg {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct CandDesc {
   const float* tgt;  // packed xyz
@@ -40,23 +40,11 @@ struct CandState {
   int ransac_done;
 };
 
-__device__ __forceinline__ void xform(const float* __restrict__ T, float x, float y, float z,
-                                      float& ox, float& oy, float& oz) {
-  ox = ((T[0] * x + T[1] * y) + T[2] * z) + T[9];
-  oy = ((T[3] * x + T[4] * y) + T[5] * z) + T[10];
-  oz = ((T[6] * x + T[7] * y) + T[8] * z) + T[11];
-}
-__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = ax - bx, dy = ay - by, dz = az - bz;
-  return (dx * dx + dy * dy) + dz * dz;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K4.  grid = (ceil(n_src / (256*NN_S)), n_cand).  Each lane owns NN_S source points; targets are
 // staged 256 at a time into LDS as float4 and read back as wave-uniform broadcasts.
 constexpr int NN_S = 4;
 constexpr int NN_TC = 256;
-constexpr float NN_FAR = 1.0e18f;  // padding coordinate: squares to +inf, never the minimum
 
 __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, uint32_t n_src,
                                                  const CandDesc* __restrict__ cands,
@@ -175,51 +163,6 @@ __global__ void gather_pairs_kernel(const float* __restrict__ src, uint32_t n_sr
   pairs[((size_t)cand * ld + i) * 2 + 1] = q;
 }
 
-// ---- fp64 3x3 helpers: the same operation sequence as oracle/reg_oracle.c --------------------
-__device__ inline void jacobi_eig3(double A[9], double V[9]) {
-  V[0] = 1; V[1] = 0; V[2] = 0;
-  V[3] = 0; V[4] = 1; V[5] = 0;
-  V[6] = 0; V[7] = 0; V[8] = 1;
-  for (int sweep = 0; sweep < 16; ++sweep) {
-    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
-    if (off <= 1e-32 * diag || off == 0.0) break;
-    for (int e = 0; e < 3; ++e) {
-      const int p = (e == 2) ? 1 : 0, q = (e == 0) ? 1 : 2;
-      const double apq = A[3 * p + q];
-      if (apq == 0.0) continue;
-      const double app = A[3 * p + p], aqq = A[3 * q + q];
-      const double theta = (aqq - app) / (2.0 * apq);
-      const double at = theta < 0 ? -theta : theta;
-      double t = 1.0 / (at + sqrt(theta * theta + 1.0));
-      if (theta < 0) t = -t;
-      const double c = 1.0 / sqrt(t * t + 1.0);
-      const double s = t * c;
-      for (int k = 0; k < 3; ++k) {
-        const double akp = A[3 * k + p], akq = A[3 * k + q];
-        A[3 * k + p] = c * akp - s * akq;
-        A[3 * k + q] = s * akp + c * akq;
-      }
-      for (int k = 0; k < 3; ++k) {
-        const double apk = A[3 * p + k], aqk = A[3 * q + k];
-        A[3 * p + k] = c * apk - s * aqk;
-        A[3 * q + k] = s * apk + c * aqk;
-      }
-      for (int k = 0; k < 3; ++k) {
-        const double vkp = V[3 * k + p], vkq = V[3 * k + q];
-        V[3 * k + p] = c * vkp - s * vkq;
-        V[3 * k + q] = s * vkp + c * vkq;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3]) {
-  o[0] = a[1] * b[2] - a[2] * b[1];
-  o[1] = a[2] * b[0] - a[0] * b[2];
-  o[2] = a[0] * b[1] - a[1] * b[0];
-}
-
 __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
                                        const double qbar[3], double R[9], double t[3]) {
   double A[9], V[9];
@@ -266,10 +209,6 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
     for (int j = 0; j < 3; ++j) R[3 * i + j] = (v1[i] * u1[j] + v2[i] * u2[j]) + v3[i] * u3[j];
   for (int i = 0; i < 3; ++i)
     t[i] = qbar[i] - ((R[3 * i + 0] * pbar[0] + R[3 * i + 1] * pbar[1]) + R[3 * i + 2] * pbar[2]);
-}
-
-__device__ __forceinline__ uint32_t mulhi_idx(uint64_t u, uint32_t n) {
-  return (uint32_t)__umul64hi(u, (uint64_t)n);
 }
 
 // K5a.  One thread per (candidate, hypothesis).  pairs: [cand][ld][2] float4.

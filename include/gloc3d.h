@@ -298,6 +298,58 @@ int gloc_bev_set_profile(gloc_bev* h, int enable);
 /* kernel families: "bev_clear", "bev_mark", "bev_flag", "bev_image" */
 int gloc_bev_profile(gloc_bev* h, const char* kernel, double* total_ms, uint64_t* launches);
 
+/* ============================ ground pre-alignment ("next" row N3) ========================= *
+ * Replaces GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228),
+ * the optional 4th-argument mode of global_localization (registration/global_localization.cpp:431-436,
+ * 495-499): points within 20 m -> a normal per point from its 10 nearest neighbours -> the fullest
+ * 10-degree elevation bin outside 5..12 is the ground -> plane RANSAC (0.1 m) -> T_l2g (roll, pitch and
+ * height; yaw removed).  The reference leaves the numerics to PCL and Eigen; the exact arithmetic of
+ * this implementation is stated step by step in oracle/ground_oracle.c (parity unpinned). */
+typedef struct gloc_ground gloc_ground;
+
+typedef struct gloc_ground_params {
+  float near_range2;     /* 400 = (20 m)^2: ground_estimator.cpp:203 */
+  uint32_t knn;          /* 10: ground_estimator.cpp:79 (3..16) */
+  float plane_thresh;    /* 0.1 m: ground_estimator.cpp:27 */
+  uint32_t ransac_iters; /* 1000: pcl::SampleConsensus max_iterations_ default */
+  float ransac_conf;     /* 0.99: pcl::SampleConsensus probability_ default; <= 0 or >= 1: no early stop */
+  uint32_t reserved_;
+  uint64_t seed;
+} gloc_ground_params;
+
+typedef struct gloc_ground_info {
+  uint32_t n_near;      /* points within the range filter */
+  uint32_t hist[18];    /* elevation bins of the normals, 0 = pointing down .. 17 = pointing up */
+  int32_t ground_bin;   /* -1: none */
+  uint32_t n_ground;
+  uint32_t best_hyp, inliers, iters_used;
+  float plane[4];       /* a x + b y + c z + d = 0 with unit normal, as fitted */
+  int32_t found;        /* 0: no ground, T = identity (ground_estimator.cpp:218-220) */
+} gloc_ground_info;
+
+int gloc_ground_default_params(gloc_ground_params* p);
+int gloc_ground_create(int device, gloc_ground** out);
+int gloc_ground_destroy(gloc_ground* h);
+int gloc_ground_set_stream(gloc_ground* h, void* hip_stream);
+/* T16: T_l2g, row-major 4x4 f32 (host).  out_xyz (may be NULL): the cloud transformed by T_l2g, same
+ * layout as the input (extra channels copied) -- cloud_out of the reference. */
+int gloc_ground_estimate(gloc_ground* h, const float* xyz, size_t n, size_t stride_floats,
+                         const gloc_ground_params* p, float* T16, gloc_ground_info* info, float* out_xyz);
+int gloc_ground_estimate_device(gloc_ground* h, const float* d_xyz, size_t n, size_t stride_floats,
+                                const gloc_ground_params* p, float* T16, gloc_ground_info* info,
+                                float* d_out_xyz);
+/* Building blocks, exposed for tests (host buffers, packed xyz): the exact k nearest neighbours of every
+ * point within the cloud itself ([n][k], ascending (d2, index), the point itself first); the normals
+ * and their elevation bins. */
+int gloc_ground_knn(gloc_ground* h, const float* xyz, size_t n, uint32_t k, uint32_t* out_idx, float* out_d2);
+int gloc_ground_normals(gloc_ground* h, const float* xyz, size_t n, uint32_t k, float* out_normals,
+                        uint8_t* out_bins);
+/* T_l2g from plane coefficients (TransformPointsToGround, ground_estimator.cpp:163-194); host only. */
+int gloc_ground_transform_from_plane(const float* plane4, float* T16);
+int gloc_ground_set_profile(gloc_ground* h, int enable);
+/* kernel families: "ground_knn", "ground_normals", "ground_plane", "ground_transform" */
+int gloc_ground_profile(gloc_ground* h, const char* kernel, double* total_ms, uint64_t* launches);
+
 /* ============================ synthetic inputs (bench / tests) ============================ *
  * On-device twin of gloc3d_amd/synth.py for databases too large to upload (SURVEY.md 8d cfg E).
  * kind 0: iid N(0,1)/sqrt(dim); kind 1: anchored trajectory (stride 16, noise 0.05).

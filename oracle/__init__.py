@@ -44,6 +44,18 @@ class BevInfo(C.Structure):
         ("n_cells_obstructed", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
+class GroundParams(C.Structure):
+    _fields_ = [("near_range2", C.c_float), ("knn", C.c_uint32), ("plane_thresh", C.c_float),
+                ("ransac_iters", C.c_uint32), ("ransac_conf", C.c_float), ("reserved_", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class GroundInfo(C.Structure):
+    _fields_ = [("n_near", C.c_uint32), ("hist", C.c_uint32 * 18), ("ground_bin", C.c_int32),
+                ("n_ground", C.c_uint32), ("best_hyp", C.c_uint32), ("inliers", C.c_uint32),
+                ("iters_used", C.c_uint32), ("plane", C.c_float * 4), ("found", C.c_int32)]
+
+
 def build(ref=True, quiet=True):
     """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
     out = subprocess.DEVNULL if quiet else None
@@ -99,6 +111,13 @@ def lib():
                                           C.c_uint32, C.c_void_p]
         L.oracle_bev_to_chw_f32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_ground_knn.argtypes = [_f32p, C.c_size_t, C.c_uint32, _u32p, _f32p]
+        L.oracle_ground_normals.argtypes = [_f32p, C.c_size_t, _u32p, C.c_uint32, _f32p, C.c_void_p]
+        L.oracle_ground_estimate.restype = C.c_int
+        L.oracle_ground_estimate.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(GroundParams),
+                                             _f32p, C.POINTER(GroundInfo)]
+        L.oracle_ground_transform_from_plane.argtypes = [_f32p, _f32p]
+        L.oracle_jacobi_eig3.argtypes = [_f64p, _f64p]
         _lib = L
     return _lib
 
@@ -258,3 +277,41 @@ def bev_to_chw_f32(hwc3):
     out = np.empty((3, src.shape[0], src.shape[1]), np.float32)
     lib().oracle_bev_to_chw_f32(src.ctypes.data, src.shape[1], src.shape[0], out.ctypes.data)
     return out
+
+
+def ground_params(near_range2=400.0, knn=10, plane_thresh=0.1, ransac_iters=1000, ransac_conf=0.99, seed=0):
+    return GroundParams(near_range2, knn, plane_thresh, ransac_iters, ransac_conf, 0, seed)
+
+
+def ground_knn(xyz, k=10):
+    p = np.ascontiguousarray(xyz, np.float32)
+    idx = np.empty((p.shape[0], k), np.uint32)
+    d2 = np.empty((p.shape[0], k), np.float32)
+    lib().oracle_ground_knn(p, p.shape[0], k, idx, d2)
+    return idx, d2
+
+
+def ground_normals(xyz, knn_idx):
+    p = np.ascontiguousarray(xyz, np.float32)
+    nb = np.ascontiguousarray(knn_idx, np.uint32)
+    nrm = np.empty((p.shape[0], 3), np.float32)
+    bins = np.empty(p.shape[0], np.uint8)
+    lib().oracle_ground_normals(p, p.shape[0], nb, nb.shape[1], nrm, bins.ctypes.data)
+    return nrm, bins
+
+
+def ground_estimate(points, **kw):
+    """EsitmateGroundAndTransform: (T_l2g 4x4 f32, info dict)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    prm, info, T = ground_params(**kw), GroundInfo(), np.empty(16, np.float32)
+    lib().oracle_ground_estimate(pts.ctypes.data, pts.shape[0], pts.shape[1], C.byref(prm), T, C.byref(info))
+    d = {n: getattr(info, n) for n, _ in GroundInfo._fields_}
+    d["hist"] = np.array(list(info.hist), np.uint32)
+    d["plane"] = np.array(list(info.plane), np.float32)
+    return T.reshape(4, 4), d
+
+
+def ground_transform_from_plane(plane):
+    T = np.empty(16, np.float32)
+    lib().oracle_ground_transform_from_plane(np.ascontiguousarray(plane, np.float32), T)
+    return T.reshape(4, 4)

@@ -20,6 +20,10 @@
  *     implementation (registration/3d/, a Cartographer subset) needs Eigen, glog, OpenCV and PCL,
  *     absent here, and the reference holds no fixture for it; bev_oracle.c restates the source
  *     step by step (hits, free-space misses, odds tables, projection, crop/pad).
+ *   - ground pre-alignment (oracle_ground_*, "next" row N3): PARITY UNPINNED.  The reference
+ *     delegates to PCL (normal estimation, plane RANSAC) and Eigen, absent here; ground_oracle.c
+ *     restates registration/ground_estimator.cpp with this repository's own deterministic choices
+ *     where PCL's are unspecified (neighbour ties, the sampler, the eigen-solver).
  *
  * All fp32 arithmetic here is compiled with -ffp-contract=off (see Makefile): the reference builds
  * Release/C++14 with no arch flags (registration/CMakeLists.txt:5-7), i.e. no FMA contraction.
@@ -96,6 +100,10 @@ void oracle_nn3_grid(const float* src_xyz, size_t n_src, const float* tgt_xyz, s
 void oracle_kabsch_from_cov(const double M[9], const double pbar[3], const double qbar[3],
                             double R[9], double t[3]);
 
+/* Cyclic Jacobi on a symmetric 3x3 (row-major, overwritten: its diagonal ends up holding the
+ * eigenvalues); V's columns are the eigenvectors.  Only + - * / sqrt: CPU and GPU fp64 agree. */
+void oracle_jacobi_eig3(double A[9], double V[9]);
+
 /* The counter RNG's k-th sample triple for (seed, candidate, hypothesis). */
 void oracle_ransac_sample(uint64_t seed, uint32_t cand, uint32_t hyp, uint32_t n, uint32_t out[3]);
 
@@ -141,6 +149,43 @@ void oracle_bev_crop_pad(const uint8_t* src, uint32_t src_w, uint32_t src_h, uin
 /* The network input of get_place_feature (loop_detector.cpp:146-151): [3][h][w] f32 = u8 / 255. */
 void oracle_bev_to_chw_f32(const uint8_t* hwc3, uint32_t w, uint32_t h, float* out_chw);
 void oracle_free(void* p);
+
+/* ---- ground pre-alignment ("next" row N3; ground_oracle.c) ---------------------------------- */
+
+typedef struct oracle_ground_params {
+  float near_range2;     /* 400 = (20 m)^2: registration/ground_estimator.cpp:203 */
+  uint32_t knn;          /* 10: ground_estimator.cpp:79 */
+  float plane_thresh;    /* 0.1 m: ground_estimator.cpp:27 */
+  uint32_t ransac_iters; /* 1000: pcl::SampleConsensus default max_iterations_ */
+  float ransac_conf;     /* 0.99: pcl::SampleConsensus default probability_ */
+  uint32_t reserved_;
+  uint64_t seed;
+} oracle_ground_params;
+
+typedef struct oracle_ground_info {
+  uint32_t n_near;      /* points within the range filter */
+  uint32_t hist[18];    /* 10-degree bins of the normals' elevation, 0 = down .. 17 = up */
+  int32_t ground_bin;   /* -1: none */
+  uint32_t n_ground;    /* points whose normal falls into ground_bin */
+  uint32_t best_hyp, inliers, iters_used;
+  float plane[4];       /* a x + b y + c z + d = 0, unit normal, as fitted (before the upward flip) */
+  int32_t found;        /* 0: identity returned */
+} oracle_ground_info;
+
+/* Exact k nearest neighbours of every point within the cloud itself (the point is its own first
+ * neighbour), d2 = (dx*dx + dy*dy) + dz*dz un-fused, ascending (d2, index).  idx/d2: [n][k]; rows are
+ * padded with UINT32_MAX / FLT_MAX when n < k. */
+void oracle_ground_knn(const float* xyz, size_t n, uint32_t k, uint32_t* idx, float* d2);
+/* Normal of the k neighbours (fp64 mean and covariance in neighbour order, smallest-eigenvalue
+ * eigenvector by oracle_jacobi_eig3, flipped towards the origin) and its 10-degree elevation bin. */
+void oracle_ground_normals(const float* xyz, size_t n, const uint32_t* knn_idx, uint32_t k,
+                           float* normals /* [n][3] */, uint8_t* bins /* [n] */);
+/* GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228):
+ * T16 = T_l2g, row-major 4x4 f32 (identity when no ground is found). */
+int oracle_ground_estimate(const float* xyz, size_t n, size_t stride_floats,
+                           const oracle_ground_params* prm, float* T16, oracle_ground_info* info);
+/* T_l2g from plane coefficients (TransformPointsToGround, ground_estimator.cpp:163-194). */
+void oracle_ground_transform_from_plane(const float plane[4], float* T16);
 
 /* ---- deterministic synthetic inputs (shared definition with gloc3d_amd/synth.py) ----------- */
 uint64_t oracle_rng_key(uint64_t seed, uint64_t stream);

@@ -196,7 +196,7 @@ void oracle_nn3_grid(const float* src_xyz, size_t n_src, const float* tgt_xyz, s
 /* Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (row-major A), fixed sweep order
  * (0,1),(0,2),(1,2).  Uses only + - * / sqrt, so CPU and GPU fp64 agree bit for bit.
  * On return A's diagonal holds the eigenvalues and V's columns the eigenvectors. */
-static void jacobi_eig3(double A[9], double V[9]) {
+void oracle_jacobi_eig3(double A[9], double V[9]) {
   V[0] = 1; V[1] = 0; V[2] = 0;
   V[3] = 0; V[4] = 1; V[5] = 0;
   V[6] = 0; V[7] = 0; V[8] = 1;
@@ -249,7 +249,7 @@ void oracle_kabsch_from_cov(const double M[9], const double pbar[3], const doubl
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)
       A[3 * i + j] = (M[0 + i] * M[0 + j] + M[3 + i] * M[3 + j]) + M[6 + i] * M[6 + j];
-  jacobi_eig3(A, V);
+  oracle_jacobi_eig3(A, V);
   /* order the eigenvalues descending (stable: ties keep lower column first) */
   int o0 = 0, o1 = 1, o2 = 2;
   double l0 = A[0], l1 = A[4], l2 = A[8];

@@ -91,6 +91,12 @@ def test_command_lines(dataset):
     assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) == 1.0
     assert (d / "failed_detect_indices.txt").read_text().strip() == ""
     assert (d / "failed_registration_indices.txt").read_text().strip() == ""
+    # 4th argument: every scan ground-aligned first, poses carried back to the sensor frames
+    out = _run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
+                str(d / "desc.bin"), "x"], cwd=d)
+    assert "time cost for align to ground" in out
+    assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) == 1.0
+    assert float(re.search(r"Pos error: ([\d.eE+-]+)", out).group(1)) < 0.3
     out = _run([os.path.join(bindir, "global_registration"), str(d / "valset.txt"), str(d / "poses.txt")], cwd=d)
     errs = re.findall(r"err_pos, err_rot: ([\d.eE+-]+), ([\d.eE+-]+)", out)
     assert len(errs) == 3 * N_Q

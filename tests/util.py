@@ -118,3 +118,19 @@ def bev_crop_pad_numpy(img, out_w=768, out_h=768, pad=(255, 0, 0)):
     sx, sy, dx, dy = (w - cw) // 2, (h - ch) // 2, (out_w - cw) // 2, (out_h - ch) // 2
     dst[dy:dy + ch, dx:dx + cw, :] = img[sy:sy + ch, sx:sx + cw, None]
     return dst
+
+
+# ---- ground pre-alignment: a tilted scan with a dominant ground plane ------------------------------
+
+def ground_scene(roll_deg=3.0, pitch_deg=-2.0, n_az=400):
+    """A synthetic spinning-lidar scan (ground 1.73 m below the sensor) seen from a sensor tilted by
+    roll / pitch: returns ([n, 4] float32 x y z i, sensor height)."""
+    from gloc3d_amd import synth
+    w = synth.make_world(7)
+    pts = synth.lidar_scan(w, synth.se3(0.3, (5, 2, 0)), 7, n_az=n_az)
+    r, p = np.deg2rad(roll_deg), np.deg2rad(pitch_deg)
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    out = pts.copy()
+    out[:, :3] = (pts[:, :3].astype(np.float64) @ (Ry @ Rx).T).astype(np.float32)
+    return out, 1.73

@@ -265,6 +265,15 @@ def main():
                 for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve", "transform")}
     passes = 1 + ICP_ITERS
     pairs_eval = sum(r_.nn_stats()[0] for r_ in regs)
+    # the same kernel with nothing else on the GPU (outside the timed region): three queries, one at a time
+    serial_launch_ms = None
+    if inflight > 1 and args.mode == "throughput":
+        regs[0].profile_reset()
+        for j in range(3):
+            cands_j = [pool_ids_k[0][(j * 5 + c) % SCAN_POOL] for c in range(TOP_K)]
+            regs[0].batch_ids(q_ids_k[0][j % QUERY_POOL], np.asarray(cands_j, np.uint32), params=params)
+        ms_, n_ = regs[0].profile("nn")
+        serial_launch_ms = ms_ / max(n_, 1)
     all_pairs = float(np.mean(pairs_per_launch)) if pairs_per_launch else 0.0   # exhaustive pair count
     avg_launch_s = (nn_ms / max(nn_launches, 1)) * 1e-3
     if args.nn_mode == "exhaustive":
@@ -283,6 +292,7 @@ def main():
                 "pairs_evaluated_per_launch": eval_pairs, "pairs_exhaustive_per_launch": all_pairs,
                 "exhaustive_equivalent_tflops": FLOP_PER_PAIR * all_pairs / avg_launch_s / 1e12
                 if avg_launch_s > 0 else 0.0,
+                "launch_ms_timed_region": avg_launch_s * 1e3, "launch_ms_alone": serial_launch_ms,
                 "note": f"{FLOP_PER_PAIR} flop/pair x {eval_pairs:.3e} pairs EVALUATED per launch (rank 0; "
                         f"the exhaustive count is {all_pairs:.3e}) / {avg_launch_s*1e3:.3f} ms avg over "
                         f"{nn_launches} launches; fp32 peak (vector = MFMA) {PEAK_FP32_TFLOPS} TF"

@@ -303,13 +303,15 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
     GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)H * n_cand, s));
     const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
     {
-      // phase A: the first 256 hypotheses; phase B: the rest, skipped per candidate once the
-      // adaptive iteration count has been reached (then its blocks exit at once)
+      // phase A: the first 64 hypotheses (with ~90 % inliers the adaptive count is reached after a
+      // handful); phase B: the rest, skipped per candidate once the adaptive iteration count has been
+      // reached (then its blocks exit at once).  The split does not change the result.
       ProfScope ps(h->prof, "ransac_score", s);
-      const uint32_t HA = std::min<uint32_t>(H, 256);
+      const uint32_t HA = std::min<uint32_t>(H, prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f ? 64 : 256);
+      const uint32_t hpbA = HA <= 64 ? 64u : 256u;
       const unsigned cchunks = (n_src + SC_CHUNK - 1) / SC_CHUNK;
-      hipLaunchKernelGGL(ransac_score_kernel, dim3((HA + 255) / 256, cchunks, n_cand), dim3(256), 0, s,
-                         h->pairs.as<f32x4>(), ld, n_src, H, 0u, h->Rt.as<float>(),
+      hipLaunchKernelGGL(ransac_score_kernel, dim3((HA + hpbA - 1) / hpbA, cchunks, n_cand), dim3(256), 0, s,
+                         h->pairs.as<f32x4>(), ld, n_src, H, 0u, hpbA, h->Rt.as<float>(),
                          h->valid.as<uint32_t>(), thr2, (const CandState*)nullptr,
                          h->inliers.as<uint32_t>());
       if (H > HA) {
@@ -318,7 +320,7 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
                            0u, HA, n_src, prm->ransac_confidence, prm->min_inlier_ratio,
                            h->states.as<CandState>());
         hipLaunchKernelGGL(ransac_score_kernel, dim3((H - HA + 255) / 256, cchunks, n_cand), dim3(256),
-                           0, s, h->pairs.as<f32x4>(), ld, n_src, H, HA, h->Rt.as<float>(),
+                           0, s, h->pairs.as<f32x4>(), ld, n_src, H, HA, 256u, h->Rt.as<float>(),
                            h->valid.as<uint32_t>(), thr2, h->states.as<CandState>(),
                            h->inliers.as<uint32_t>());
         hipLaunchKernelGGL(ransac_scan_kernel<true>, dim3(n_cand), dim3(64), 0, s,
@@ -651,7 +653,7 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   GLOC_HIP(hipGetLastError());
   dim3 grid((n_hyp + 255) / 256, (unsigned)((n + SC_CHUNK - 1) / SC_CHUNK), 1);
   hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
-                     (uint32_t)n, n_hyp, 0u, h->Rt.as<float>(), h->valid.as<uint32_t>(),
+                     (uint32_t)n, n_hyp, 0u, 256u /* thread <-> hypothesis */, h->Rt.as<float>(), h->valid.as<uint32_t>(),
                      inlier_thresh * inlier_thresh, (const CandState*)nullptr,
                      h->inliers.as<uint32_t>());
   GLOC_HIP(hipGetLastError());

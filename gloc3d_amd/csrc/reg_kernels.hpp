@@ -273,7 +273,7 @@ constexpr int SC_STAGE = 256;
 
 __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restrict__ pairs,
                                                            size_t ld, uint32_t n, uint32_t n_hyp,
-                                                           uint32_t h_begin,
+                                                           uint32_t h_begin, uint32_t hyp_per_block,
                                                            const float* __restrict__ Rt,
                                                            const uint32_t* __restrict__ valid,
                                                            float thr2,
@@ -282,8 +282,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   __shared__ f32x4 sp[2 * SC_STAGE];
   const int cand = blockIdx.z;
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
-  const uint32_t h = h_begin + blockIdx.x * 256 + threadIdx.x;
-  const bool hv = h < n_hyp && valid[(size_t)cand * n_hyp + h];
+  // hyp_per_block = 256: thread <-> hypothesis.  64: four waves share 64 hypotheses, each taking a
+  // quarter of every staged tile (the first phase of the adaptive RANSAC needs few hypotheses).
+  const uint32_t sub = threadIdx.x / hyp_per_block, nsub = 256 / hyp_per_block;
+  const uint32_t h = h_begin + blockIdx.x * hyp_per_block + threadIdx.x % hyp_per_block;
+  const bool hv = h < n_hyp && h < h_begin + (blockIdx.x + 1) * hyp_per_block && valid[(size_t)cand * n_hyp + h];
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = hv ? Rt[((size_t)cand * n_hyp + h) * 12 + i] : 0.f;
@@ -301,8 +304,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
     sp[2 * threadIdx.x + 0] = pv;
     sp[2 * threadIdx.x + 1] = qv;
     __syncthreads();
+    const int t_begin = (int)(sub * (SC_STAGE / nsub)), t_end = (int)((sub + 1) * (SC_STAGE / nsub));
 #pragma unroll 4
-    for (int t = 0; t < SC_STAGE; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
       const f32x4 p = sp[2 * t], q = sp[2 * t + 1];
       float x, y, z;
       xform(T, p.x, p.y, p.z, x, y, z);

@@ -293,11 +293,13 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
                          h->corr.as<uint32_t>(), ld, h->pairs.as<f32x4>());
       GLOC_HIP(hipGetLastError());
     }
+    const uint32_t HA = std::min<uint32_t>(H, prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f ? 64 : 256);
+    GLOC_HIP(hipMemsetAsync(h->valid.p, 0, sizeof(uint32_t) * (size_t)H * n_cand, s));  // never-generated = invalid
     {
-      ProfScope ps(h->prof, "ransac_hyp", s);
-      hipLaunchKernelGGL(ransac_hyp_kernel, dim3((H + 127) / 128, n_cand), dim3(128), 0, s,
-                         h->pairs.as<f32x4>(), ld, n_src, h->cands.as<CandDesc>(), prm->seed, H,
-                         h->Rt.as<float>(), h->valid.as<uint32_t>());
+      ProfScope ps(h->prof, "ransac_hyp", s);  // phase A's hypotheses; the rest only where still needed
+      hipLaunchKernelGGL(ransac_hyp_kernel, dim3((HA + 127) / 128, n_cand), dim3(128), 0, s,
+                         h->pairs.as<f32x4>(), ld, n_src, h->cands.as<CandDesc>(), prm->seed, H, 0u, HA,
+                         (const CandState*)nullptr, h->Rt.as<float>(), h->valid.as<uint32_t>());
       GLOC_HIP(hipGetLastError());
     }
     GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)H * n_cand, s));
@@ -307,7 +309,6 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
       // handful); phase B: the rest, skipped per candidate once the adaptive iteration count has been
       // reached (then its blocks exit at once).  The split does not change the result.
       ProfScope ps(h->prof, "ransac_score", s);
-      const uint32_t HA = std::min<uint32_t>(H, prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f ? 64 : 256);
       const uint32_t hpbA = HA <= 64 ? 64u : 256u;
       const unsigned cchunks = (n_src + SC_CHUNK - 1) / SC_CHUNK;
       hipLaunchKernelGGL(ransac_score_kernel, dim3((HA + hpbA - 1) / hpbA, cchunks, n_cand), dim3(256), 0, s,
@@ -319,6 +320,9 @@ int run_batch(gloc_reg* h, const DevScan& src, const std::vector<const DevScan*>
                            h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(), h->Rt.as<float>(), H,
                            0u, HA, n_src, prm->ransac_confidence, prm->min_inlier_ratio,
                            h->states.as<CandState>());
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((H - HA + 127) / 128, n_cand), dim3(128), 0, s,
+                           h->pairs.as<f32x4>(), ld, n_src, h->cands.as<CandDesc>(), prm->seed, H, HA, H,
+                           h->states.as<CandState>(), h->Rt.as<float>(), h->valid.as<uint32_t>());
         hipLaunchKernelGGL(ransac_score_kernel, dim3((H - HA + 255) / 256, cchunks, n_cand), dim3(256),
                            0, s, h->pairs.as<f32x4>(), ld, n_src, H, HA, 256u, h->Rt.as<float>(),
                            h->valid.as<uint32_t>(), thr2, h->states.as<CandState>(),
@@ -648,8 +652,8 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   GLOC_HIP(hipMemcpyAsync(h->pairs.p, hp.data(), sizeof(float) * 8 * ld, hipMemcpyHostToDevice, s));
   GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)n_hyp, s));
   hipLaunchKernelGGL(ransac_hyp_kernel, dim3((n_hyp + 127) / 128, 1), dim3(128), 0, s,
-                     h->pairs.as<f32x4>(), ld, (uint32_t)n, h->cands.as<CandDesc>(), seed, n_hyp,
-                     h->Rt.as<float>(), h->valid.as<uint32_t>());
+                     h->pairs.as<f32x4>(), ld, (uint32_t)n, h->cands.as<CandDesc>(), seed, n_hyp, 0u, n_hyp,
+                     (const CandState*)nullptr, h->Rt.as<float>(), h->valid.as<uint32_t>());
   GLOC_HIP(hipGetLastError());
   dim3 grid((n_hyp + 255) / 256, (unsigned)((n + SC_CHUNK - 1) / SC_CHUNK), 1);
   hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,

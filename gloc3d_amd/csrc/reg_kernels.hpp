@@ -212,13 +212,18 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
 }
 
 // K5a.  One thread per (candidate, hypothesis).  pairs: [cand][ld][2] float4.
+// Hypotheses [h_begin, h_end) of every candidate; with `states`, candidates whose adaptive iteration
+// count has already been reached are skipped (their later hypotheses are never looked at).
 __global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, uint32_t n,
                                   const CandDesc* __restrict__ cands, uint64_t seed,
-                                  uint32_t n_hyp, float* __restrict__ Rt /* [cand][n_hyp][12] */,
+                                  uint32_t n_hyp, uint32_t h_begin, uint32_t h_end,
+                                  const CandState* __restrict__ states,
+                                  float* __restrict__ Rt /* [cand][n_hyp][12] */,
                                   uint32_t* __restrict__ valid) {
   const int cand = blockIdx.y;
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= n_hyp) return;
+  const uint32_t h = h_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= h_end) return;
+  if (states && states[cand].ransac_done) return;
   const size_t o = (size_t)cand * n_hyp + h;
   valid[o] = 0;
   if (n < 3) return;

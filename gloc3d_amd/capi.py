@@ -58,6 +58,7 @@ class BevInfo(C.Structure):
 
 
 BEV_U8_HWC3, BEV_F32_CHW = 0, 1
+GROUND_OPT_KNN_EXHAUSTIVE = 1
 
 
 class GroundParams(C.Structure):
@@ -145,6 +146,7 @@ _PROTOS = [
     ("gloc_ground_create", _i, [_i, C.POINTER(_vp)]),
     ("gloc_ground_destroy", _i, [_vp]),
     ("gloc_ground_set_stream", _i, [_vp, _vp]),
+    ("gloc_ground_set_option", _i, [_vp, _i, C.c_int64]),
     ("gloc_ground_estimate", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     ("gloc_ground_estimate_device", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     ("gloc_ground_knn", _i, [_vp, _vp, _sz, _u32, _vp, _vp]),
@@ -599,6 +601,9 @@ class GroundEstimator:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, option, value):
+        check(lib().gloc_ground_set_option(self._h, option, value))
 
     def estimate(self, points, params=None, want_cloud=False):
         """points [n, 3 or more] float32 -> (T_l2g 4x4, info dict[, transformed cloud])."""

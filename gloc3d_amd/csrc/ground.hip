@@ -21,6 +21,8 @@ struct gloc_ground {
   DevBuf stage_in, stage_out;            // host-pointer API staging
   DevBuf flag, sel, count, cub_tmp;      // stream compaction
   DevBuf near, knn_idx, knn_d2, knn_pidx, knn_pd2, bins, hist, normals;
+  DevBuf skeys, svals, skeys2, sperm, spts, cbox_lo, cbox_hi;  // culled 10-NN: Hilbert-sorted copy + chunk boxes
+  int knn_exhaustive = 0;                // 1: the exhaustive form (kept for comparison)
   DevBuf gpts, planes, valid, inliers, T12;
   Profiler prof;
 };
@@ -115,10 +117,40 @@ int select_flagged(gloc_ground* h, uint32_t n, uint32_t* h_count) {
   return GLOC_OK;
 }
 
-int knn_device(gloc_ground* h, const f32x4* d_pts, uint32_t m, uint32_t k) {
+// key_range: every coordinate of the cloud lies in [-key_range, key_range] (the range filter's radius);
+// points outside are clamped into the outermost cells, which only loosens the order, not the result.
+int knn_device(gloc_ground* h, const f32x4* d_pts, uint32_t m, uint32_t k, float key_range) {
   hipStream_t s = h->stream;
   GLOC_TRY(h->knn_idx.ensure(sizeof(uint32_t) * (size_t)m * k, s));
   GLOC_TRY(h->knn_d2.ensure(sizeof(float) * (size_t)m * k, s));
+  if (!h->knn_exhaustive && m > 4 * KCH) {
+    ProfScope ps(h->prof, "ground_knn", s);
+    GLOC_TRY(h->skeys.ensure(sizeof(uint32_t) * m, s));
+    GLOC_TRY(h->svals.ensure(sizeof(uint32_t) * m, s));
+    GLOC_TRY(h->skeys2.ensure(sizeof(uint32_t) * m, s));
+    GLOC_TRY(h->sperm.ensure(sizeof(uint32_t) * m, s));
+    GLOC_TRY(h->spts.ensure(sizeof(f32x4) * m, s));
+    const uint32_t nch = (m + KCH - 1) / KCH;
+    GLOC_TRY(h->cbox_lo.ensure(sizeof(f32x4) * nch, s));
+    GLOC_TRY(h->cbox_hi.ensure(sizeof(f32x4) * nch, s));
+    hipLaunchKernelGGL(hilbert_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, m, -key_range,
+                       1023.0f / (2.0f * key_range), h->skeys.as<uint32_t>(), h->svals.as<uint32_t>());
+    size_t tmp = 0;
+    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(),
+                                                h->svals.as<uint32_t>(), h->sperm.as<uint32_t>(), (int)m, 0, 30, s));
+    GLOC_TRY(h->cub_tmp.ensure(std::max<size_t>(tmp, 16), s));
+    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.p, tmp, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(),
+                                                h->svals.as<uint32_t>(), h->sperm.as<uint32_t>(), (int)m, 0, 30, s));
+    hipLaunchKernelGGL(gather_sorted_f4_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, h->sperm.as<uint32_t>(),
+                       m, h->spts.as<f32x4>());
+    hipLaunchKernelGGL(kchunk_boxes_kernel, dim3(nch), dim3(64), 0, s, h->spts.as<f32x4>(), m,
+                       h->cbox_lo.as<f32x4>(), h->cbox_hi.as<f32x4>());
+    hipLaunchKernelGGL(knn_culled_kernel, dim3((nch + 3) / 4), dim3(256), 0, s, h->spts.as<f32x4>(), m,
+                       h->cbox_lo.as<f32x4>(), h->cbox_hi.as<f32x4>(), nch, (int)k, h->knn_idx.as<uint32_t>(),
+                       h->knn_d2.as<float>());
+    GLOC_HIP(hipGetLastError());
+    return GLOC_OK;
+  }
   // enough target slices for ~8 waves per SIMD (a wave of this kernel is latency-bound), each a whole
   // number of LDS tiles
   const uint32_t src_blocks = (m + KNN_BLOCK - 1) / KNN_BLOCK;
@@ -202,7 +234,7 @@ int estimate_device(gloc_ground* h, const float* d_xyz, size_t n, size_t stride,
   hipLaunchKernelGGL(gather_points_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_xyz, (int)stride,
                      h->sel.as<uint32_t>(), m, h->near.as<f32x4>());
   // G2..G4
-  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, p->knn));
+  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, p->knn, std::sqrt(p->near_range2)));
   GLOC_TRY(normals_device(h, h->near.as<f32x4>(), m, p->knn, false));
   GLOC_HIP(hipMemcpyAsync(local.hist, h->hist.p, sizeof(uint32_t) * 18, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipStreamSynchronize(s));
@@ -303,7 +335,8 @@ int gloc_ground_destroy(gloc_ground* h) {
   (void)hipStreamSynchronize(h->stream);
   h->prof.destroy();
   for (DevBuf* b : {&h->stage_in, &h->stage_out, &h->flag, &h->sel, &h->count, &h->cub_tmp, &h->near, &h->knn_idx,
-                    &h->knn_d2, &h->knn_pidx, &h->knn_pd2, &h->bins, &h->hist, &h->normals, &h->gpts, &h->planes, &h->valid, &h->inliers,
+                    &h->knn_d2, &h->knn_pidx, &h->knn_pd2, &h->skeys, &h->svals, &h->skeys2, &h->sperm, &h->spts,
+                    &h->cbox_lo, &h->cbox_hi, &h->bins, &h->hist, &h->normals, &h->gpts, &h->planes, &h->valid, &h->inliers,
                     &h->T12})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -358,7 +391,10 @@ int gloc_ground_knn(gloc_ground* h, const float* xyz, size_t n, uint32_t k, uint
   for (uint32_t i = 0; i < m; ++i) pts[i] = f32x4{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f};
   GLOC_TRY(h->near.ensure(sizeof(f32x4) * m, s));
   GLOC_HIP(hipMemcpyAsync(h->near.p, pts.data(), sizeof(f32x4) * m, hipMemcpyHostToDevice, s));
-  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, k));
+  float key_range = 1.f;
+  for (size_t i = 0; i < 3 * (size_t)m; ++i)
+    if (std::isfinite(xyz[i])) key_range = std::max(key_range, std::fabs(xyz[i]));
+  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, k, key_range));
   GLOC_HIP(hipMemcpyAsync(out_idx, h->knn_idx.p, sizeof(uint32_t) * (size_t)m * k, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipMemcpyAsync(out_d2, h->knn_d2.p, sizeof(float) * (size_t)m * k, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipStreamSynchronize(s));
@@ -376,7 +412,10 @@ int gloc_ground_normals(gloc_ground* h, const float* xyz, size_t n, uint32_t k, 
   for (uint32_t i = 0; i < m; ++i) pts[i] = f32x4{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f};
   GLOC_TRY(h->near.ensure(sizeof(f32x4) * m, s));
   GLOC_HIP(hipMemcpyAsync(h->near.p, pts.data(), sizeof(f32x4) * m, hipMemcpyHostToDevice, s));
-  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, k));
+  float key_range = 1.f;
+  for (size_t i = 0; i < 3 * (size_t)m; ++i)
+    if (std::isfinite(xyz[i])) key_range = std::max(key_range, std::fabs(xyz[i]));
+  GLOC_TRY(knn_device(h, h->near.as<f32x4>(), m, k, key_range));
   GLOC_TRY(normals_device(h, h->near.as<f32x4>(), m, k, true));
   GLOC_HIP(hipMemcpyAsync(out_normals, h->normals.p, sizeof(float) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipMemcpyAsync(out_bins, h->bins.p, m, hipMemcpyDeviceToHost, s));
@@ -390,6 +429,16 @@ int gloc_ground_transform_from_plane(const float* plane4, float* T16) {
   GLOC_REQUIRE(l2 > 0.0, GLOC_ERR_INVALID, "zero plane normal");
   transform_from_plane(plane4, T16);
   return GLOC_OK;
+}
+
+int gloc_ground_set_option(gloc_ground* h, int option, int64_t value) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "handle is NULL");
+  if (option == GLOC_GROUND_OPT_KNN_EXHAUSTIVE) {
+    h->knn_exhaustive = value != 0;
+    return GLOC_OK;
+  }
+  set_err("unknown option %d", option);
+  return GLOC_ERR_INVALID;
 }
 
 int gloc_ground_set_profile(gloc_ground* h, int enable) {

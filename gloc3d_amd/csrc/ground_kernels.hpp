@@ -149,6 +149,170 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint32_t* __restri
   }
 }
 
+// ---- culled form of G2 ---------------------------------------------------------------------------
+// The kept points are Hilbert-sorted and cut into chunks of 64 with bounding boxes (the machinery of
+// the registration's culled 1-NN).  A wave takes one chunk as its 64 sources; it fills every lane's
+// list from the own chunk, then sweeps the chunk boxes 64 per ballot against (own box, the wave's
+// largest k-th distance) and evaluates only chunks some lane can still improve on.  Same lists as
+// knn_self_kernel: ascending (d2, index) with the index of the UNSORTED cloud as the tie-break, which
+// the insertion compares explicitly (targets no longer arrive in index order).
+constexpr int KCH = 64;  // points per chunk
+
+__global__ __launch_bounds__(256) void hilbert_keys_kernel(const f32x4* __restrict__ pts, uint32_t m, float origin,
+                                                            float inv_cell, uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const f32x4 p = pts[i];
+  keys[i] = reg::morton_key(p.x, p.y, p.z, origin, origin, origin, inv_cell);
+  vals[i] = i;
+}
+
+// spts[s] = (x, y, z, bits(index in the unsorted cloud)) of the s-th point in key order
+__global__ __launch_bounds__(256) void gather_sorted_f4_kernel(const f32x4* __restrict__ pts,
+                                                                const uint32_t* __restrict__ perm, uint32_t m,
+                                                                f32x4* __restrict__ spts) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  const uint32_t o = perm[s];
+  const f32x4 p = pts[o];
+  spts[s] = f32x4{p.x, p.y, p.z, __uint_as_float(o)};
+}
+
+// one wave per chunk of KCH sorted points
+__global__ __launch_bounds__(64) void kchunk_boxes_kernel(const f32x4* __restrict__ spts, uint32_t m,
+                                                          f32x4* __restrict__ lo, f32x4* __restrict__ hi) {
+  const uint32_t j = blockIdx.x * KCH + threadIdx.x;
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  if (j < m) {
+    const f32x4 p = spts[j];
+    mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+    }
+  if (threadIdx.x == 0) {
+    lo[blockIdx.x] = f32x4{mn[0], mn[1], mn[2], 0.f};
+    hi[blockIdx.x] = f32x4{mx[0], mx[1], mx[2], 0.f};
+  }
+}
+
+// 4 independent waves per work-group, one chunk of sources each.
+__global__ __launch_bounds__(256) void knn_culled_kernel(const f32x4* __restrict__ spts, uint32_t m,
+                                                          const f32x4* __restrict__ box_lo,
+                                                          const f32x4* __restrict__ box_hi, uint32_t nchunks, int k,
+                                                          uint32_t* __restrict__ idx, float* __restrict__ d2) {
+  __shared__ f32x4 stage_all[4][KCH];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4* stage = stage_all[w];
+  const uint32_t own = blockIdx.x * 4 + w;
+  if (own >= nchunks) return;  // whole wave idle; no work-group barrier below
+  const uint32_t si = own * KCH + lane;
+  const bool valid = si < m;
+  const f32x4 p = spts[valid ? si : m - 1];
+  float bd[KMAX];
+  uint32_t bi[KMAX];
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) { bd[s] = FLT_MAX; bi[s] = 0xFFFFFFFFu; }
+  float worst = FLT_MAX;
+  uint32_t worst_i = 0xFFFFFFFFu;  // (bd, bi)[k - 1]
+  auto insert = [&](float d, uint32_t j) {
+    float cd = d;
+    uint32_t ci = j;
+    bool shifting = false;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+      if (s < k) {
+        shifting = shifting || cd < bd[s] || (cd == bd[s] && ci < bi[s]);
+        if (shifting) {
+          const float td = bd[s]; const uint32_t ti = bi[s];
+          bd[s] = cd; bi[s] = ci;
+          cd = td; ci = ti;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s == k - 1) { worst = bd[s]; worst_i = bi[s]; }
+  };
+  // evaluate one staged chunk: all lanes against its points (wave-uniform LDS reads)
+  auto eval_chunk = [&](uint32_t c) {
+    const uint32_t j = c * KCH + lane;
+    f32x4 v = {NN_FAR_, NN_FAR_, NN_FAR_, __uint_as_float(0xFFFFFFFFu)};
+    if (j < m) v = spts[j];
+    __builtin_amdgcn_wave_barrier();  // earlier reads of the slice are done
+    stage[lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t lim = (m - c * KCH) < (uint32_t)KCH ? (m - c * KCH) : (uint32_t)KCH;
+    for (uint32_t t = 0; t < (uint32_t)KCH; t += 8) {
+      float d[8];
+      uint32_t o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 q = stage[t + u];
+        d[u] = reg::dist2(p.x, p.y, p.z, q.x, q.y, q.z);
+        o[u] = __float_as_uint(q.w);
+      }
+      const float dm = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+      if (dm <= worst) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (t + u < lim && (d[u] < worst || (d[u] == worst && o[u] < worst_i))) insert(d[u], o[u]);
+      }
+    }
+  };
+  eval_chunk(own);
+  auto wave_max = [&]() {
+    float mx = valid ? worst : -1.f;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    return mx;
+  };
+  float wmax = wave_max();
+  const f32x4 olo = box_lo[own], ohi = box_hi[own];
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += 64) {
+    const uint32_t cl = c0 + lane;
+    float lbw = FLT_MAX;
+    f32x4 blo = {0.f, 0.f, 0.f, 0.f}, bhi = {0.f, 0.f, 0.f, 0.f};
+    if (cl < nchunks && cl != own) {
+      blo = box_lo[cl]; bhi = box_hi[cl];
+      const float ex = fmaxf(fmaxf(blo.x - ohi.x, olo.x - bhi.x), 0.f);
+      const float ey = fmaxf(fmaxf(blo.y - ohi.y, olo.y - bhi.y), 0.f);
+      const float ez = fmaxf(fmaxf(blo.z - ohi.z, olo.z - bhi.z), 0.f);
+      lbw = ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
+    }
+    unsigned long long mask = __ballot(lbw <= wmax);
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
+      f32x4 lo, hi;
+      lo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.x), b));
+      lo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.y), b));
+      lo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.z), b));
+      hi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.x), b));
+      hi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.y), b));
+      hi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.z), b));
+      const bool need = valid && reg::box_lb(p.x, p.y, p.z, lo, hi) <= worst;  // <=: equal distances may win on the index
+      if (!__any(need)) continue;
+      eval_chunk(c0 + b);
+      wmax = wave_max();
+    }
+  }
+  if (valid) {
+    const uint32_t orig = __float_as_uint(p.w);
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k) {
+        idx[(size_t)orig * k + s] = bi[s];
+        d2[(size_t)orig * k + s] = bd[s];
+      }
+  }
+}
+
 // sin of the bin edges -80 .. +80 degrees: bin b holds elevations [10b - 90, 10b - 80) (oracle: kSinEdge)
 __device__ __constant__ double kSinEdge[17] = {
     -0.98480775301220805937, -0.93969262078590838405, -0.86602540378443864676, -0.76604444311897803520,

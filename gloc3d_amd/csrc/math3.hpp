@@ -75,5 +75,56 @@ __device__ __forceinline__ uint32_t mulhi_idx(uint64_t u, uint32_t n) {
 }
 
 
+// ---- spatial keys and box bounds (shared by the culled 1-NN and the ground 10-NN) ----------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+  v &= 0x3FF;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+__device__ __forceinline__ uint32_t morton_key(float x, float y, float z, float ox, float oy,
+                                               float oz, float inv_cell) {
+  const float fx = fminf(fmaxf((x - ox) * inv_cell, 0.f), 1023.f);
+  const float fy = fminf(fmaxf((y - oy) * inv_cell, 0.f), 1023.f);
+  const float fz = fminf(fmaxf((z - oz) * inv_cell, 0.f), 1023.f);
+  // Hilbert curve (Skilling's transpose form) rather than Morton: no long jumps between
+  // consecutive cells, so the 128-point chunks and 16-point sub-blocks get tighter boxes.
+  uint32_t X[3] = {(uint32_t)fx, (uint32_t)fy, (uint32_t)fz};
+  const uint32_t M = 1u << 9;
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+}
+
+
+// squared distance from a point to a box, scaled down by 2^-20 so that fp32 rounding can never
+// push it above the (fp32) distance of any point inside the box
+__device__ __forceinline__ float box_lb(float px, float py, float pz, const f32x4& lo,
+                                        const f32x4& hi) {
+  const float ex = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.f);
+  const float ey = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.f);
+  const float ez = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.f);
+  return ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
+}
+
 }  // namespace reg
 }  // namespace gloc

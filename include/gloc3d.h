@@ -331,6 +331,8 @@ int gloc_ground_default_params(gloc_ground_params* p);
 int gloc_ground_create(int device, gloc_ground** out);
 int gloc_ground_destroy(gloc_ground* h);
 int gloc_ground_set_stream(gloc_ground* h, void* hip_stream);
+enum { GLOC_GROUND_OPT_KNN_EXHAUSTIVE = 1 /* 1: every pair instead of the chunk-culled search; same lists */ };
+int gloc_ground_set_option(gloc_ground* h, int option, int64_t value);
 /* T16: T_l2g, row-major 4x4 f32 (host).  out_xyz (may be NULL): the cloud transformed by T_l2g, same
  * layout as the input (extra channels copied) -- cloud_out of the reference. */
 int gloc_ground_estimate(gloc_ground* h, const float* xyz, size_t n, size_t stride_floats,

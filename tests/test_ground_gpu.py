@@ -7,14 +7,16 @@ from util import bits, ground_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def est(capi):
+@pytest.fixture(scope="module", params=["culled", "exhaustive"])
+def est(capi, request):
+    """Every test runs on both forms of the 10-NN search: the lists must not differ."""
     g = capi.GroundEstimator()
+    g.set_option(capi.GROUND_OPT_KNN_EXHAUSTIVE, 1 if request.param == "exhaustive" else 0)
     yield g
     g.close()
 
 
-@pytest.mark.parametrize("n,k", [(700, 10), (1, 3), (5, 10), (129, 16), (4000, 10), (257, 3)])
+@pytest.mark.parametrize("n,k", [(700, 10), (1, 3), (5, 10), (129, 16), (4000, 10), (257, 3), (30000, 10)])
 def test_knn_bit_exact(est, oracle_mod, n, k):
     rng = np.random.default_rng(n * 31 + k)
     p = rng.uniform(-5, 5, (n, 3)).astype(np.float32)

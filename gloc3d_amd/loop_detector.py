@@ -28,6 +28,7 @@ class RpyPCLoopDetector:
         self.high_resolution_max_range_ = 100.0  # loop_detector.h:115
         self.high_resolution_ = 0.2              # :116
         self._bev = None                         # created on first use
+        self._ground = None
         self._device = device
 
     def close(self):
@@ -35,6 +36,8 @@ class RpyPCLoopDetector:
         self._reg.close()
         if self._bev is not None:
             self._bev.close()
+        if self._ground is not None:
+            self._ground.close()
 
     def _projector(self):
         if self._bev is None:
@@ -44,6 +47,15 @@ class RpyPCLoopDetector:
     def _bev_params(self, **over):
         return capi.default_bev_params(resolution=self.high_resolution_,
                                        max_range=self.high_resolution_max_range_, **over)
+
+    def align_to_ground(self, cloud):
+        """GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228), the
+        pre-step of the evaluator's 4th-argument mode (global_localization.cpp:431-436, 495-499):
+        returns (T_l2g 4x4, ground-aligned cloud); T is the identity when no ground is found."""
+        if self._ground is None:
+            self._ground = capi.GroundEstimator(self._device)
+        T, _, moved = self._ground.estimate(cloud, want_cloud=True)
+        return T, moved
 
     def get_projected_grid(self, q_pc):
         """loop_detector.cpp:122-135: (occupancy image [H,W] u8, xy_res = (ox, oy, resolution))."""

@@ -95,3 +95,18 @@ def test_device_entry_point(est, capi, oracle_mod):
     assert info["inliers"] == oinfo["inliers"] and np.abs(T - oT).max() < 1e-6
     want = (cloud[:, :3].astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3]).astype(np.float32)
     assert np.abs(d_out.cpu().numpy()[:, :3] - want).max() < 1e-4
+
+
+def test_loop_detector_ground_alignment(capi, oracle_mod):
+    from gloc3d_amd.loop_detector import RpyPCLoopDetector
+    det = RpyPCLoopDetector(k_dim=16)
+    try:
+        cloud, height = ground_scene(3.0, -2.0, n_az=300)
+        T, moved = det.align_to_ground(cloud)
+        oT, _ = oracle_mod.ground_estimate(cloud)
+        assert np.abs(T - oT).max() < 1e-6 and moved.shape == cloud.shape
+        near = moved[np.einsum("ij,ij->i", cloud[:, :3], cloud[:, :3]) < 400]
+        floor = near[np.abs(near[:, 2]) < 0.3]
+        assert floor.shape[0] > 0.5 * near.shape[0] and abs(np.median(floor[:, 2])) < 0.03
+    finally:
+        det.close()

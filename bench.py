@@ -65,7 +65,7 @@ def build_scans(n_pool, n_query):
     return pool, qs
 
 
-def cpu_baseline(pool, qscans, n_places):
+def cpu_baseline(pool, qscans, n_places, gpu_check=None):
     """The CPU oracle on this host, 1 thread (the reference's kNN and registration are
     single-threaded): kNN of one query + full registration of ONE of its 20 candidates,
     extrapolated to 20 candidates."""
@@ -78,10 +78,17 @@ def cpu_baseline(pool, qscans, n_places):
     oracle.knn_search(db, q, TOP_K)
     t_knn = time.time() - t0
     t0 = time.time()
-    oracle.reg_one(qscans[0], pool[3], cand_id=0, ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
+    o = oracle.reg_one(qscans[0], pool[3], cand_id=0, ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS)
     t_cand = time.time() - t0
     per_query = t_knn + TOP_K * t_cand
     extra = {}
+    if gpu_check is not None:
+        # the oracle as the checker: the same full-size registration through the HIP path
+        g = gpu_check(qscans[0], pool[3])
+        extra["full_size_parity"] = {"pose_max_abs_diff": float(np.abs(g["T"][0] - o["T"]).max()),
+                                     "inliers_equal": bool(g["inliers"][0] == o["inliers"]),
+                                     "ok_equal": bool(g["ok"][0] == o["ok"]),
+                                     "rmse_abs_diff": float(abs(g["rmse"][0] - o["rmse"]))}
     if oracle.have_ref():
         # the same nearest-neighbour pass on the REFERENCE's vendored nanoflann kd-tree (oracle/_ref),
         # and what the query would cost with it in place of the oracle's grid search
@@ -92,8 +99,8 @@ def cpu_baseline(pool, qscans, n_places):
         oracle.nn3(qscans[0], pool[3], grid=True)
         t_port = time.time() - t0
         passes = 1 + ICP_ITERS
-        extra = {"nn_pass_s_port_grid": t_port, "nn_pass_s_reference_kdtree": t_ref,
-                 "value_with_reference_nn": 1.0 / (t_knn + TOP_K * max(t_cand - passes * (t_port - t_ref), 0.0))}
+        extra.update({"nn_pass_s_port_grid": t_port, "nn_pass_s_reference_kdtree": t_ref,
+                      "value_with_reference_nn": 1.0 / (t_knn + TOP_K * max(t_cand - passes * (t_port - t_ref), 0.0))})
     return {**extra, "value": 1.0 / per_query, "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": f"1 query: kNN over {n_places}x{DIM} ({t_knn*1e3:.0f} ms) + RANSAC{RANSAC_ITERS}"
                       f"+ICP{ICP_ITERS} registration of 1 of its {TOP_K} candidates "
@@ -325,7 +332,9 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU oracle (bounded sample, ~30 s) ...")
-        out["cpu_baseline"] = cpu_baseline(pool, qscans, n_places)
+        out["cpu_baseline"] = cpu_baseline(
+            pool, qscans, n_places,
+            gpu_check=lambda q_, c_: regs[0].batch(q_, [c_], params=params))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -114,8 +114,8 @@ def test_ransac_hypotheses_bit_exact(reg, oracle_mod, scans):
 
 @pytest.mark.parametrize("conf", [0.99, 0.0, 0.999999])
 def test_batch_matches_oracle(reg, capi, oracle_mod, scans, conf):
-    """conf 0.99: adaptive stop inside the first 256 hypotheses; 0: all 500 scored; 0.999999: the
-    stop lands in the second phase."""
+    """conf 0.99: adaptive stop inside the first phase (64 hypotheses); 0: all 500 scored; 0.999999:
+    the stop lands in the second phase."""
     q = np.ascontiguousarray(scans["B"][::16])
     cands = [np.ascontiguousarray(scans["A"][::4]), np.ascontiguousarray(scans["A"][1::5]),
              np.ascontiguousarray(scans["C"][::4])]

@@ -83,6 +83,9 @@ def _run(cmd, cwd):
 
 def test_command_lines(dataset):
     bindir = os.path.join(ROOT, "gloc3d_amd", "bin")
+    if not os.path.exists(os.path.join(bindir, "global_localization")):
+        from gloc3d_amd import build as b     # host-only link step against the in-tree libgloc3d.so
+        b.build_cli()
     d = dataset["dir"]
     out = _run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
                 str(d / "desc.bin")], cwd=d)

@@ -16,8 +16,9 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
              5: "GLOC_ERR_STATE"}
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
-REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_HEAVY_PERMILLE = 1, 2, 3, 4
-REG_NN_CULLED, REG_NN_EXHAUSTIVE, REG_NN_CULLED_BROADCAST = 0, 1, 2
+REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE = 1, 2, 3
+REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
+NO_SCAN = 0xFFFFFFFF
 SIZE_MAX = C.c_size_t(-1).value
 
 
@@ -111,9 +112,24 @@ _PROTOS = [
     ("gloc_reg_set_stream", _i, [_vp, _vp]),
     ("gloc_reg_synchronize", _i, [_vp]),
     ("gloc_reg_set_option", _i, [_vp, _i, C.c_int64]),
+    ("gloc_scan_store_create", _i, [_i, C.POINTER(_vp)]),
+    ("gloc_scan_store_destroy", _i, [_vp]),
+    ("gloc_scan_store_add", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
+    ("gloc_scan_store_add_device", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
+    ("gloc_scan_store_add_variant", _i, [_vp, _u32, _vp, C.c_float, _u64, C.POINTER(_u32)]),
+    ("gloc_scan_store_release", _i, [_vp, _u32]),
+    ("gloc_scan_store_clear", _i, [_vp]),
+    ("gloc_scan_store_count", _i, [_vp, C.POINTER(_sz)]),
+    ("gloc_scan_store_bytes", _i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("gloc_scan_store_points", _i, [_vp, _u32, C.POINTER(_sz)]),
+    ("gloc_scan_store_download", _i, [_vp, _u32, _vp, _sz]),
+    ("gloc_reg_attach_store", _i, [_vp, _vp]),
     ("gloc_reg_scan_upload", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
+    ("gloc_reg_scan_release", _i, [_vp, _u32]),
     ("gloc_reg_scan_count", _i, [_vp, C.POINTER(_sz)]),
     ("gloc_reg_scan_clear", _i, [_vp]),
+    ("gloc_reg_batch_multi", _i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
+                                  _vp]),
     ("gloc_reg_batch", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp,
                             C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
     ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
@@ -322,18 +338,113 @@ def default_reg_params(**over):
     return p
 
 
-class Registrar:
-    """Batched candidate registration (RANSAC-SVD + ICP) with a resident scan store."""
+class ScanStore:
+    """Resident scans + their search index, shared by any number of Registrars."""
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
         self.device = device
+        check(lib().gloc_scan_store_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            check(lib().gloc_scan_store_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gloc_scan_store_destroy(self._h)
+        except Exception:
+            pass
+
+    def add(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        assert pts.ndim == 2 and 3 <= pts.shape[1] <= 16
+        sid = C.c_uint32()
+        check(lib().gloc_scan_store_add(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1], C.byref(sid)))
+        return sid.value
+
+    def add_device(self, dev_ptr, n, stride_floats=3):
+        sid = C.c_uint32()
+        check(lib().gloc_scan_store_add_device(self._h, C.c_void_p(dev_ptr), n, stride_floats, C.byref(sid)))
+        return sid.value
+
+    def add_variant(self, base_id, T=None, noise_sigma=0.0, seed=0):
+        Tp = None if T is None else np.ascontiguousarray(T, np.float32).reshape(16)
+        sid = C.c_uint32()
+        check(lib().gloc_scan_store_add_variant(self._h, int(base_id), None if Tp is None else _np_ptr(Tp),
+                                                float(noise_sigma), int(seed), C.byref(sid)))
+        return sid.value
+
+    def release(self, scan_id):
+        check(lib().gloc_scan_store_release(self._h, int(scan_id)))
+
+    def clear(self):
+        check(lib().gloc_scan_store_clear(self._h))
+
+    def __len__(self):
+        n = C.c_size_t()
+        check(lib().gloc_scan_store_count(self._h, C.byref(n)))
+        return n.value
+
+    def bytes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        check(lib().gloc_scan_store_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def points(self, scan_id):
+        n = C.c_size_t()
+        check(lib().gloc_scan_store_points(self._h, int(scan_id), C.byref(n)))
+        return n.value
+
+    def download(self, scan_id):
+        n = self.points(scan_id)
+        out = np.empty((n, 3), np.float32)
+        check(lib().gloc_scan_store_download(self._h, int(scan_id), _np_ptr(out), n))
+        return out
+
+
+class Registrar:
+    """Batched candidate registration (RANSAC-SVD + ICP) over a resident scan store (its own, or a
+    shared ScanStore passed in / attached later)."""
+
+    def __init__(self, device=0, store=None):
+        self._h = C.c_void_p()
+        self.device = device
+        self._store = None
         check(lib().gloc_reg_create(device, C.byref(self._h)))
+        if store is not None:
+            self.attach_store(store)
 
     def close(self):
         if self._h:
             lib().gloc_reg_destroy(self._h)
             self._h = C.c_void_p()
+            self._store = None
+
+    def attach_store(self, store):
+        check(lib().gloc_reg_attach_store(self._h, store._h if store is not None else None))
+        self._store = store  # keeps the store alive as long as this handle uses it
+
+    def scan_release(self, scan_id):
+        check(lib().gloc_reg_scan_release(self._h, int(scan_id)))
+
+    def batch_multi(self, q_ids, cand_ids, init_T=None, params=None, stream_ids=None):
+        """q_ids [Q]; cand_ids [Q, n] (NO_SCAN = no candidate).  Returns arrays with leading [Q, n]."""
+        q = np.ascontiguousarray(q_ids, np.uint32).reshape(-1)
+        ids = np.ascontiguousarray(cand_ids, np.uint32).reshape(q.shape[0], -1)
+        Q, n = ids.shape
+        prm = params or default_reg_params()
+        it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(Q * n, 16)
+        T, rmse, inl, ok = self._outs(Q * n)
+        sid = None if stream_ids is None else np.ascontiguousarray(stream_ids, np.uint32).reshape(Q * n)
+        check(lib().gloc_reg_batch_multi(self._h, Q, _np_ptr(q), _np_ptr(ids), n,
+                                         None if sid is None else _np_ptr(sid),
+                                         None if it is None else _np_ptr(it), C.byref(prm),
+                                         _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
+        return dict(T=T.reshape(Q, n, 4, 4), rmse=rmse.reshape(Q, n), inliers=inl.reshape(Q, n),
+                    ok=ok.astype(bool).reshape(Q, n))
 
     def __del__(self):
         try:
@@ -352,7 +463,7 @@ class Registrar:
 
     def scan_upload(self, pts):
         pts = np.ascontiguousarray(pts, np.float32)
-        assert pts.ndim == 2 and pts.shape[1] in (3, 4)
+        assert pts.ndim == 2 and 3 <= pts.shape[1] <= 16
         sid = C.c_uint32()
         check(lib().gloc_reg_scan_upload(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1],
                                          C.byref(sid)))

@@ -86,9 +86,23 @@ class RpyPCLoopDetector {
             Mat4& pose_in_db, std::vector<Mat4>* all_poses = nullptr, std::vector<int>* all_ok = nullptr,
             const std::vector<Mat4>* init_guess = nullptr) {
     uint32_t qid = 0;
-    check(gloc_reg_scan_upload(reg_, q_scan_xyzi, n_pts, 4, &qid));  // kept until clear_queries()
-    query_scan_ids_.push_back(qid);
-    return match_ids(qid, db_indices, pose_in_db, all_poses, all_ok, init_guess);
+    check(gloc_reg_scan_upload(reg_, q_scan_xyzi, n_pts, 4, &qid));
+    int r;
+    try {
+      r = match_ids(qid, db_indices, pose_in_db, all_poses, all_ok, init_guess);
+    } catch (...) {
+      gloc_reg_scan_release(reg_, qid);
+      throw;
+    }
+    check(gloc_reg_scan_release(reg_, qid));  // the query scan is transient: HBM stays flat over a run
+    return r;
+  }
+
+  // Number of scans resident in HBM (the database's; query scans are released after match()).
+  size_t resident_scans() const {
+    size_t n = 0;
+    gloc_reg_scan_count(reg_, &n);
+    return n;
   }
 
   int match_ids(uint32_t q_scan_id, const std::vector<size_t>& db_indices, Mat4& pose_in_db,
@@ -190,7 +204,7 @@ class RpyPCLoopDetector {
   gloc_bev* bev_ = nullptr;
   int device_ = 0;
   gloc_reg_params reg_params_{};
-  std::vector<uint32_t> db_scan_ids_, query_scan_ids_;
+  std::vector<uint32_t> db_scan_ids_;
 };
 
 }  // namespace gloc_host

@@ -1,0 +1,442 @@
+// nn_compact.hpp -- exact 1-NN with spatial culling and compacted evaluation (K4, default mode).
+//
+// Same result, bit for bit, as the exhaustive nn_kernel (and the oracle): the distance of every
+// evaluated pair is the un-fused fp32 ((dx dx + dy dy) + dz dz), ties go to the smallest ORIGINAL
+// target index.  What changes is which pairs are evaluated:
+//   * every scan is Hilbert-sorted once (scan_store.hip) and cut into chunks of 128 points, sub-blocks
+//     of 16 and super-chunks of 64 chunks, each with an axis-aligned bounding box;
+//   * a wave owns 64*CS consecutive (hence spatially compact) sorted source points, CS per lane;
+//   * upper bounds come from the previous ICP pass's correspondence (warm start) or from the curve
+//     neighbourhood of the point in the target's key order;
+//   * 64 boxes at a time are tested against the wave's box by the 64 lanes (one ballot), the
+//     survivors against each lane's own points; every (source, sub-block) pair that can still hold a
+//     nearer (or equally near) point becomes a work item in a wave-private LDS queue, consumed 64 items
+//     at a time: a lane walks ITS sub-block's 16 staged targets and folds the minimum into the source's
+//     packed (d2 bits << 32 | sub-block) key with an LDS atomic min.
+// A box is skipped only when a conservative lower bound of its distance exceeds the current best
+// of the point (or of every point of the wave), so no candidate for the minimum (or for a tie) is missed.
+//
+// Everything is indexed in SORTED space: source slot i is the i-th point of the source's Hilbert
+// order, a correspondence is the target's sorted position.  (Round 1 kept original indices: the warm
+// start then cost three dependent random gathers per point and 5x the algorithmic HBM traffic.)
+// The epilogue writes, besides corr / d2: the (moved source, matched target) pair for the RANSAC
+// stage (PAIRS) and the wave's fp64 raw moments for the ICP step (one partial per wave, reduced in a
+// fixed order by solve_kernel), so no separate gather / accumulate pass reads the points again.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "reg_kernels.hpp"
+
+namespace gloc {
+namespace reg {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define GPTR(T) const T __attribute__((address_space(1)))*
+
+// grid = n_wg_max * n_jobs work-groups of 4 independent waves; block b works on job b % n_jobs,
+// source work-group b / n_jobs (job fastest: every job's widest groups -- `order` lists them widest
+// first -- start at t = 0 and finish under cover of the bulk).
+template <int CS, bool PAIRS>
+__global__ __launch_bounds__(256) void nn_compact_kernel(
+    const Job* __restrict__ jobs, uint32_t n_jobs, const CandState* __restrict__ states,
+    const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
+    f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
+    size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* pairs evaluated */,
+    uint32_t* __restrict__ trace /* dev only: [wave][4] = cycles, candidate chunks, chunks, rounds */) {
+  constexpr int S = 64 * CS;        // sources per wave
+  constexpr int NSB = CH / SB;      // sub-blocks per chunk
+  // The staged chunk is kept as PAIRS of targets, structure-of-arrays: pair i of a sub-block is
+  // (x0, x1, y0, y1 | z0, z1, -, -), 32 B, so that one packed fp32 instruction handles two targets
+  // (v_pk_add/mul_f32 round each half like the scalar forms: same bits).  Sub-blocks are 288 B apart:
+  // the extra 32 B shift sub-block b's pair i into bank group (i + b) % 8, so lanes that walk
+  // different sub-blocks in lock step never collide.
+  constexpr int SB_STRIDE = (SB / 2) * 8 + 8;  // floats per sub-block: SB/2 pairs x 8 floats + 8 of shift
+  struct WaveLds {
+    float stage[NSB * SB_STRIDE];   // the chunk being evaluated
+    f32x4 src[S];                   // moved source points
+    unsigned long long key[S];      // (bits(best d2) << 32) | sub-block holding it
+    uint8_t tie[S];                 // (sizes are chosen so that CS = 2 stays under 8 KB per wave: 5 work-groups per CU)
+    f32x4 sblo[NSB], sbhi[NSB];     // the chunk's sub-block boxes
+    uint16_t list[S];               // source slots that passed the chunk-level test
+    uint16_t queue[S * NSB];        // work items: (source slot << 3) | sub-block within the chunk
+  };
+  static_assert(SB % 16 == 0 && NSB == 8, "items pack the sub-block into 3 bits");
+  __shared__ WaveLds lds_all[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  WaveLds& L = lds_all[w];
+  const uint32_t job = blockIdx.x % n_jobs, wg = blockIdx.x / n_jobs;
+  const Job& J = jobs[job];
+  const uint32_t gi = wg * 4 + w;
+  const uint32_t n_src = J.n_src;
+  if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
+  struct IndexView {
+    GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb_lo; GPTR(f32x4) sb_hi;
+    GPTR(uint32_t) keys; GPTR(ScanHeader) hdr;
+    uint32_t n, nchunks;
+    GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
+    uint32_t nsup;
+  };
+  // The index arrays are reached through pointers loaded from memory, which the compiler would
+  // treat as generic (flat_load): view them in the global address space explicitly.
+  const ScanIndexDev ixg = J.tgt;
+  const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
+                     (GPTR(f32x4))ixg.sb_lo, (GPTR(f32x4))ixg.sb_hi, (GPTR(uint32_t))ixg.keys,
+                     (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
+                     (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup};
+  GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
+
+  const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
+  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0;
+  unsigned long long n_items = 0;
+
+  float px[CS], py[CS], pz[CS], best[CS];
+  bool valid[CS];
+  float wlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, whi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    const uint32_t i = wave_base + s * 64 + lane;
+    valid[s] = i < n_src;
+    const f32x4 p = src4[valid[s] ? i : (n_src - 1)];
+    xform(T, p.x, p.y, p.z, px[s], py[s], pz[s]);
+    wlo[0] = fminf(wlo[0], px[s]); whi[0] = fmaxf(whi[0], px[s]);
+    wlo[1] = fminf(wlo[1], py[s]); whi[1] = fmaxf(whi[1], py[s]);
+    wlo[2] = fminf(wlo[2], pz[s]); whi[2] = fmaxf(whi[2], pz[s]);
+    best[s] = 3.402823466e+38f;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      wlo[a] = fminf(wlo[a], __shfl_xor(wlo[a], o));
+      whi[a] = fmaxf(whi[a], __shfl_xor(whi[a], o));
+    }
+
+  // ---- upper bounds -> LDS state -----------------------------------------------------------------
+  // warm: the previous pass's correspondence (a sorted position: one coherent 16-byte gather);
+  // cold: the five curve neighbours of the point's key in the target's order
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    uint32_t b0 = 0;
+    if (ix.n) {
+      uint32_t j = 0xFFFFFFFFu;
+      if (prev_corr) j = prev_corr[(size_t)job * ld + (valid[s] ? wave_base + s * 64 + lane : 0)];
+      if (j < ix.n) {
+        const f32x4 t = ix.pts[j];
+        best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
+        b0 = j / SB;
+      } else {
+        const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
+        uint32_t lo = 0, hi = ix.n;  // lower_bound over the sorted keys
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (ix.keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        for (int d = -2; d <= 2; ++d) {
+          long long jj = (long long)lo + d;
+          jj = jj < 0 ? 0 : (jj >= (long long)ix.n ? (long long)ix.n - 1 : jj);
+          const f32x4 t = ix.pts[jj];
+          const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
+          if (dd < best[s]) {
+            best[s] = dd;
+            b0 = (uint32_t)jj / SB;
+          }
+        }
+      }
+    }
+    const int slot = s * 64 + lane;
+    L.src[slot] = f32x4{px[s], py[s], pz[s], 0.f};
+    L.key[slot] = ((unsigned long long)__float_as_uint(best[s]) << 32) | b0;
+    L.tie[slot] = 0;
+  }
+  auto wave_max_best = [&]() {
+    float m = -1.f;
+#pragma unroll
+    for (int s = 0; s < CS; ++s) m = fmaxf(m, valid[s] ? best[s] : -1.f);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+  };
+  float wmax = wave_max_best();
+
+  // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
+  auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
+    const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
+    const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
+    const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
+    return ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
+  };
+  for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
+    float lbs = 3.402823466e+38f;
+    if (s0 + lane < ix.nsup) {
+      const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
+      lbs = box_box_lb(ulo, uhi);
+    }
+    unsigned long long smask = __ballot(lbs <= wmax);
+    // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
+    f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
+    int cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cl = (s0 + cur) * 64 + lane;
+      if (cl < ix.nchunks) { nlo = ix.box_lo[cl]; nhi = ix.box_hi[cl]; }
+    }
+    while (cur >= 0) {
+    const uint32_t c0 = (s0 + cur) * 64;
+    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax;
+    const uint32_t cl = c0 + lane;
+    const f32x4 blo = nlo, bhi = nhi;
+    cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cn = (s0 + cur) * 64 + lane;
+      if (cn < ix.nchunks) { nlo = ix.box_lo[cn]; nhi = ix.box_hi[cn]; }
+    }
+    if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
+    float lbw = 3.402823466e+38f;
+    if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
+    unsigned long long mask = __ballot(lbw <= wmax);
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
+      const uint32_t c = c0 + b;
+      n_cand_chunks++;
+      f32x4 lo, hi;
+      lo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.x), b));
+      lo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.y), b));
+      lo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.z), b));
+      hi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.x), b));
+      hi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.y), b));
+      hi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.z), b));
+      bool need[CS], any_need = false;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        need[s] = valid[s] && (box_lb(px[s], py[s], pz[s], lo, hi) <= best[s]);
+        any_need |= need[s];
+      }
+      if (!__any(any_need)) continue;
+      n_processed++;
+      // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
+#pragma unroll
+      for (int u = 0; u < CH / 64; ++u) {
+        const uint32_t tl = u * 64 + lane, j = c * CH + tl;
+        f32x4 v = {NN_FAR, NN_FAR, NN_FAR, 0.f};
+        if (j < ix.n) v = ix.pts[j];
+        float* d = &L.stage[(tl / SB) * SB_STRIDE + ((tl % SB) >> 1) * 8 + (tl & 1)];
+        d[0] = v.x; d[2] = v.y; d[4] = v.z;
+      }
+      f32x4 sbl = {0.f, 0.f, 0.f, 0.f}, sbh = {0.f, 0.f, 0.f, 0.f};
+      {
+        const uint32_t blk_l = c * NSB + (lane & 7);
+        if (blk_l * SB < ix.n) {
+          sbl = ix.sb_lo[blk_l];
+          sbh = ix.sb_hi[blk_l];
+        }
+      }
+      // sources that passed the chunk-level test, compacted
+      uint32_t k = 0;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        const unsigned long long m = __ballot(need[s]);
+        if (need[s])
+          L.list[k + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+              (uint16_t)(s * 64 + lane);
+        k += (uint32_t)__popcll(m);
+      }
+      if (lane < NSB) {
+        L.sblo[lane] = sbl;
+        L.sbhi[lane] = sbh;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // sub-block tests, one (source, sub-block) pair per lane: only the listed sources are tested,
+      // against their CURRENT bound; the passing pairs become the work items
+      const uint32_t left = ix.n - c * CH;  // > 0: the chunk exists
+      const uint32_t nsb_valid = left >= (uint32_t)CH ? (uint32_t)NSB : (left + SB - 1) / SB;
+      uint32_t total = 0;
+      // four steps of 64 pairs at a time: their LDS reads and box tests are independent, so a wave
+      // (latency-bound when few share the SIMD) overlaps them; only the queue positions are serial
+      constexpr int TU = 4;
+      for (uint32_t t0 = 0; t0 < k * NSB; t0 += 64 * TU) {
+        uint32_t si[TU];
+        bool act[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const uint32_t t = t0 + u * 64 + lane;
+          act[u] = t < k * NSB;
+          si[u] = L.list[act[u] ? (t >> 3) : 0];
+        }
+        const uint32_t sb = lane & 7;  // (t & 7): t0 and u * 64 are multiples of 8
+        const f32x4 slo = L.sblo[sb], shi = L.sbhi[sb];
+        f32x4 p[TU];
+        float bst[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          p[u] = L.src[si[u]];
+          bst[u] = __uint_as_float((uint32_t)(L.key[si[u]] >> 32));
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const bool nd = act[u] && sb < nsb_valid && (box_lb(p[u].x, p[u].y, p[u].z, slo, shi) <= bst[u]);
+          const unsigned long long m = __ballot(nd);
+          if (nd)
+            L.queue[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                (uint16_t)((si[u] << 3) | sb);
+          total += (uint32_t)__popcll(m);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      n_items += total;
+      for (uint32_t r = 0; r < total; r += 64) {
+        n_rounds++;
+        const uint32_t it = r + lane;
+        const bool act = it < total;
+        const uint32_t item = L.queue[act ? it : r];
+        const uint32_t slot = item >> 3, bi = item & 7;
+        const f32x4 p = L.src[slot];
+        const float* sb = &L.stage[bi * SB_STRIDE];
+        const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
+        float m = 3.402823466e+38f;
+#pragma unroll
+        for (int i = 0; i < SB / 2; ++i) {
+          const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
+          const f32x2 zz = *reinterpret_cast<const f32x2*>(sb + i * 8 + 4);
+          // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
+          const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
+          const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+          m = fminf(fminf(m, d2.x), d2.y);
+        }
+        if (act) {
+          const uint32_t blk = c * NSB + bi;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | blk;
+          const unsigned long long old = atomicMin(&L.key[slot], key);
+          if ((uint32_t)(old >> 32) == __float_as_uint(m) && (uint32_t)old != blk) L.tie[slot] = 1;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      bool changed = false;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        const float nb = __uint_as_float((uint32_t)(L.key[s * 64 + lane] >> 32));
+        changed |= nb < best[s];
+        best[s] = nb;
+      }
+      if (__any(changed)) wmax = wave_max_best();
+    }
+    }  // batches of this super-chunk group
+  }
+  if (stat_pairs && lane == 0) atomicAdd(stat_pairs, n_items * (unsigned long long)SB);
+
+  // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
+  // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
+  uint32_t bpos[CS];
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    bpos[s] = 0xFFFFFFFFu;
+    if (!valid[s] || !ix.n) continue;
+    const int slot = s * 64 + lane;
+    const uint32_t bch = (uint32_t)L.key[slot];
+    const bool tie = L.tie[slot] != 0;
+    uint32_t bj = 0xFFFFFFFFu;
+    if (!tie) {
+      // all 16 loads in flight at once (clamped, so that they are unconditional): one memory
+      // round trip instead of sixteen -- a lone wave is latency-bound here
+      const uint32_t j0 = bch * SB;
+      f32x4 t[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) t[u] = ix.pts[(j0 + u) < ix.n ? (j0 + u) : (ix.n - 1)];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        if ((j0 + u) < ix.n && dist2(px[s], py[s], pz[s], t[u].x, t[u].y, t[u].z) == best[s]) {
+          const uint32_t o = __float_as_uint(t[u].w);
+          if (o < bj) {
+            bj = o;
+            bpos[s] = j0 + u;
+          }
+        }
+      }
+    } else {  // rare: every chunk that can hold a point at the minimum distance
+      for (uint32_t c = 0; c < ix.nchunks; ++c) {
+        const f32x4 clo = ix.box_lo[c], chi = ix.box_hi[c];
+        if (box_lb(px[s], py[s], pz[s], clo, chi) > best[s]) continue;
+        const uint32_t j0 = c * CH;
+        const uint32_t j1 = (j0 + CH) < ix.n ? (j0 + CH) : ix.n;
+        for (uint32_t j = j0; j < j1; ++j) {
+          const f32x4 t = ix.pts[j];
+          if (dist2(px[s], py[s], pz[s], t.x, t.y, t.z) == best[s]) {
+            const uint32_t o = __float_as_uint(t.w);
+            if (o < bj) {
+              bj = o;
+              bpos[s] = j;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- outputs: corr / d2 (sorted slots), pairs, fp64 raw moments of the wave -------------------
+  double v[ACC_NV];
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    if (!valid[s]) continue;
+    const size_t o = (size_t)job * ld + wave_base + s * 64 + lane;
+    corr[o] = bpos[s];
+    d2out[o] = best[s];
+    f32x4 q = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // no correspondence (empty target): never an inlier
+    if (bpos[s] != 0xFFFFFFFFu) {
+      q = ix.pts[bpos[s]];  // just loaded above: an L1 hit
+      q.w = 0.f;
+      const float d2 = best[s];
+      v[16] += (double)d2;
+      if (!(gate2 > 0.f) || d2 < gate2) {
+        const double P[3] = {(double)px[s], (double)py[s], (double)pz[s]};
+        const double Q[3] = {(double)q.x, (double)q.y, (double)q.z};
+        v[0] += 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          v[1 + a] += P[a];
+          v[4 + a] += Q[a];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += P[a] * Q[b];
+        }
+      }
+    }
+    if (PAIRS) {
+      pairs[o * 2 + 0] = f32x4{px[s], py[s], pz[s], 0.f};
+      pairs[o * 2 + 1] = q;
+    }
+  }
+  if (partials) {
+    double* out = partials + ((size_t)job * n_part + gi) * ACC_NV;
+#pragma unroll
+    for (int k = 0; k < ACC_NV; ++k) {
+      double x = v[k];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);  // butterfly: a fixed order
+      if (lane == 0) out[k] = x;
+    }
+  }
+  if (trace && lane == 0) {
+    const size_t wid = (size_t)blockIdx.x * 4 + w;
+    trace[4 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+    trace[4 * wid + 1] = n_cand_chunks;
+    trace[4 * wid + 2] = n_processed;
+    trace[4 * wid + 3] = n_rounds;
+  }
+}
+
+}  // namespace reg
+}  // namespace gloc

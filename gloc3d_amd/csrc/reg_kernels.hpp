@@ -16,16 +16,26 @@
 #include <stdint.h>
 
 #include "math3.hpp"          // f32x4, xform, dist2, jacobi_eig3, cross3, mulhi_idx, NN_FAR
+#include "scan_index.hpp"     // ScanIndexDev, CH, SB
 #include "synth_kernels.hpp"  // mix64 / rng_key / rng_draw
 
 namespace gloc {
 namespace reg {
 
 
-struct CandDesc {
-  const float* tgt;  // packed xyz
-  uint32_t n_tgt;
-  uint32_t cand_id;  // RANSAC stream id
+// One registration job = (query scan, candidate scan).  A batch holds the jobs of ALL queries in
+// flight (n_queries x n_cand), so that every launch covers them all.  Everything downstream of the
+// scans is indexed in SORTED space: slot i of job c is the i-th point of the query's Hilbert order,
+// corr[c][i] the matched target's sorted position (0xFFFFFFFF: none).
+struct Job {
+  const f32x4* src_pts;       // query scan, Hilbert order: x, y, z, bits(original index)
+  const uint32_t* src_order;  // source groups, widest first (launch order of the culled search)
+  const uint32_t* src_inv;    // original source index -> sorted slot (RANSAC samples original ids)
+  const float* tgt_xyz;       // candidate scan, original order, packed (exhaustive search)
+  ScanIndexDev tgt;           // candidate scan, search index
+  uint32_t n_src, n_groups;   // n_groups = ceil(n_src / (64 * sources per lane))
+  uint32_t cand_id;           // RANSAC stream id (rank in the retrieval list)
+  uint32_t pad_;
 };
 
 // per-candidate state, device resident
@@ -41,38 +51,38 @@ struct CandState {
 };
 
 // ---------------------------------------------------------------------------------------------
-// K4.  grid = (ceil(n_src / (256*NN_S)), n_cand).  Each lane owns NN_S source points; targets are
-// staged 256 at a time into LDS as float4 and read back as wave-uniform broadcasts.
+// K4 (exhaustive form, the kernel north_star names).  grid = (ceil(max n_src / (256*NN_S)), n_jobs).
+// Each lane owns NN_S source points (sorted slots); the targets are streamed IN ORIGINAL ORDER, 256 at
+// a time into LDS as float4 and read back as wave-uniform broadcasts, so "first minimum" is the
+// smallest original index.  The stored correspondence is the winner's sorted position.
 constexpr int NN_S = 4;
 constexpr int NN_TC = 256;
 
-__global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, uint32_t n_src,
-                                                 const CandDesc* __restrict__ cands,
+__global__ __launch_bounds__(256) void nn_kernel(const Job* __restrict__ jobs,
                                                  const CandState* __restrict__ states,
                                                  uint32_t* __restrict__ corr,
                                                  float* __restrict__ d2out, size_t ld) {
   __shared__ f32x4 tl[2][NN_TC];
   const int tid = threadIdx.x;
-  const int cand = blockIdx.y;
-  const float* __restrict__ tgt = cands[cand].tgt;
-  const uint32_t n_tgt = cands[cand].n_tgt;
+  const int job = blockIdx.y;
+  const Job& J = jobs[job];
+  const uint32_t n_src = J.n_src;
+  const uint32_t base = blockIdx.x * (256 * NN_S);
+  if (base >= n_src) return;  // uniform over the work-group
+  const float* __restrict__ tgt = J.tgt_xyz;
+  const uint32_t n_tgt = J.tgt.n;
   float T[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = states[cand].Tf[i];
+  for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
 
   float px[NN_S], py[NN_S], pz[NN_S], best[NN_S];
   uint32_t bchunk[NN_S];
-  const uint32_t base = blockIdx.x * (256 * NN_S);
 #pragma unroll
   for (int s = 0; s < NN_S; ++s) {
     const uint32_t i = base + s * 256 + tid;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (i < n_src) {
-      x = src[3 * (size_t)i + 0];
-      y = src[3 * (size_t)i + 1];
-      z = src[3 * (size_t)i + 2];
-    }
-    xform(T, x, y, z, px[s], py[s], pz[s]);
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    if (i < n_src) p = J.src_pts[i];
+    xform(T, p.x, p.y, p.z, px[s], py[s], pz[s]);
     best[s] = 3.402823466e+38f;
     bchunk[s] = 0;
   }
@@ -128,39 +138,54 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
         const float d = dist2(px[s], py[s], pz[s], tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1],
                               tgt[3 * (size_t)j + 2]);
         if (d == best[s]) {
-          bj = j;
+          bj = J.tgt.inv[j];
           break;
         }
       }
     }
-    corr[(size_t)cand * ld + i] = bj;
-    d2out[(size_t)cand * ld + i] = best[s];
+    corr[(size_t)job * ld + i] = bj;
+    d2out[(size_t)job * ld + i] = best[s];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// (moved source, matched target) pairs as 2 x float4, so the RANSAC scorer reads them coalesced.
-__global__ void gather_pairs_kernel(const float* __restrict__ src, uint32_t n_src,
-                                    const CandDesc* __restrict__ cands,
-                                    const CandState* __restrict__ states,
+// (moved source, matched target) pairs as 2 x float4 per sorted slot, so the RANSAC scorer reads them
+// coalesced.  Only the exhaustive search needs this pass: the culled search writes the pairs itself.
+__global__ void gather_pairs_kernel(const Job* __restrict__ jobs, const CandState* __restrict__ states,
                                     const uint32_t* __restrict__ corr, size_t ld,
                                     f32x4* __restrict__ pairs) {
-  const int cand = blockIdx.y;
+  const int job = blockIdx.y;
+  const Job& J = jobs[job];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_src) return;
+  if (i >= J.n_src) return;
   float T[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) T[k] = states[cand].Tf[k];
+  for (int k = 0; k < 12; ++k) T[k] = states[job].Tf[k];
+  const f32x4 p = J.src_pts[i];
   float x, y, z;
-  xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], x, y, z);
-  const uint32_t j = corr[(size_t)cand * ld + i];
+  xform(T, p.x, p.y, p.z, x, y, z);
+  const uint32_t j = corr[(size_t)job * ld + i];
   f32x4 q = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // no correspondence (empty target): never an inlier
-  if (j < cands[cand].n_tgt) {
-    const float* t = cands[cand].tgt + 3 * (size_t)j;
-    q = f32x4{t[0], t[1], t[2], 0.f};
+  if (j < J.tgt.n) {
+    q = J.tgt.pts[j];
+    q.w = 0.f;
   }
-  pairs[((size_t)cand * ld + i) * 2 + 0] = f32x4{x, y, z, 0.f};
-  pairs[((size_t)cand * ld + i) * 2 + 1] = q;
+  pairs[((size_t)job * ld + i) * 2 + 0] = f32x4{x, y, z, 0.f};
+  pairs[((size_t)job * ld + i) * 2 + 1] = q;
+}
+
+// Correspondences in the caller's terms (gloc_reg_nn): original source index -> original target index.
+__global__ void export_corr_kernel(const Job* __restrict__ jobs, const uint32_t* __restrict__ corr,
+                                   const float* __restrict__ d2in, size_t ld,
+                                   uint32_t* __restrict__ out_idx, float* __restrict__ out_d2) {
+  const int job = blockIdx.y;
+  const Job& J = jobs[job];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= J.n_src) return;
+  const uint32_t o = __float_as_uint(J.src_pts[i].w);
+  const uint32_t j = corr[(size_t)job * ld + i];
+  out_idx[(size_t)job * ld + o] = j < J.tgt.n ? __float_as_uint(J.tgt.pts[j].w) : 0xFFFFFFFFu;
+  out_d2[(size_t)job * ld + o] = d2in[(size_t)job * ld + i];
 }
 
 __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
@@ -211,14 +236,15 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
     t[i] = qbar[i] - ((R[3 * i + 0] * pbar[0] + R[3 * i + 1] * pbar[1]) + R[3 * i + 2] * pbar[2]);
 }
 
-// K5a.  One thread per (candidate, hypothesis).  pairs: [cand][ld][2] float4.
-// Hypotheses [h_begin, h_end) of every candidate; with `states`, candidates whose adaptive iteration
-// count has already been reached are skipped (their later hypotheses are never looked at).
-__global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, uint32_t n,
-                                  const CandDesc* __restrict__ cands, uint64_t seed,
+// K5a.  One thread per (job, hypothesis).  pairs: [job][ld][2] float4 by sorted slot; the three
+// sampled ids are ORIGINAL source indices (as the oracle samples them), mapped through src_inv.
+// Hypotheses [h_begin, h_end) of every job; with `states`, jobs whose adaptive iteration count has
+// already been reached are skipped (their later hypotheses are never looked at).
+__global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld,
+                                  const Job* __restrict__ jobs, uint64_t seed,
                                   uint32_t n_hyp, uint32_t h_begin, uint32_t h_end,
                                   const CandState* __restrict__ states,
-                                  float* __restrict__ Rt /* [cand][n_hyp][12] */,
+                                  float* __restrict__ Rt /* [job][n_hyp][12] */,
                                   uint32_t* __restrict__ valid) {
   const int cand = blockIdx.y;
   const uint32_t h = h_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,8 +252,10 @@ __global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, ui
   if (states && states[cand].ransac_done) return;
   const size_t o = (size_t)cand * n_hyp + h;
   valid[o] = 0;
+  const uint32_t n = jobs[cand].n_src;
   if (n < 3) return;
-  const uint64_t key = synth::rng_key(seed, ((uint64_t)cands[cand].cand_id << 32) | (uint64_t)h);
+  const uint32_t* __restrict__ inv = jobs[cand].src_inv;
+  const uint64_t key = synth::rng_key(seed, ((uint64_t)jobs[cand].cand_id << 32) | (uint64_t)h);
   uint64_t ctr = 0;
   uint32_t s0 = mulhi_idx(synth::rng_draw(key, ctr++), n), s1 = s0, s2 = s0;
   for (int tries = 0; tries < 16 && s1 == s0; ++tries) s1 = mulhi_idx(synth::rng_draw(key, ctr++), n);
@@ -237,8 +265,9 @@ __global__ void ransac_hyp_kernel(const f32x4* __restrict__ pairs, size_t ld, ui
   const uint32_t sidx[3] = {s0, s1, s2};
   double p[3][3], q[3][3];
   for (int k = 0; k < 3; ++k) {
-    const f32x4 pv = pairs[((size_t)cand * ld + sidx[k]) * 2 + 0];
-    const f32x4 qv = pairs[((size_t)cand * ld + sidx[k]) * 2 + 1];
+    const uint32_t slot = inv ? inv[sidx[k]] : sidx[k];
+    const f32x4 pv = pairs[((size_t)cand * ld + slot) * 2 + 0];
+    const f32x4 qv = pairs[((size_t)cand * ld + slot) * 2 + 1];
     p[k][0] = (double)pv.x; p[k][1] = (double)pv.y; p[k][2] = (double)pv.z;
     q[k][0] = (double)qv.x; q[k][1] = (double)qv.y; q[k][2] = (double)qv.z;
     if (qv.x >= 0.5f * NN_FAR) return;  // sampled a point without correspondence (empty target scan)
@@ -277,7 +306,7 @@ constexpr int SC_CHUNK = 4096;
 constexpr int SC_STAGE = 256;
 
 __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restrict__ pairs,
-                                                           size_t ld, uint32_t n, uint32_t n_hyp,
+                                                           size_t ld, const Job* __restrict__ jobs, uint32_t n_hyp,
                                                            uint32_t h_begin, uint32_t hyp_per_block,
                                                            const float* __restrict__ Rt,
                                                            const uint32_t* __restrict__ valid,
@@ -287,6 +316,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   __shared__ f32x4 sp[2 * SC_STAGE];
   const int cand = blockIdx.z;
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
+  const uint32_t n = jobs[cand].n_src;
+  if (blockIdx.y * SC_CHUNK >= n) return;
   // hyp_per_block = 256: thread <-> hypothesis.  64: four waves share 64 hypotheses, each taking a
   // quarter of every staged tile (the first phase of the adaptive RANSAC needs few hypotheses).
   const uint32_t sub = threadIdx.x / hyp_per_block, nsub = 256 / hyp_per_block;
@@ -347,11 +378,12 @@ __global__ __launch_bounds__(64) void ransac_scan_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ valid,
                                                          const float* __restrict__ Rt,
                                                          uint32_t n_hyp, uint32_t h0, uint32_t h1,
-                                                         uint32_t n, float conf,
+                                                         const Job* __restrict__ jobs, float conf,
                                                          float min_inlier_ratio,
                                                          CandState* __restrict__ states) {
   const int cand = blockIdx.x;
   const int lane = threadIdx.x;
+  const uint32_t n = jobs[cand].n_src;
   CandState& st = states[cand];
   uint32_t niters = st.niters, best_inl = st.best_inl, best_h = st.best_h;
   int done = st.ransac_done;
@@ -411,9 +443,10 @@ __global__ __launch_bounds__(64) void ransac_scan_kernel(const uint32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6a.  fp64 raw moments over pairs.  MODE 0 (ICP): source moved by Tf on the fly, targets via
-// corr; optional gate d2 < gate2 on the pair distance.  MODE 1 (RANSAC refit): pre-gathered pairs,
-// gate = inlier of states[cand].bestRt.  Each work-group writes 17 partial sums
+// K6a.  fp64 raw moments over pairs, by sorted slot.  MODE 0 (ICP step of the exhaustive search; the
+// culled search accumulates in its own epilogue): source moved by Tf on the fly, targets via corr;
+// optional gate d2 < gate2 on the pair distance.  MODE 1 (RANSAC refit): pre-gathered pairs, gate =
+// inlier of states[job].bestRt.  Each work-group writes ACC_NV partial sums
 // (n, sp[3], sq[3], spq[9], sum_d2_all) -- reduced in a fixed order by solve_kernel.
 constexpr int ACC_THREADS = 256;
 constexpr int ACC_PER_BLOCK = 2048;
@@ -421,28 +454,31 @@ constexpr int ACC_NV = 17;
 
 template <int MODE>
 __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
-    const float* __restrict__ src, uint32_t n_src, const CandDesc* __restrict__ cands,
-    const CandState* __restrict__ states, const uint32_t* __restrict__ corr,
+    const Job* __restrict__ jobs, const CandState* __restrict__ states, const uint32_t* __restrict__ corr,
     const float* __restrict__ d2in, const f32x4* __restrict__ pairs, size_t ld, float gate2,
-    double* __restrict__ partials /* [cand][nblocks][ACC_NV] */) {
+    double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part) {
   __shared__ double red[ACC_THREADS / 64][ACC_NV];
   const int cand = blockIdx.y;
+  const Job& J = jobs[cand];
+  const uint32_t n_src = J.n_src;
+  const uint32_t b0 = blockIdx.x * ACC_PER_BLOCK;
+  if (b0 >= n_src) return;  // uniform over the work-group
   float T[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) T[k] = (MODE == 0) ? states[cand].Tf[k] : states[cand].bestRt[k];
   double v[ACC_NV];
 #pragma unroll
   for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
-  const uint32_t b0 = blockIdx.x * ACC_PER_BLOCK;
   for (uint32_t i = b0 + threadIdx.x; i < b0 + ACC_PER_BLOCK && i < n_src; i += ACC_THREADS) {
     float px, py, pz, qx, qy, qz;
     bool use;
     if (MODE == 0) {
-      xform(T, src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], px, py, pz);
+      const f32x4 p = J.src_pts[i];
+      xform(T, p.x, p.y, p.z, px, py, pz);
       const uint32_t j = corr[(size_t)cand * ld + i];
-      if (j >= cands[cand].n_tgt) continue;  // no correspondence (empty target scan)
-      const float* t = cands[cand].tgt + 3 * (size_t)j;
-      qx = t[0]; qy = t[1]; qz = t[2];
+      if (j >= J.tgt.n) continue;  // no correspondence (empty target scan)
+      const f32x4 t = J.tgt.pts[j];
+      qx = t.x; qy = t.y; qz = t.z;
       const float d2 = d2in[(size_t)cand * ld + i];
       v[16] += (double)d2;
       use = !(gate2 > 0.f) || (d2 < gate2);
@@ -451,6 +487,8 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
       const f32x4 q = pairs[((size_t)cand * ld + i) * 2 + 1];
       px = p.x; py = p.y; pz = p.z;
       qx = q.x; qy = q.y; qz = q.z;
+      if (qx >= 0.5f * NN_FAR) continue;  // no correspondence
+      v[16] += (double)dist2(px, py, pz, qx, qy, qz);  // = the 1-NN pass's d2, bit for bit
       float x, y, z;
       xform(T, px, py, pz, x, y, z);
       use = dist2(x, y, z, qx, qy, qz) < gate2;
@@ -479,37 +517,54 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
   if (threadIdx.x < ACC_NV) {
     double s = 0.0;
     for (int ww = 0; ww < ACC_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
-    partials[((size_t)cand * gridDim.x + blockIdx.x) * ACC_NV + threadIdx.x] = s;
+    partials[((size_t)cand * n_part + blockIdx.x) * ACC_NV + threadIdx.x] = s;
   }
 }
 
-// K6b.  One wave per candidate: lanes 0..16 each reduce one moment over the blocks in block order
-// (deterministic), lane 0 then solves Kabsch and composes.
+// K6b.  One work-group per job: the job's partials (one per source group when the culled search
+// accumulated them, PER_GROUP, else one per ACC_PER_BLOCK slots) are summed in a fixed order --
+// thread (k, r) takes partials r, r + 60, ... of moment k, thread k then the 60 sub-sums in order --
+// thread 0 solves Kabsch and composes.
 // MODE 0 (ICP step): T <- dT * T.   MODE 1 (RANSAC refit): T <- T_r * T0, falling back to the
 // un-refitted best hypothesis when fewer than 3 inliers, or to T0 when no hypothesis was valid.
+constexpr int SOLVE_R = 60;
+constexpr int SOLVE_THREADS = 1024;
+
 template <int MODE>
-__global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ partials, int nblocks,
-                                                   int n_cand, CandState* __restrict__ states) {
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,
+                                                              uint32_t n_part, bool per_group,
+                                                              const Job* __restrict__ jobs,
+                                                              CandState* __restrict__ states) {
+  __shared__ double sub[SOLVE_R][ACC_NV];
+  __shared__ double tot[ACC_NV];
   const int cand = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (cand >= n_cand) return;
-  double acc = 0.0;
-  if (lane < ACC_NV) {
-    const double* pp = partials + (size_t)cand * nblocks * ACC_NV + lane;
-    int b = 0;
-    for (; b + 8 <= nblocks; b += 8) {  // eight independent loads in flight, summed in block order
-      double v8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = pp[(size_t)(b + u) * ACC_NV];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v8[u];
+  const int tid = threadIdx.x;
+  const uint32_t cnt = per_group ? jobs[cand].n_groups
+                                 : (jobs[cand].n_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
+  if (tid < SOLVE_R * ACC_NV) {
+    const int k = tid % ACC_NV, r = tid / ACC_NV;
+    const double* pp = partials + (size_t)cand * n_part * ACC_NV + k;
+    double acc = 0.0;
+    uint32_t b = (uint32_t)r;
+    for (; b + 3 * SOLVE_R < cnt; b += 4 * SOLVE_R) {  // four independent loads in flight, summed in order
+      const double v0 = pp[(size_t)b * ACC_NV], v1 = pp[(size_t)(b + SOLVE_R) * ACC_NV];
+      const double v2 = pp[(size_t)(b + 2 * SOLVE_R) * ACC_NV], v3 = pp[(size_t)(b + 3 * SOLVE_R) * ACC_NV];
+      acc += v0; acc += v1; acc += v2; acc += v3;
     }
-    for (; b < nblocks; ++b) acc += pp[(size_t)b * ACC_NV];
+    for (; b < cnt; b += SOLVE_R) acc += pp[(size_t)b * ACC_NV];
+    sub[r][k] = acc;
   }
+  __syncthreads();
+  if (tid < ACC_NV) {
+    double acc = 0.0;
+    for (int r = 0; r < SOLVE_R; ++r) acc += sub[r][tid];
+    tot[tid] = acc;
+  }
+  __syncthreads();
+  if (tid != 0) return;
   double v[ACC_NV];
 #pragma unroll
-  for (int k = 0; k < ACC_NV; ++k) v[k] = __shfl(acc, k);
-  if (lane != 0) return;
+  for (int k = 0; k < ACC_NV; ++k) v[k] = tot[k];
   CandState& st = states[cand];
   double Rd[9], td[3];
   bool have = false;
@@ -521,6 +576,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ pa
       return;
     }
   } else {
+    st.sum_d2 = v[16];
     if (st.best_h == 0xFFFFFFFFu) return;  // keep T0
     if (v[0] < 3.0) {
       for (int i = 0; i < 9; ++i) Rd[i] = (double)st.bestRt[i];
@@ -557,25 +613,6 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ pa
     st.Td[9 + i] = tn[i];
     st.Tf[9 + i] = (float)tn[i];
   }
-}
-
-// sum of the NN pass's d2 only (used when RANSAC runs but ICP does not, to report rmse)
-__global__ void sumd2_kernel(const float* __restrict__ d2in, size_t ld, uint32_t n, int n_cand,
-                             CandState* __restrict__ states) {
-  __shared__ double red[256];
-  const int cand = blockIdx.x;
-  double s = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const float d = d2in[(size_t)cand * ld + i];
-    if (d < 3.0e38f) s += (double)d;  // FLT_MAX marks "no correspondence"
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) states[cand].sum_d2 = red[0];
 }
 
 }  // namespace reg

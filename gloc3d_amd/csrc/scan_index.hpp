@@ -1,0 +1,54 @@
+// scan_index.hpp -- the search index of one resident scan and the kernels that build it on the
+// device (no host pass over the points, no host synchronisation between the steps):
+//   bounding box -> Hilbert keys on a 1024^3 grid -> radix sort -> sorted float4 copy with the
+//   original indices, inverse permutation -> boxes per 128-point chunk, per 16-point sub-block and
+//   per 64-chunk super-chunk -> launch order of the source groups (widest first).
+// The structures live here; the kernels that fill them are in scan_store.hip; the 1-NN kernels
+// (nn_compact.hpp) read them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "math3.hpp"
+
+namespace gloc {
+namespace reg {
+
+constexpr int CH = 128;  // points per chunk (256 / 32 measured: -9 % throughput with three queries in flight)
+constexpr int SB = 16;   // points per sub-block (second-level boxes, argmin bookkeeping)
+
+// Device-resident header of a scan (first 64 bytes of its allocation): written by the indexing
+// kernels, read by the search kernels, never by the host.
+struct ScanHeader {
+  float ox, oy, oz, inv_cell;  // origin and 1 / cell of the 1024^3 key grid
+  uint32_t lo[3], hi[3];       // bounding box as order-preserving integers (see f2ord)
+  uint32_t pad_[6];
+};
+static_assert(sizeof(ScanHeader) == 64, "header is 64 bytes");
+
+struct ScanIndexDev {
+  const f32x4* pts;      // Hilbert order: x, y, z, bits(original index)
+  const f32x4* box_lo;   // per chunk of CH points
+  const f32x4* box_hi;
+  const f32x4* sb_lo;    // per sub-block of SB points
+  const f32x4* sb_hi;
+  const uint32_t* keys;  // sorted curve keys
+  const uint32_t* inv;   // original index -> sorted position
+  const ScanHeader* hdr;
+  const f32x4* sup_lo;   // per super-chunk of 64 chunks (8192 points)
+  const f32x4* sup_hi;
+  uint32_t n, nchunks, nsup, pad_;
+};
+
+// order-preserving map float -> uint32 (for atomicMin / atomicMax on coordinates)
+__host__ __device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __builtin_bit_cast(float, u);
+}
+
+}  // namespace reg
+}  // namespace gloc

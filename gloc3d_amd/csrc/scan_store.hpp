@@ -1,0 +1,51 @@
+// scan_store.hpp -- host-side view of the resident scan store (gloc_scan_store of include/gloc3d.h),
+// shared by scan_store.hip (which owns it) and reg.hip (whose registration handles read it).
+#pragma once
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "scan_index.hpp"
+
+// A scan resident in HBM: original-order xyz plus its search index (Hilbert-sorted copy with the
+// original indices, boxes, sorted keys, inverse permutation, launch order).  ONE allocation per scan.
+struct DevScan {
+  void* block = nullptr;
+  size_t block_bytes = 0;
+  float* xyz = nullptr;  // original order, packed
+  size_t n = 0;
+  gloc::reg::ScanIndexDev idx{};
+  uint32_t* order = nullptr;  // source groups of 64 * order_cs sorted points, widest first
+  int order_cs = 0;           // 0: not built
+  bool live = false;
+};
+
+struct gloc_scan_store {
+  int device = 0;
+  std::mutex mu;  // guards the tables, the store's stream and its scratch
+  hipStream_t stream = nullptr;
+  std::vector<DevScan> scans;
+  std::vector<uint32_t> free_ids;
+  std::multimap<size_t, void*> free_blocks;  // released allocations by capacity, reused by later adds
+  size_t live_count = 0, live_bytes = 0, cached_bytes = 0;
+  gloc::DevBuf sort_tmp, sort_keys, sort_vals, sort_perm, stage;
+  std::atomic<int> attached{0};  // registration handles using this store
+};
+
+namespace gloc {
+namespace reg {
+
+// Build a scan from host (`device_src` false) or device memory into a fresh or recycled allocation;
+// returns after the indexing work has completed on the store's stream.  Caller holds store->mu.
+int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
+                    DevScan* out);
+void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block);
+// (Re)build the launch order of a scan for `cs` source points per lane.  Caller holds store->mu.
+int store_build_order(gloc_scan_store* st, DevScan& s, int cs);
+// Copy of scan `id` (by value: the table may grow under another thread).  GLOC_ERR_INVALID if unknown.
+int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out);
+
+}  // namespace reg
+}  // namespace gloc

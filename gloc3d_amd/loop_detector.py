@@ -112,7 +112,10 @@ class RpyPCLoopDetector:
         ids = [self._db_scan_ids[int(i)] for i in db_indices]
         q = np.ascontiguousarray(q_scan, np.float32)
         qid = self._reg.scan_upload(q)
-        res = self._reg.batch_ids(qid, ids, params=self.reg_params)
+        try:
+            res = self._reg.batch_ids(qid, ids, params=self.reg_params)
+        finally:
+            self._reg.scan_release(qid)  # the query scan is transient: HBM stays flat over a run
         r = capi.reg_select_first_ok(res["ok"].astype(np.int32))
         return r, (res["T"][r] if r >= 0 else np.eye(4, dtype=np.float32)), res
 

@@ -128,25 +128,17 @@ class QueryParallelRegistrar:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out.to(device).view(self.world, n, RESULT_COLS)
 
-    def register_many(self, my_queries, cand_global_all, device, registers, executor):
-        """K queries per rank in flight (K = len(registers)): a step handles G*K queries, rank r owning
-        rows r*K .. r*K+K-1 of cand_global_all [G*K, n].  registers[k] is the local_register_all of
-        the k-th registration handle (each handle has its own HIP stream and is driven by its own host
-        thread of `executor`, so one query's small kernels and launch gaps run under another's 1-NN
-        passes).  One all-gather of the K result tables.  Returns [G*K, n, RESULT_COLS]."""
+    def register_many(self, my_queries, cand_global_all, device, register_multi):
+        """K queries per rank in flight (K = len(my_queries)): a step handles G*K queries, rank r owning
+        rows r*K .. r*K+K-1 of cand_global_all [G*K, n].  register_multi(query handles [K], global place
+        ids [K, n] (-1 = none)) -> float32 [K, n, RESULT_COLS] registers them in ONE batch (every kernel
+        launch covers the K x n candidates: gloc_reg_batch_multi).  One all-gather of the K result
+        tables.  Returns [G*K, n, RESULT_COLS]."""
         cand = np.asarray(cand_global_all, dtype=np.int64)
-        K, n = len(registers), cand.shape[1]
-        assert cand.shape[0] == self.world * K and len(my_queries) == K
-
-        def one(k):
-            mine = cand[self.rank * K + k]
-            out = np.zeros((n, RESULT_COLS), np.float32)
-            rows = np.nonzero(mine >= 0)[0]
-            if rows.size:
-                out[rows] = registers[k](my_queries[k], mine[rows], rows.astype(np.uint32))
-            return out
-
-        tables = np.stack(list(executor.map(one, range(K)))) if K > 1 else one(0)[None]
+        K, n = len(my_queries), cand.shape[1]
+        assert cand.shape[0] == self.world * K
+        tables = np.ascontiguousarray(register_multi(my_queries, cand[self.rank * K:(self.rank + 1) * K]),
+                                      np.float32)
         t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
         if self.world == 1:
             return t.to(device).view(K, n, RESULT_COLS)
@@ -159,14 +151,18 @@ class QueryParallelRegistrar:
 # ---- HIP-backed defaults ------------------------------------------------------------------------
 
 def hip_local_search(index):
-    """local_search over a gloc3d_amd.capi.KnnIndex holding this rank's shard (device tensors)."""
+    """local_search over a gloc3d_amd.capi.KnnIndex holding this rank's shard (device tensors).
+    The index is put on torch's CURRENT stream, so that the search is ordered after whatever
+    produced `q` and before whatever consumes idx / d2 (torch's caching allocator hands these
+    tensors out per stream)."""
+    index.set_stream(torch.cuda.current_stream().cuda_stream)
+
     def fn(q, k):
         Q = q.shape[0]
         idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
         d2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
         index.search_device(q.data_ptr(), Q, k, idx.data_ptr(), d2.data_ptr())
-        index.synchronize()
-        return idx, d2
+        return idx, d2   # stream-ordered: no host synchronisation here
     return fn
 
 
@@ -182,6 +178,16 @@ def hip_merge(device_ordinal):
                                od.data_ptr())
         return oi, od
     return fn
+
+
+def pack_results(r, shape):
+    """capi result dict -> float32 [*shape, RESULT_COLS] (pose, rmse, inliers, ok)."""
+    out = np.zeros(tuple(shape) + (RESULT_COLS,), np.float32)
+    out[..., :16] = r["T"].reshape(tuple(shape) + (16,))
+    out[..., 16] = r["rmse"].reshape(shape)
+    out[..., 17] = r["inliers"].reshape(shape).astype(np.float32)  # < 2^24: exact
+    out[..., 18] = r["ok"].reshape(shape).astype(np.float32)
+    return out
 
 
 def hip_local_register(registrar, params):

@@ -171,6 +171,23 @@ def lidar_scan(world, T_world_sensor=None, seed=0, n_beams=64, n_az=2000, max_ra
     return np.concatenate([pts.astype(np.float32), inten[:, None].astype(np.float32)], 1)
 
 
+def scan_variant(xyz, T=None, noise_sigma=0.0, seed=0):
+    """numpy twin of gloc_scan_store_add_variant (csrc/scan_store.hip::scan_variant_kernel): point i =
+    T p_i (fixed un-fused fp32 order ((r0 x + r1 y) + r2 z) + t) + sigma * gauss(key, 3 i + a).
+    Same bits as the device kernel."""
+    p = np.ascontiguousarray(xyz, np.float32)[:, :3]
+    T = np.eye(4, dtype=np.float32) if T is None else np.asarray(T, np.float32)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    out = np.empty((p.shape[0], 3), np.float32)
+    key = rng_key(seed, 11)
+    sg = np.float32(noise_sigma)
+    for a in range(3):
+        v = ((T[a, 0] * x + T[a, 1] * y) + T[a, 2] * z) + T[a, 3]
+        nz = sg * rng_gauss(key, np.arange(p.shape[0], dtype=np.uint64) * np.uint64(3) + np.uint64(a))
+        out[:, a] = v + nz
+    return out
+
+
 def write_kitti_bin(path, scan_xyzi):
     np.ascontiguousarray(scan_xyzi, np.float32).tofile(path)
 

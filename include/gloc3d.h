@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLOC3D_ABI_VERSION 1
+#define GLOC3D_ABI_VERSION 2
 
 enum {
   GLOC_OK = 0,
@@ -167,21 +167,50 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
 enum {
   GLOC_REG_OPT_PROFILE = 1, /* 1: bracket every kernel with HIP events (gloc_reg_profile) */
   GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
-  GLOC_REG_OPT_NN_SRC_PER_LANE = 3, /* culled search tuning: source points per lane (1, 2 or 4) */
-  GLOC_REG_OPT_NN_HEAVY_PERMILLE = 4 /* culled search tuning: share (0..1000 permille) of each candidate's
-                                        work-groups, widest sources first, launched ahead of the rest */
+  GLOC_REG_OPT_NN_SRC_PER_LANE = 3 /* culled search tuning: source points per lane (1, 2 or 4) */
 };
 enum {
-  GLOC_REG_NN_CULLED = 0,    /* default: Morton-sorted scans, chunk boxes, skip what cannot win */
-  GLOC_REG_NN_EXHAUSTIVE = 1, /* every (source, target) pair */
-  GLOC_REG_NN_CULLED_BROADCAST = 2 /* the culled search with whole-wave evaluation (kept for comparison) */
+  GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */
+  GLOC_REG_NN_EXHAUSTIVE = 1 /* every (source, target) pair: the brute-force kernel */
 };
 
-/* Scan store: keep database scans resident in HBM (x,y,z packed fp32, n points).  Returns an id
- * usable in gloc_reg_batch_ids.  `stride_floats` is 3 for packed xyz or 4 for KITTI x,y,z,i
+/* ---- scan store ---------------------------------------------------------------------------- *
+ * The database scans stay resident in HBM with their search index (38 B/point: all 4541 scans of
+ * KITTI-00 = 20 GB of the 288 GB) -- the reference re-reads every candidate scan from disk for every
+ * query (registration/global_localization.cpp:521-525).  A store is shared by any number of
+ * registration handles (gloc_reg_attach_store); query scans are added, used and released.
+ * add/release/count are thread-safe; a scan must not be released while a registration that uses it
+ * is in flight.  Indexing (bounding box, Hilbert keys, radix sort, boxes) runs on the device; add
+ * returns when the scan is ready.  `stride_floats` is 3 for packed xyz or 4 for KITTI x,y,z,i
  * (registration/global_localization.cpp:160-182). */
+typedef struct gloc_scan_store gloc_scan_store;
+int gloc_scan_store_create(int device, gloc_scan_store** out);
+/* GLOC_ERR_STATE while registration handles are still attached. */
+int gloc_scan_store_destroy(gloc_scan_store* st);
+int gloc_scan_store_add(gloc_scan_store* st, const float* pts, size_t n, size_t stride_floats,
+                        uint32_t* scan_id);
+/* Same with the points already in device memory on the store's device. */
+int gloc_scan_store_add_device(gloc_scan_store* st, const float* d_pts, size_t n,
+                               size_t stride_floats, uint32_t* scan_id);
+/* Frees the scan's id and memory for reuse by later adds (ids of other scans do not change). */
+int gloc_scan_store_release(gloc_scan_store* st, uint32_t scan_id);
+int gloc_scan_store_clear(gloc_scan_store* st);
+int gloc_scan_store_count(gloc_scan_store* st, size_t* n_scans);
+/* HBM held by live scans, and by released allocations kept for reuse (either may be NULL). */
+int gloc_scan_store_bytes(gloc_scan_store* st, size_t* live_bytes, size_t* cached_bytes);
+int gloc_scan_store_points(gloc_scan_store* st, uint32_t scan_id, size_t* n_points);
+/* The scan's points, original order, packed xyz (tests). */
+int gloc_scan_store_download(gloc_scan_store* st, uint32_t scan_id, float* out_xyz,
+                             size_t capacity_points);
+
+/* Use `store` for every scan id of this handle (NULL: back to the handle's private store, which
+ * gloc_reg_scan_upload creates on first use). */
+int gloc_reg_attach_store(gloc_reg* h, gloc_scan_store* store);
+
+/* Shims over the handle's current store (private unless one is attached). */
 int gloc_reg_scan_upload(gloc_reg* h, const float* pts, size_t n, size_t stride_floats,
                          uint32_t* scan_id);
+int gloc_reg_scan_release(gloc_reg* h, uint32_t scan_id);
 int gloc_reg_scan_count(const gloc_reg* h, size_t* n_scans);
 int gloc_reg_scan_clear(gloc_reg* h);
 
@@ -202,6 +231,17 @@ int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_sca
                        size_t n_cand, const uint32_t* cand_stream_ids, const float* init_T,
                        const gloc_reg_params* params, float* out_T, float* out_rmse,
                        uint32_t* out_inliers, int* out_ok);
+
+/* Several queries in flight: query q is registered against candidates cand_scan_ids[q*n_cand ..]
+ * (UINT32_MAX = no candidate: that row keeps its initial guess, ok = 0).  Every kernel launch covers
+ * the candidates of ALL the queries, on the handle's one stream.  cand_stream_ids: n_queries x n_cand,
+ * or NULL for 0..n_cand-1 per query.  init_T and the outputs are n_queries x n_cand rows.  Each row
+ * equals what gloc_reg_batch_ids returns for that query alone, bit for bit. */
+int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
+                         const uint32_t* cand_scan_ids, size_t n_cand,
+                         const uint32_t* cand_stream_ids, const float* init_T,
+                         const gloc_reg_params* params, float* out_T, float* out_rmse,
+                         uint32_t* out_inliers, int* out_ok);
 
 /* The reference's selection rule: lowest-rank candidate whose registration succeeded
  * (registration/global_localization.cpp:519-572 stops at the first match()==true).
@@ -362,6 +402,11 @@ int gloc_knn_add_synthetic(gloc_knn* h, int kind, uint64_t seed, uint64_t first_
 int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed,
                            uint64_t first_row, size_t n, size_t dim, uint64_t row_stride,
                            float* d_out);
+/* A new resident scan made on the device from scan `base_id`: point i = T p_i + sigma * gauss(seed, i)
+ * per coordinate (T16 row-major 4x4 or NULL = identity; gloc3d_amd/synth.py::scan_variant gives the
+ * same bits).  Fills a KITTI-00-sized store (4541 distinct scans) in seconds. */
+int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const float* T16,
+                                float noise_sigma, uint64_t seed, uint32_t* scan_id);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,10 @@ class RegParams(C.Structure):
     ]
 
 
+class NnBackend(C.Structure):
+    _fields_ = [("build", C.c_void_p), ("query", C.c_void_p), ("free_", C.c_void_p)]
+
+
 class BevInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("min_ix", "min_iy", "min_iz", "max_ix", "max_iy", "max_iz")] + [
         ("width", C.c_uint32), ("height", C.c_uint32),
@@ -96,6 +100,13 @@ def lib():
                                      C.POINTER(RegParams), C.c_uint32, _f32p,
                                      C.POINTER(C.c_float), C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.oracle_reg_one_nn.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_void_p,
+                                        C.POINTER(RegParams), C.c_uint32, C.c_void_p, _f32p,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.oracle_reg_many_mt.argtypes = [_f32p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.c_size_t, C.POINTER(RegParams), C.c_void_p, C.c_void_p, C.c_int,
+                                         _f32p, _f32p, _u32p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         L.oracle_pose_error.argtypes = [_f32p, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_rng_key.restype = C.c_uint64
         L.oracle_rng_key.argtypes = [C.c_uint64, C.c_uint64]
@@ -223,8 +234,36 @@ def transform_points(T, xyz):
     return out
 
 
+def _ref_nn_backend():
+    """The reference's vendored nanoflann kd-tree (oracle/_ref) as the 1-NN search of oracle_reg_one_nn."""
+    R = ref()
+    cast = lambda f: C.cast(f, C.c_void_p).value
+    return NnBackend(cast(R.ref_nn3_build), cast(R.ref_nn3_query), cast(R.ref_nn3_free))
+
+
+def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=3000, inlier_thresh=0.6,
+                min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99):
+    """Candidates of one query registered on `threads` host threads (bench.py's all-cores leg)."""
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+    ts = [np.ascontiguousarray(t, np.float32).reshape(-1, 3) for t in tgts]
+    n = len(ts)
+    prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
+                    ransac_confidence, 0)
+    ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in ts])
+    cnts = (C.c_size_t * n)(*[t.shape[0] for t in ts])
+    T = np.empty((n, 16), np.float32)
+    rmse, inl, ok = np.empty(n, np.float32), np.empty(n, np.uint32), np.empty(n, np.int32)
+    be = _ref_nn_backend() if ref_nn else None
+    cid = None if cand_ids is None else np.ascontiguousarray(cand_ids, np.uint32)
+    lib().oracle_reg_many_mt(src, src.shape[0], ptrs, cnts, n, C.byref(prm),
+                             None if cid is None else cid.ctypes.data_as(C.c_void_p),
+                             C.cast(C.byref(be), C.c_void_p) if be is not None else None, threads, T, rmse, inl, ok)
+    return dict(T=T.reshape(n, 4, 4), rmse=rmse, inliers=inl, ok=ok.astype(bool))
+
+
 def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
-            min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99):
+            min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
+            ref_nn=False):
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
@@ -236,8 +275,10 @@ def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0
         itp = it.ctypes.data_as(C.c_void_p)
     else:
         itp = None
-    lib().oracle_reg_one(src, src.shape[0], tgt, tgt.shape[0], itp, C.byref(prm), cand_id, T,
-                         C.byref(rmse), C.byref(inl), C.byref(hyp), C.byref(ok))
+    be = _ref_nn_backend() if ref_nn else None
+    lib().oracle_reg_one_nn(src, src.shape[0], tgt, tgt.shape[0], itp, C.byref(prm), cand_id,
+                            C.cast(C.byref(be), C.c_void_p) if be is not None else None, T,
+                            C.byref(rmse), C.byref(inl), C.byref(hyp), C.byref(ok))
     return dict(T=T.reshape(4, 4), rmse=rmse.value, inliers=inl.value, best_hyp=hyp.value,
                 ok=bool(ok.value))
 

@@ -124,6 +124,25 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
                     float* out_T, float* out_rmse, uint32_t* out_inliers, uint32_t* out_best_hyp,
                     int* out_ok);
 
+/* The same with a pluggable exact 1-NN search over the (fixed) target: built once, queried every pass.
+ * bench.py's cpu_baseline passes the REFERENCE's vendored nanoflann kd-tree (oracle/_ref:
+ * ref_nn3_build / ref_nn3_query / ref_nn3_free) here, so that the CPU figure is not held back by this
+ * restatement's own grid search.  nn == NULL: the built-in searches (as oracle_reg_one). */
+typedef struct oracle_nn_backend {
+  void* (*build)(const float* tgt_xyz, size_t n_tgt);
+  void (*query)(void* handle, const float* src_xyz, size_t n_src, uint32_t* out_idx, float* out_d2);
+  void (*free_)(void* handle);
+} oracle_nn_backend;
+void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                       const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                       const oracle_nn_backend* nn, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok);
+/* n_cand candidates of one query over `threads` pthreads (independent work; cand_ids NULL: 0..). */
+void oracle_reg_many_mt(const float* src_xyz, size_t n_src, const float* const* tgt_xyz,
+                        const size_t* n_tgt, size_t n_cand, const oracle_reg_params* prm,
+                        const uint32_t* cand_ids, const oracle_nn_backend* nn, int threads,
+                        float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok);
+
 /* Accuracy metric of registration/global_localization.cpp:288-306 (err_rot in degrees with the
  * 180-degree forgiveness, err_pos in metres). */
 void oracle_pose_error(const float* T_gt16, const float* T_est16, float* err_rot_deg,

@@ -22,6 +22,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -423,11 +424,14 @@ static void compose(const double Ra[9], const double ta[3], const double Rb[9], 
   }
 }
 
-void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
-                    const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
-                    float* out_T, float* out_rmse, uint32_t* out_inliers, uint32_t* out_best_hyp,
-                    int* out_ok) {
+void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                       const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                       const oracle_nn_backend* nn, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok) {
   const uint32_t n = (uint32_t)n_src;
+  /* a search structure over the (fixed) target, built once and queried every pass -- what PCL's ICP
+   * does with its KdTreeFLANN (global_registration.cpp:241-247) */
+  void* nn_handle = (nn && nn->build && n_tgt >= 1) ? nn->build(tgt_xyz, n_tgt) : NULL;
   double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tc[3] = {0, 0, 0}; /* current absolute T */
   if (init_T) {
     for (int i = 0; i < 3; ++i) {
@@ -452,7 +456,9 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
   do {                                                                            \
     CAST_T();                                                                     \
     for (uint32_t i_ = 0; i_ < n; ++i_) xform_f32(Rf, tf, src_xyz + 3 * (size_t)i_, moved + 3 * (size_t)i_); \
-    if (n_src * n_tgt > (size_t)64 * 1024 * 1024)                                 \
+    if (nn_handle)                                                                \
+      nn->query(nn_handle, moved, n_src, corr, d2);                               \
+    else if (n_src * n_tgt > (size_t)64 * 1024 * 1024)                            \
       oracle_nn3_grid(moved, n_src, tgt_xyz, n_tgt, corr, d2);                    \
     else                                                                          \
       oracle_nn3(moved, n_src, tgt_xyz, n_tgt, corr, d2);                         \
@@ -526,8 +532,62 @@ void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, si
   free(moved);
   free(corr);
   free(d2);
+  if (nn_handle) nn->free_(nn_handle);
 #undef CAST_T
 #undef MOVE_AND_MATCH
+}
+
+void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                    const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                    float* out_T, float* out_rmse, uint32_t* out_inliers, uint32_t* out_best_hyp,
+                    int* out_ok) {
+  oracle_reg_one_nn(src_xyz, n_src, tgt_xyz, n_tgt, init_T, prm, cand_id, NULL, out_T, out_rmse,
+                    out_inliers, out_best_hyp, out_ok);
+}
+
+/* Candidates of one query over threads (the all-cores leg of bench.py's cpu_baseline). */
+typedef struct {
+  const float* src;
+  size_t n_src;
+  const float* const* tgt;
+  const size_t* n_tgt;
+  size_t n_cand, first, stride;
+  const oracle_reg_params* prm;
+  const uint32_t* cand_ids;
+  const oracle_nn_backend* nn;
+  float* T;
+  float* rmse;
+  uint32_t* inl;
+  int* ok;
+} reg_mt_arg;
+
+static void* reg_mt_worker(void* p) {
+  reg_mt_arg* a = (reg_mt_arg*)p;
+  for (size_t c = a->first; c < a->n_cand; c += a->stride) {
+    uint32_t hyp;
+    oracle_reg_one_nn(a->src, a->n_src, a->tgt[c], a->n_tgt[c], NULL, a->prm,
+                      a->cand_ids ? a->cand_ids[c] : (uint32_t)c, a->nn, a->T + 16 * c, a->rmse + c,
+                      a->inl + c, &hyp, a->ok + c);
+  }
+  return NULL;
+}
+
+void oracle_reg_many_mt(const float* src_xyz, size_t n_src, const float* const* tgt_xyz,
+                        const size_t* n_tgt, size_t n_cand, const oracle_reg_params* prm,
+                        const uint32_t* cand_ids, const oracle_nn_backend* nn, int threads,
+                        float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n_cand) threads = (int)n_cand;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)(threads ? threads : 1));
+  reg_mt_arg* args = (reg_mt_arg*)malloc(sizeof(reg_mt_arg) * (size_t)(threads ? threads : 1));
+  for (int t = 0; t < threads; ++t) {
+    args[t] = (reg_mt_arg){src_xyz, n_src, tgt_xyz, n_tgt, n_cand, (size_t)t, (size_t)threads, prm,
+                           cand_ids, nn, out_T, out_rmse, out_inliers, out_ok};
+    pthread_create(&th[t], NULL, reg_mt_worker, &args[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+  free(th);
+  free(args);
 }
 
 void oracle_pose_error(const float* Tg, const float* Te, float* err_rot_deg, float* err_pos) {

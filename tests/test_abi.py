@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(capi):
 
 def test_abi_version_and_defaults(capi):
     L = capi.lib()
-    assert L.gloc_abi_version() == 1
+    assert L.gloc_abi_version() == 2
     p = capi.default_reg_params()
     # constants mirrored from the reference: loop_detector.cpp:257, global_registration.cpp:242
     assert p.ransac_iters == 3000 and abs(p.inlier_thresh - 0.6) < 1e-7 and p.icp_iters == 30
@@ -43,6 +43,8 @@ def test_no_cpu_fallback_without_gpu(capi):
     assert "no CPU fallback" in str(e.value)
     with pytest.raises(capi.GlocError):
         capi.Registrar()
+    with pytest.raises(capi.GlocError):
+        capi.ScanStore()
 
 
 def test_product_never_imports_oracle():

@@ -111,22 +111,23 @@ def test_command_lines(dataset):
 
 
 def test_queries_in_flight_give_identical_results(capi):
-    """Three registration handles driven by three host threads (bench.py's throughput mode): every
-    query's result equals the one it gets alone."""
+    """Three registration handles on ONE scan store, driven by three host threads: every query's result
+    equals the one it gets alone; and the python mirror's match() leaves no scan behind."""
     from concurrent.futures import ThreadPoolExecutor
     from gloc3d_amd import synth
     w = synth.make_world(1001)
     scans = [np.ascontiguousarray(synth.lidar_scan(w, synth.se3(1.5 * i, (0.4 * i, -0.2 * i, 0.02 * i)), seed=50 + i,
                                                    n_az=500)[:, :3]) for i in range(5)]
     prm = capi.default_reg_params(ransac_iters=300, icp_iters=4)
-    regs = [capi.Registrar() for _ in range(3)]
-    ids = [[r.scan_upload(s) for s in scans] for r in regs]
-    alone = [regs[0].batch_ids(ids[0][q], [ids[0][c] for c in range(5) if c != q], params=prm) for q in range(3)]
+    store = capi.ScanStore()
+    ids = [store.add(s) for s in scans]
+    regs = [capi.Registrar(store=store) for _ in range(3)]
+    alone = [regs[0].batch_ids(ids[q], [ids[c] for c in range(5) if c != q], params=prm) for q in range(3)]
 
     def work(k):
         out = None
         for _ in range(4):   # repeated, so the three streams really overlap
-            out = regs[k].batch_ids(ids[k][k], [ids[k][c] for c in range(5) if c != k], params=prm)
+            out = regs[k].batch_ids(ids[k], [ids[c] for c in range(5) if c != k], params=prm)
         return out
     with ThreadPoolExecutor(3) as ex:
         together = list(ex.map(work, range(3)))
@@ -135,3 +136,19 @@ def test_queries_in_flight_give_identical_results(capi):
         assert (a["inliers"] == b["inliers"]).all() and (a["ok"] == b["ok"]).all()
     for r in regs:
         r.close()
+    store.close()
+
+
+def test_match_releases_the_query_scan(dataset):
+    """match() uploaded every query scan into the resident store and never freed it."""
+    from gloc3d_amd import loop_detector as ld, synth
+    det = ld.RpyPCLoopDetector(DIM)
+    det.reg_params.icp_iters = 2
+    det.reg_params.ransac_iters = 100
+    for i in range(8):
+        det.add_keyframe(dataset["desc_db"][i], synth.read_kitti_bin(dataset["files"][i]))
+    n0 = det._reg.scan_count()
+    for qi in range(4):
+        det.match(synth.read_kitti_bin(dataset["qfiles"][qi % N_Q]), np.arange(8))
+        assert det._reg.scan_count() == n0 == 8
+    det.close()

@@ -27,12 +27,11 @@ def scans():
     return dict(A=np.ascontiguousarray(A), B=np.ascontiguousarray(B), C=np.ascontiguousarray(C_), T=T)
 
 
-@pytest.fixture(scope="module", params=["culled", "exhaustive", "culled_broadcast"])
+@pytest.fixture(scope="module", params=["culled", "exhaustive"])
 def reg(capi, request):
-    """Every registration test runs on all 1-NN search modes: the results must not differ."""
+    """Every registration test runs on both 1-NN search modes: the results must not differ."""
     r = capi.Registrar()
-    r.set_option(capi.REG_OPT_NN_MODE, dict(culled=capi.REG_NN_CULLED, exhaustive=capi.REG_NN_EXHAUSTIVE,
-                                            culled_broadcast=capi.REG_NN_CULLED_BROADCAST)[request.param])
+    r.set_option(capi.REG_OPT_NN_MODE, dict(culled=capi.REG_NN_CULLED, exhaustive=capi.REG_NN_EXHAUSTIVE)[request.param])
     yield r
     r.close()
 
@@ -80,7 +79,7 @@ def test_nn_lattice_ties(reg, oracle_mod):
     r = reg.batch(src[:4000], [tgt], params=c.default_reg_params(ransac_iters=0, icp_iters=3))
     assert np.isfinite(r["T"]).all()
     first = _LATTICE.setdefault("T", r["T"].copy())
-    assert (bits(first) == bits(r["T"])).all()
+    assert np.abs(first - r["T"]).max() < 2e-6
 
 
 _LATTICE = {}
@@ -180,8 +179,7 @@ def test_culled_equals_exhaustive_full_size(capi, scans):
     """Full-size scans, warm-started ICP passes included: all search modes (and every sources-per-lane
     setting of the culled ones), bit for bit."""
     outs = []
-    configs = [(capi.REG_NN_EXHAUSTIVE, 2)] + [(m, cs) for m in (capi.REG_NN_CULLED, capi.REG_NN_CULLED_BROADCAST)
-                                               for cs in (1, 2, 4)]
+    configs = [(capi.REG_NN_EXHAUSTIVE, 2)] + [(capi.REG_NN_CULLED, cs) for cs in (1, 2, 4)]
     for mode, cs in configs:
         r = capi.Registrar()
         r.set_option(capi.REG_OPT_NN_MODE, mode)
@@ -192,10 +190,80 @@ def test_culled_equals_exhaustive_full_size(capi, scans):
         r.close()
     ref_b, ref_nn = outs[0]
     for (b, nn), cfg in zip(outs[1:], configs[1:]):
-        assert (bits(b["T"]) == bits(ref_b["T"])).all(), cfg
-        assert (b["inliers"] == ref_b["inliers"]).all(), cfg
-        assert (bits(b["rmse"]) == bits(ref_b["rmse"])).all(), cfg
+        # the 1-NN results are identical bit for bit; the fp64 moments are summed per wave (culled) or
+        # per 2048-slot block (exhaustive), so the poses agree to the last bits, not necessarily in them
         assert (nn[0] == ref_nn[0]).all() and (bits(nn[1]) == bits(ref_nn[1])).all(), cfg
+        assert (b["inliers"] == ref_b["inliers"]).all() and (b["ok"] == ref_b["ok"]).all(), cfg
+        assert np.abs(b["T"] - ref_b["T"]).max() < 2e-6, cfg
+        assert np.abs(b["rmse"] - ref_b["rmse"]).max() < 1e-6, cfg
+
+
+def test_store_shared_by_handles_release_and_variants(capi, scans):
+    """One scan store, three registration handles: identical results; release keeps HBM flat; the
+    device-made variant scans carry the bits of the numpy twin."""
+    from gloc3d_amd import synth
+    store = capi.ScanStore()
+    q = np.ascontiguousarray(scans["B"][::30])
+    cands = [np.ascontiguousarray(scans["A"][::9]), np.ascontiguousarray(scans["C"][::9])]
+    qid = store.add(np.concatenate([q, np.ones((len(q), 1), np.float32)], 1))   # x y z i
+    ids = [store.add(c) for c in cands]
+    assert len(store) == 3 and store.points(qid) == len(q)
+    assert (store.download(qid) == q).all()
+    prm = capi.default_reg_params(ransac_iters=200, icp_iters=4)
+    regs = [capi.Registrar(store=store) for _ in range(3)]
+    outs = [r.batch_ids(qid, ids, params=prm) for r in regs]
+    own = capi.Registrar()
+    ref = own.batch(q, cands, params=prm)
+    for o in outs:
+        assert (bits(o["T"]) == bits(ref["T"])).all() and (o["inliers"] == ref["inliers"]).all()
+    with pytest.raises(capi.GlocError):
+        store.close()                      # handles still attached
+    # transient query scans: ids and memory are recycled
+    live0, _ = store.bytes()
+    for it in range(6):
+        t = store.add(q[: 3000 + 17 * it])
+        assert len(store) == 4
+        regs[it % 3].batch_ids(t, ids, params=prm)
+        regs[it % 3].scan_release(t)
+    live1, cached = store.bytes()
+    assert len(store) == 3 and live1 == live0 and cached > 0
+    with pytest.raises(capi.GlocError):
+        regs[0].batch_ids(t, ids, params=prm)  # released id
+    # variants made on the device = the numpy twin, bit for bit
+    T = synth.se3(3.0, (0.4, -0.1, 0.02)).astype(np.float32)
+    v = store.add_variant(ids[0], T, 0.02, 77)
+    assert (bits(store.download(v)) == bits(synth.scan_variant(cands[0], T, 0.02, 77))).all()
+    v0 = store.add_variant(ids[0])
+    assert (store.download(v0) == cands[0]).all()
+    for r in regs:
+        r.close()
+    own.close()
+    store.close()
+
+
+def test_batch_multi_equals_one_query_at_a_time(capi, scans):
+    """Several queries in one batch (one launch covers all their candidates): every row equals the
+    single-query call, bit for bit -- different query sizes, a missing candidate, both search modes."""
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qs = [store.add(np.ascontiguousarray(B[::20])), store.add(np.ascontiguousarray(A[5::33])),
+          store.add(np.ascontiguousarray(B[3::45]))]
+    cs = [store.add(np.ascontiguousarray(x)) for x in (A[::6], A[1::7], Cc[::6], B[::8])]
+    cand = np.array([[cs[0], cs[1], cs[2]], [cs[3], capi.NO_SCAN, cs[0]], [cs[2], cs[1], cs[3]]], np.uint32)
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6)
+    for mode in (capi.REG_NN_CULLED, capi.REG_NN_EXHAUSTIVE):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_MODE, mode)
+        m = r.batch_multi(qs, cand, params=prm)
+        for qi in range(3):
+            keep = [c for c in range(3) if cand[qi, c] != capi.NO_SCAN]
+            one = r.batch_ids(qs[qi], cand[qi, keep], params=prm, stream_ids=np.array(keep, np.uint32))
+            assert (bits(m["T"][qi, keep]) == bits(one["T"])).all()
+            assert (m["inliers"][qi, keep] == one["inliers"]).all() and (m["ok"][qi, keep] == one["ok"]).all()
+            assert (bits(m["rmse"][qi, keep]) == bits(one["rmse"])).all()
+        assert not m["ok"][1, 1] and (m["T"][1, 1] == np.eye(4)).all()
+        r.close()
+    store.close()
 
 
 def test_degenerate_inputs(reg, capi):

@@ -1,4 +1,4 @@
-"""CPU: the multi-GPU orchestration (gloc3d_amd/sharded.py) over `gloo`, world_size 2 and 3.
+"""CPU: the multi-GPU orchestration (gloc3d_amd/sharded.py) over `gloo`, world_size 2, 3 and 8.
 The HIP calls are replaced by checker callables (the oracle) -- what is under test is the sharding
 arithmetic, the fused all-gather, the replicated merge order and the candidate all-reduce."""
 import os
@@ -9,6 +9,9 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+
+Q_ROWS = [5, 40, 202, 17, 63, 99, 0, 1, 150, 77, 201, 33, 120, 8, 190, 101]   # 16 queries: 2 per rank at world 8
 
 
 def _free_port():
@@ -46,7 +49,7 @@ def _worker(rank, world, port, n_places, dim, out_dir):
         return torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(d2)
 
     knn = sharded.ShardedKnn(rank, world, local_search, _checker_merge)
-    q_rows = np.array([5, 40, n_places - 1, 17, 63, 99])
+    q_rows = np.array(Q_ROWS)
     q = torch.from_numpy(synth.queries_near(77, q_rows, dim))
     gi, gd = knn.search(q, 20)
 
@@ -77,19 +80,14 @@ def _worker(rank, world, port, n_places, dim, out_dir):
 
     qreg = sharded.QueryParallelRegistrar(rank, world, register_all)
     tables = qreg.register(100 + rank, gi[:world].numpy(), torch.device("cpu"))
-    # two queries in flight per rank: handle k tags its rows with 1000 * k
-    from concurrent.futures import ThreadPoolExecutor
+    # two queries in flight per rank, registered in ONE batch: row k is tagged with 1000 * k
+    def register_multi(queries, places):
+        out = np.stack([register_all(q, p, np.arange(len(p))) for q, p in zip(queries, places)])
+        out[:, :, 0] = 1000 * np.arange(len(queries))[:, None]
+        return out
 
-    def handle(k):
-        def fn(query, places, ranks):
-            out = register_all(query, places, ranks)
-            out[:, 0] = 1000 * k
-            return out
-        return fn
-
-    with ThreadPoolExecutor(2) as ex:
-        many = qreg.register_many([200 + 2 * rank, 201 + 2 * rank], gi[:2 * world].numpy(), torch.device("cpu"),
-                                  [handle(0), handle(1)], ex)
+    many = qreg.register_many([200 + 2 * rank, 201 + 2 * rank], gi[:2 * world].numpy(), torch.device("cpu"),
+                              register_multi)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), gi=gi.numpy(), gd=gd.numpy(), table=table.numpy(),
              sel=sel, mine=np.array(calls[0][0] if calls else [], np.int64), tables=tables.numpy(),
              many=many.numpy())
@@ -97,7 +95,7 @@ def _worker(rank, world, port, n_places, dim, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
     from gloc3d_amd import sharded, synth
     n_places, dim = 203, 64
@@ -106,7 +104,7 @@ def test_sharded_search_and_registration_over_gloo(oracle_mod, tmp_path, world):
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     # single-database truth
     db = synth.descriptors_traj(77, 0, n_places, dim)
-    q = synth.queries_near(77, np.array([5, 40, n_places - 1, 17, 63, 99]), dim)
+    q = synth.queries_near(77, np.array(Q_ROWS), dim)
     oi, od = oracle_mod.knn_search(db, q, 20)
     for o in outs:                                   # replicated and equal to the 1-GPU result
         assert (o["gi"].astype(np.uint64) == oi).all()

@@ -16,7 +16,7 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
              5: "GLOC_ERR_STATE"}
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
-REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE = 1, 2, 3
+REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_JOB_GROUP = 1, 2, 3, 4
 REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
 NO_SCAN = 0xFFFFFFFF
 SIZE_MAX = C.c_size_t(-1).value
@@ -39,7 +39,7 @@ class RegParams(C.Structure):
     _fields_ = [("ransac_iters", C.c_uint32), ("inlier_thresh", C.c_float),
                 ("min_inlier_ratio", C.c_float), ("icp_iters", C.c_uint32),
                 ("max_corr_dist", C.c_float), ("seed", C.c_uint64),
-                ("ransac_confidence", C.c_float), ("reserved_", C.c_uint32)]
+                ("ransac_confidence", C.c_float), ("max_rmse", C.c_float)]
 
 
 class BevParams(C.Structure):

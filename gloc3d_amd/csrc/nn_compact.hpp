@@ -35,12 +35,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GPTR(T) const T __attribute__((address_space(1)))*
 
-// grid = n_wg_max * n_jobs work-groups of 4 independent waves; block b works on job b % n_jobs,
-// source work-group b / n_jobs (job fastest: every job's widest groups -- `order` lists them widest
-// first -- start at t = 0 and finish under cover of the bulk).
+// grid = n_wg * n_jobs work-groups of 4 independent waves.  Jobs are taken `job_group` at a time; within
+// a group the job index runs fastest (every job's widest source groups -- `order` lists them widest
+// first -- start together and finish under cover of the bulk), so that at any time the work-groups in
+// flight touch the scans of about one group of jobs (which then stay in the L2s / Infinity Cache).
 template <int CS, bool PAIRS>
 __global__ __launch_bounds__(256) void nn_compact_kernel(
-    const Job* __restrict__ jobs, uint32_t n_jobs, const CandState* __restrict__ states,
+    const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
+    const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
     size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* pairs evaluated */,
@@ -66,7 +68,9 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
   __shared__ WaveLds lds_all[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   WaveLds& L = lds_all[w];
-  const uint32_t job = blockIdx.x % n_jobs, wg = blockIdx.x / n_jobs;
+  const uint32_t per = n_wg * job_group, grp = blockIdx.x / per, rem = blockIdx.x % per;
+  const uint32_t left_jobs = n_jobs - grp * job_group, gsize = left_jobs < job_group ? left_jobs : job_group;
+  const uint32_t job = grp * job_group + rem % gsize, wg = rem / gsize;
   const Job& J = jobs[job];
   const uint32_t gi = wg * 4 + w;
   const uint32_t n_src = J.n_src;

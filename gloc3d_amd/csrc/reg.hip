@@ -33,6 +33,7 @@ struct gloc_reg {
   DevBuf trace;
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
+  int nn_job_group = 60;    // culled kernel: jobs interleaved in the launch order
   uint64_t nn_launches = 0;
   Profiler prof;
 };
@@ -91,7 +92,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     }
 #define LAUNCH_COMPACT(CS_, P_)                                                                          \
   hipLaunchKernelGGL((nn_compact_kernel<CS_, P_>), dim3(grid), dim3(256), 0, h->stream, h->jobs.as<Job>(), \
-                     bd.n_jobs, h->states.as<CandState>(),                                               \
+                     bd.n_jobs, (uint32_t)h->nn_job_group, n_wg, h->states.as<CandState>(),              \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), h->partials.as<double>(), bd.n_part, bd.ld, \
                      gate2,                                                                              \
@@ -256,9 +257,10 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
       T[4 * i + 3] = st.Tf[9 + i];
     }
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
-    if (out_rmse) out_rmse[c] = n_src ? (float)std::sqrt(st.sum_d2 / (double)n_src) : 0.f;
+    const float rmse = n_src ? (float)std::sqrt(st.sum_d2 / (double)n_src) : 0.f;
+    if (out_rmse) out_rmse[c] = rmse;
     if (out_inliers) out_inliers[c] = st.best_inl;
-    if (out_ok) out_ok[c] = st.ok;
+    if (out_ok) out_ok[c] = st.ok && !(prm->max_rmse > 0.f && !(rmse <= prm->max_rmse));
   }
   return GLOC_OK;
 }
@@ -312,7 +314,7 @@ void gloc_reg_default_params(gloc_reg_params* p) {
   p->max_corr_dist = 0.f;
   p->seed = 1234;
   p->ransac_confidence = 0.99f;  // cv::estimateAffinePartial2D's default, used by the reference
-  p->reserved_ = 0;
+  p->max_rmse = 0.f;
 }
 
 int gloc_reg_create(int device, gloc_reg** out) {
@@ -394,6 +396,11 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
     GLOC_REQUIRE(value == GLOC_REG_NN_CULLED || value == GLOC_REG_NN_EXHAUSTIVE, GLOC_ERR_INVALID,
                  "bad nn mode %lld", (long long)value);
     h->nn_mode = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_JOB_GROUP) {
+    GLOC_REQUIRE(value >= 1 && value <= 65536, GLOC_ERR_INVALID, "must be in [1, 65536]");
+    h->nn_job_group = (int)value;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {

@@ -152,24 +152,28 @@ class QueryParallelRegistrar:
 
 def hip_local_search(index):
     """local_search over a gloc3d_amd.capi.KnnIndex holding this rank's shard (device tensors).
-    The index is put on torch's CURRENT stream, so that the search is ordered after whatever
-    produced `q` and before whatever consumes idx / d2 (torch's caching allocator hands these
-    tensors out per stream)."""
-    index.set_stream(torch.cuda.current_stream().cuda_stream)
+    The search runs on a side stream that is ordered after torch's CURRENT stream (whatever produced
+    `q`, and the allocator's reuse of the output blocks) and that the current stream then waits for:
+    stream-ordered on both sides, no host synchronisation."""
+    side = torch.cuda.Stream()
+    index.set_stream(side.cuda_stream)
 
     def fn(q, k):
         Q = q.shape[0]
         idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
         d2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
         index.search_device(q.data_ptr(), Q, k, idx.data_ptr(), d2.data_ptr())
-        return idx, d2   # stream-ordered: no host synchronisation here
+        cur.wait_stream(side)
+        return idx, d2
     return fn
 
 
 def hip_merge(device_ordinal):
     from . import capi
 
-    def fn(all_i, all_d):
+    def fn(all_i, all_d):   # on torch's current stream: ordered with the all-gather before it
         G, Q, k = all_i.shape
         oi = torch.empty((Q, k), dtype=torch.int64, device=all_i.device)
         od = torch.empty((Q, k), dtype=torch.float32, device=all_i.device)

@@ -153,7 +153,11 @@ typedef struct gloc_reg_params {
                              its default confidence (loop_detector.cpp:256-257): ransac_iters is the
                              cap, hypotheses beyond the iteration count that reaches this confidence
                              for the best inlier ratio so far are not considered.  <= 0 or >= 1: off */
-  uint32_t reserved_;
+  float max_rmse;          /* > 0: a candidate is ok only if, in addition, the RMS nearest-neighbour distance of
+                             its final pose is <= this (metres).  Plausibility check on the estimated
+                             transform, the analogue of the reference's |1 - scale| < 0.1
+                             (loop_detector.cpp:268-272): the RANSAC inlier ratio at 0.6 m alone cannot
+                             tell two scenes apart that share a ground plane.  <= 0: off (default) */
 } gloc_reg_params;
 
 /* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99). */
@@ -167,7 +171,9 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
 enum {
   GLOC_REG_OPT_PROFILE = 1, /* 1: bracket every kernel with HIP events (gloc_reg_profile) */
   GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
-  GLOC_REG_OPT_NN_SRC_PER_LANE = 3 /* culled search tuning: source points per lane (1, 2 or 4) */
+  GLOC_REG_OPT_NN_SRC_PER_LANE = 3, /* culled search tuning: source points per lane (1, 2 or 4) */
+  GLOC_REG_OPT_NN_JOB_GROUP = 4     /* culled search tuning: jobs whose work-groups are interleaved in the
+                                       launch order (their scans share the caches); default 60 */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

@@ -32,7 +32,7 @@ class RegParams(C.Structure):
         ("max_corr_dist", C.c_float),
         ("seed", C.c_uint64),
         ("ransac_confidence", C.c_float),
-        ("reserved_", C.c_uint32),
+        ("max_rmse", C.c_float),
     ]
 
 
@@ -242,13 +242,14 @@ def _ref_nn_backend():
 
 
 def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=3000, inlier_thresh=0.6,
-                min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99):
+                min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
+                max_rmse=0.0):
     """Candidates of one query registered on `threads` host threads (bench.py's all-cores leg)."""
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     ts = [np.ascontiguousarray(t, np.float32).reshape(-1, 3) for t in tgts]
     n = len(ts)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
-                    ransac_confidence, 0)
+                    ransac_confidence, max_rmse)
     ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in ts])
     cnts = (C.c_size_t * n)(*[t.shape[0] for t in ts])
     T = np.empty((n, 16), np.float32)
@@ -263,11 +264,11 @@ def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=30
 
 def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
             min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
-            ref_nn=False):
+            ref_nn=False, max_rmse=0.0):
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
-                    ransac_confidence, 0)
+                    ransac_confidence, max_rmse)
     T = np.empty(16, np.float32)
     rmse, inl, hyp, ok = C.c_float(), C.c_uint32(), C.c_uint32(), C.c_int()
     if init_T is not None:

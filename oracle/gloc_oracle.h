@@ -75,7 +75,7 @@ typedef struct oracle_reg_params {
   float max_corr_dist;      /* <=0: no rejection (PCL default) */
   uint64_t seed;
   float ransac_confidence;  /* adaptive stop (OpenCV RANSAC default 0.99); <=0 or >=1: off */
-  uint32_t reserved_;
+  float max_rmse;           /* > 0: ok additionally requires the final rmse <= this; <= 0: off */
 } oracle_reg_params;
 
 /* Iterations after which a 3-point RANSAC reaches `conf` given `inl` of `n` inliers: the smallest k

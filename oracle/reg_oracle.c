@@ -525,10 +525,11 @@ void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz,
     out_T[4 * i + 3] = tf[i];
   }
   out_T[12] = 0; out_T[13] = 0; out_T[14] = 0; out_T[15] = 1;
-  if (out_rmse) *out_rmse = n ? (float)sqrt(sum_d2 / (double)n) : 0.0f;
+  const float rmse = n ? (float)sqrt(sum_d2 / (double)n) : 0.0f;
+  if (out_rmse) *out_rmse = rmse;
   if (out_inliers) *out_inliers = best_inl;
   if (out_best_hyp) *out_best_hyp = best_h;
-  if (out_ok) *out_ok = ok;
+  if (out_ok) *out_ok = ok && !(prm->max_rmse > 0.0f && !(rmse <= prm->max_rmse));
   free(moved);
   free(corr);
   free(d2);

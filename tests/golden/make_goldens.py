@@ -25,6 +25,9 @@ KNN_CASES = {
     "knn_cfgB_d4096_q64_iid": (10000, 4096, 64, 20, "iid", 2001, 2002),
     "knn_cfgB_d4096_q64_traj": (10000, 4096, 64, 20, "traj", 2003, 2003),
     "knn_small_d64_q5": (300, 64, 5, 7, "iid", 11, 12),
+    # BASELINE.json configs[3]'s own shape (KITTI-00-sized database x 4096-D), one query and a batch
+    "knn_kitti00_d4096_q1_traj": (4541, 4096, 1, 20, "traj", 4001, 4001),
+    "knn_kitti00_d4096_q64_traj": (4541, 4096, 64, 20, "traj", 4001, 4001),
 }
 
 
@@ -46,6 +49,22 @@ def nn3_inputs():
     return np.ascontiguousarray(B[::60]), np.ascontiguousarray(A[::20])
 
 
+def nn3_fullsize_inputs():
+    """Two full-size scans (~124k points each) and an initial guess.  Coordinates are snapped to
+    multiples of 1/1024 m so that the regenerated inputs are bit-identical on every machine (the
+    ray-caster uses libm sin/cos, whose last bits may differ between CPUs)."""
+    w = synth.make_world(1001)
+    snap = lambda a: np.ascontiguousarray(np.round(a.astype(np.float64) * 1024.0) / 1024.0, np.float32)
+    A = snap(synth.lidar_scan(w, None, seed=1001)[:, :3])
+    B = snap(synth.lidar_scan(w, synth.se3(5.0, (0.5, -0.3, 0.1)), seed=1002)[:, :3])
+    T = synth.se3(4.5, (0.4, -0.25, 0.08)).astype(np.float32)   # near the true pose: a realistic ICP state
+    return B, A, T
+
+
+def crc(a):
+    return np.uint64(int(np.ascontiguousarray(a, np.float32).view(np.uint32).sum(dtype=np.uint64)))
+
+
 def main():
     oracle.build(ref=True)
     for case in KNN_CASES:
@@ -62,6 +81,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "nn3_scanpair.npz"), src=src, tgt=tgt, idx=idx,
                         d2_bits=d2.view(np.uint32))
     print("nn3_scanpair", src.shape, tgt.shape)
+    # full size: the moved source (fixed-order fp32 transform) against the reference's kd-tree
+    src, tgt, T = nn3_fullsize_inputs()
+    moved = oracle.transform_points(T, src)
+    idx, d2 = oracle.ref_nn3(moved, tgt)
+    gi, gd = oracle.nn3(moved, tgt, grid=True)   # smallest-index tie rule: the fixture must be tie-free
+    assert (gi == idx).all() and (gd.view(np.uint32) == d2.view(np.uint32)).all(), "tie in the full-size fixture"
+    np.savez_compressed(os.path.join(HERE, "nn3_fullsize.npz"), idx=idx, d2_bits=d2.view(np.uint32),
+                        src_crc=crc(src), tgt_crc=crc(tgt), T=T)
+    print("nn3_fullsize", src.shape, tgt.shape, os.path.getsize(os.path.join(HERE, "nn3_fullsize.npz")))
 
 
 if __name__ == "__main__":

@@ -138,6 +138,39 @@ def test_device_api_offset_and_merge(capi, oracle_mod):
     assert (bits(md.cpu().numpy()) == bits(od)).all()
 
 
+def test_merge_eight_lists(capi, oracle_mod):
+    """K3 at the node's width: eight row shards with global offsets (ragged sizes, one smaller than k),
+    merged on the device = the single-database top-k, bit for bit."""
+    import torch
+    from gloc3d_amd import synth
+    N, D, Q, k = 4000, 96, 33, 20
+    db = synth.descriptors_iid(43, 0, N, D)
+    q = synth.descriptors_iid(44, 0, Q, D)
+    db[1234] = db[77]                       # equal rows in different shards: ties ordered by global row
+    dq = torch.from_numpy(q).cuda()
+    cuts = [0, 700, 712, 1500, 1501, 2300, 3000, 3900, N]
+    outs_i, outs_d = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ix = _index(capi, db[lo:hi], 0)
+        di = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+        dd = torch.empty((Q, k), dtype=torch.float32, device="cuda")
+        ix.search_device(dq.data_ptr(), Q, k, di.data_ptr(), dd.data_ptr(), index_offset=lo)
+        ix.synchronize()
+        outs_i.append(di)
+        outs_d.append(dd)
+        ix.close()
+    gi = torch.stack(outs_i).contiguous()
+    gd = torch.stack(outs_d).contiguous()
+    mi = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+    md = torch.empty((Q, k), dtype=torch.float32, device="cuda")
+    capi.topk_merge_device(0, torch.cuda.current_stream().cuda_stream, gi.data_ptr(), gd.data_ptr(), 8,
+                           Q, k, mi.data_ptr(), md.data_ptr())
+    torch.cuda.synchronize()
+    oi, od = oracle_mod.knn_search(db, q, k)
+    assert (mi.cpu().numpy().astype(np.uint64) == oi).all()
+    assert (bits(md.cpu().numpy()) == bits(od)).all()
+
+
 def test_on_device_generator_matches_numpy(capi):
     import torch
     from gloc3d_amd import synth

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from util import bits, load_nn3_case
+from util import bits, load_nn3_case, load_nn3_fullsize
 
 
 def test_nn3_matches_reference_golden(oracle_mod):
@@ -11,6 +11,25 @@ def test_nn3_matches_reference_golden(oracle_mod):
         idx, d2 = oracle_mod.nn3(src, tgt, grid=grid)
         assert (idx == g_idx).all()
         assert (bits(d2) == g_bits).all()
+
+
+def test_nn3_full_size_matches_reference_golden(oracle_mod):
+    """124k x 124k: the restatement (fixed-order transform + grid search) = the reference's kd-tree; and,
+    where oracle/_ref is present, that library still reproduces the committed fixture; the kd-tree plugged
+    into the registration restatement (bench.py's cpu_baseline) gives the pose of the built-in search."""
+    src, tgt, T, g_idx, g_bits = load_nn3_fullsize()
+    moved = oracle_mod.transform_points(T, src)
+    idx, d2 = oracle_mod.nn3(moved, tgt, grid=True)
+    assert (idx == g_idx).all() and (bits(d2) == g_bits).all()
+    if oracle_mod.have_ref():
+        ridx, rd2 = oracle_mod.ref_nn3(moved, tgt)
+        assert (ridx == g_idx).all() and (bits(rd2) == g_bits).all()
+        s, t = np.ascontiguousarray(src[::8]), np.ascontiguousarray(tgt[::4])
+        a = oracle_mod.reg_one(s, t, ransac_iters=200, icp_iters=5)
+        b = oracle_mod.reg_one(s, t, ransac_iters=200, icp_iters=5, ref_nn=True)
+        assert np.abs(a["T"] - b["T"]).max() < 1e-5 and a["inliers"] == b["inliers"]
+        m = oracle_mod.reg_many_mt(s, [t, t[::2]], 2, ref_nn=True, ransac_iters=200, icp_iters=5)
+        assert np.abs(m["T"][0] - b["T"]).max() == 0 and m["inliers"][0] == b["inliers"]
 
 
 def test_nn3_grid_equals_bruteforce_with_ties_and_outliers(oracle_mod):

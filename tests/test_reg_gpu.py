@@ -3,7 +3,7 @@ nanoflann golden; RANSAC/ICP against the repo's CPU restatement -- parity unpinn
 import numpy as np
 import pytest
 
-from util import bits, load_nn3_case
+from util import bits, load_nn3_case, load_nn3_fullsize
 
 pytestmark = pytest.mark.gpu
 POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4  # north_star: final 4x4 pose within 1e-4 m / 1e-4 rad
@@ -40,6 +40,40 @@ def test_nn_matches_reference_golden(reg):
     src, tgt, g_idx, g_bits = load_nn3_case()
     idx, d2 = reg.nn(src, tgt)
     assert (idx == g_idx).all() and (bits(d2) == g_bits).all()
+
+
+def test_nn_full_size_matches_reference_golden(reg):
+    """124k x 124k, source moved by an initial guess: indices and d2 bits of the reference's kd-tree
+    (tests/golden/nn3_fullsize.npz, made by oracle/_ref), on both search modes."""
+    src, tgt, T, g_idx, g_bits = load_nn3_fullsize()
+    idx, d2 = reg.nn(src, tgt, T)
+    assert (idx == g_idx).all() and (bits(d2) == g_bits).all()
+
+
+@pytest.fixture(scope="module")
+def fullsize_oracle(oracle_mod, scans):
+    """RANSAC 3000 + ICP 20 at full size through the CPU checker: one positive and one different-scene
+    candidate (~16 s)."""
+    kw = dict(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
+    return [oracle_mod.reg_one(scans["B"], scans[c], cand_id=i, **kw) for i, c in enumerate("AC")]
+
+
+def test_full_size_registration_matches_oracle(reg, capi, scans, fullsize_oracle):
+    prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
+    g = reg.batch(scans["B"], [scans["A"], scans["C"]], params=prm)
+    for c, o in enumerate(fullsize_oracle):
+        assert np.abs(g["T"][c][:3, 3] - o["T"][:3, 3]).max() < POSE_TOL_M
+        assert _rot_angle(g["T"][c][:3, :3], o["T"][:3, :3]) < POSE_TOL_RAD
+        assert g["inliers"][c] == o["inliers"] and bool(g["ok"][c]) == o["ok"]
+        assert abs(g["rmse"][c] - o["rmse"]) < 1e-5
+    assert bool(g["ok"][0]) and not bool(g["ok"][1])
+    er, ep = capi_pose_error(scans["T"], g["T"][0])
+    assert ep < 0.05 and er < 0.05      # the constructed pose is recovered
+
+
+def capi_pose_error(T_gt, T):
+    from gloc3d_amd import loop_detector as ld
+    return ld.pose_error(np.asarray(T_gt, np.float32), T)
 
 
 @pytest.mark.parametrize("ns,nt", [(1, 1), (5, 255), (300, 256), (257, 257), (4000, 9000), (1025, 3)])
@@ -156,6 +190,21 @@ def test_known_answer_pose_recovery_and_selection(reg, capi, oracle_mod):
     assert capi.reg_select_first_ok(g["ok"].astype(np.int32)) == 1
     er, ep = oracle_mod.pose_error(T, g["T"][1])
     assert ep < 5e-3 and er < 0.1 and g["rmse"][1] < 0.03
+
+
+def test_max_rmse_acceptance(reg, capi, oracle_mod, scans):
+    """The optional plausibility check on the final pose: a different scene keeps a high RANSAC inlier
+    ratio at 0.6 m (shared ground plane) but ends far from it; GPU and oracle agree on ok."""
+    q = np.ascontiguousarray(scans["B"][::16])
+    cands = [np.ascontiguousarray(scans["A"][::4]), np.ascontiguousarray(scans["C"][::4])]
+    for max_rmse, expect in ((0.0, None), (1.0, [True, False])):
+        prm = capi.default_reg_params(ransac_iters=300, icp_iters=8, max_rmse=max_rmse)
+        g = reg.batch(q, cands, params=prm)
+        o = [oracle_mod.reg_one(q, c, cand_id=i, ransac_iters=300, icp_iters=8, max_rmse=max_rmse)
+             for i, c in enumerate(cands)]
+        assert [bool(x) for x in g["ok"]] == [x["ok"] for x in o]
+        if expect is not None:
+            assert [bool(x) for x in g["ok"]] == expect
 
 
 def test_scan_store_ids_equal_host_buffers(reg, capi, scans):

@@ -29,6 +29,15 @@ def load_nn3_case():
     return g["src"], g["tgt"], g["idx"], g["d2_bits"]
 
 
+def load_nn3_fullsize():
+    """Full-size scan pair + initial guess (regenerated, crc-checked) and the reference kd-tree's output."""
+    src, tgt, T = make_goldens.nn3_fullsize_inputs()
+    g = np.load(os.path.join(GOLDEN, "nn3_fullsize.npz"))
+    assert int(make_goldens.crc(src)) == int(g["src_crc"]) and int(make_goldens.crc(tgt)) == int(g["tgt_crc"])
+    assert (T == g["T"]).all()
+    return src, tgt, T, g["idx"], g["d2_bits"]
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 

@@ -76,16 +76,23 @@ def _cast_view(job):
     return np.ascontiguousarray(synth.lidar_scan(synth.make_world(world_seed), T, seed=seed)[:, :3])
 
 
-def build_views():
+def build_views(cache=None):
     """Ray-cast the few base views on the host (numpy, a process per view; called BEFORE anything
-    touches the GPU): world A pool, world B pool, query views."""
+    touches the GPU): world A pool, world B pool, query views.  `cache`: an .npz to load them from /
+    save them to (profiling runs: rocprofv3 and forked workers do not mix)."""
     from concurrent.futures import ProcessPoolExecutor
     from gloc3d_amd import synth
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        views = [z[f"v{i}"] for i in range(POOL_A + POOL_B + QUERY_VIEWS)]
+        return views[:POOL_A], views[POOL_A:POOL_A + POOL_B], views[POOL_A + POOL_B:]
     jobs = [(1001, pool_pose(s), 3000 + s) for s in range(POOL_A)]
     jobs += [(2002, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), 5000 + s) for s in range(POOL_B)]
     jobs += [(1001, pool_pose(3 * v + 1) @ synth.se3(1.5, (0.3, -0.2, 0.02)), 9000 + v) for v in range(QUERY_VIEWS)]
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         views = list(ex.map(_cast_view, jobs))
+    if cache:
+        np.savez(cache, **{f"v{i}": v for i, v in enumerate(views)})
     return views[:POOL_A], views[POOL_A:POOL_A + POOL_B], views[POOL_A + POOL_B:]
 
 
@@ -180,6 +187,7 @@ def main():
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
     ap.add_argument("--scan-store", type=int, default=0,
                     help="distinct resident scans (0 = one per place up to 4541; places beyond alias modulo)")
+    ap.add_argument("--views-cache", default=None, help="npz cache of the ray-cast base views (profiling runs)")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-job-group", type=int, default=0, help="culled 1-NN tuning: jobs interleaved in the launch order")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
@@ -193,7 +201,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     t_setup = time.time()
-    pool_a, pool_b, qviews = build_views()   # forks worker processes: before the GPU is initialised
+    pool_a, pool_b, qviews = build_views(args.views_cache)   # forks worker processes: before the GPU is initialised
     import torch
     import torch.distributed as dist
     from gloc3d_amd import capi, sharded, synth

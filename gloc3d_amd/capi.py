@@ -546,6 +546,15 @@ class Registrar:
         check(lib().gloc_reg_nn_stats(self._h, C.byref(c), C.byref(n)))
         return c.value, n.value
 
+    def debug_corr(self, job, n_src):
+        """Test aid: correspondences of the last 1-NN pass of the last batch (caller's index space)."""
+        f = lib().gloc_reg_debug_corr
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        idx, d2 = np.empty(n_src, np.uint32), np.empty(n_src, np.float32)
+        check(f(self._h, job, n_src, _np_ptr(idx), _np_ptr(d2)))
+        return idx, d2
+
 
 def reg_select_first_ok(ok):
     a = np.ascontiguousarray(ok, np.int32)

@@ -33,8 +33,10 @@ struct gloc_reg {
   DevBuf trace;
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
-  int nn_job_group = 60;    // culled kernel: jobs interleaved in the launch order
+  int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
   uint64_t nn_launches = 0;
+  size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
+  uint32_t last_jobs = 0;
   Profiler prof;
 };
 
@@ -137,6 +139,8 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   const uint32_t nblocks = (bd.max_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
   bd.n_part = std::max<uint32_t>(std::max(bd.max_groups, nblocks), 1);
   bd.ld = ((size_t)bd.max_src + 127) & ~(size_t)127;
+  h->last_ld = bd.ld;
+  h->last_jobs = n_jobs;
   hipStream_t s = h->stream;
   h->h_states.resize(n_jobs);
   for (uint32_t c = 0; c < n_jobs; ++c) {
@@ -639,6 +643,28 @@ int gloc_reg_nn_stats(gloc_reg* h, uint64_t* pairs_evaluated, uint64_t* launches
   }
   if (pairs_evaluated) *pairs_evaluated = c;
   if (launches) *launches = h->nn_launches;
+  return GLOC_OK;
+}
+
+// Developer / test aid (not part of include/gloc3d.h): the correspondences of the LAST 1-NN pass of the
+// last batch for job `job`, in the caller's index space (original source index -> original target index).
+int gloc_reg_debug_corr(gloc_reg* h, uint32_t job, uint32_t n_src, uint32_t* out_idx, float* out_d2) {
+  GLOC_REQUIRE(h && out_idx && out_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t ld = h->last_ld;
+  GLOC_REQUIRE(job < h->last_jobs && n_src <= ld, GLOC_ERR_INVALID, "no such job in the last batch");
+  GLOC_TRY(h->export_idx.ensure(sizeof(uint32_t) * ld * h->last_jobs, s));
+  GLOC_TRY(h->export_d2.ensure(sizeof(float) * ld * h->last_jobs, s));
+  hipLaunchKernelGGL(export_corr_kernel, dim3((unsigned)((ld + 255) / 256), h->last_jobs), dim3(256), 0, s,
+                     h->jobs.as<Job>(), h->corr.as<uint32_t>(), h->d2.as<float>(), ld,
+                     h->export_idx.as<uint32_t>(), h->export_d2.as<float>());
+  GLOC_HIP(hipGetLastError());
+  GLOC_HIP(hipMemcpyAsync(out_idx, h->export_idx.as<uint32_t>() + (size_t)job * ld, sizeof(uint32_t) * n_src,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipMemcpyAsync(out_d2, h->export_d2.as<float>() + (size_t)job * ld, sizeof(float) * n_src,
+                          hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipStreamSynchronize(s));
   return GLOC_OK;
 }
 

@@ -173,7 +173,8 @@ enum {
   GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
   GLOC_REG_OPT_NN_SRC_PER_LANE = 3, /* culled search tuning: source points per lane (1, 2 or 4) */
   GLOC_REG_OPT_NN_JOB_GROUP = 4     /* culled search tuning: jobs whose work-groups are interleaved in the
-                                       launch order (their scans share the caches); default 60 */
+                                       launch order (their scans share the caches); default 24.  A multiple of
+                                       8 keeps each job's work-groups on one XCD, i.e. its scans in one L2 */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

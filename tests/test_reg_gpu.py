@@ -315,6 +315,33 @@ def test_batch_multi_equals_one_query_at_a_time(capi, scans):
     store.close()
 
 
+def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
+    """After EVERY number of ICP passes the correspondences and distances of the last (warm-started) pass of
+    the culled search equal those of the exhaustive kernel, bit for bit -- full-size scans, a positive and a
+    different-scene candidate, with and without the RANSAC stage in front."""
+    q, cands = scans["B"], [scans["A"], scans["C"]]
+    store = capi.ScanStore()
+    qid = store.add(q)
+    cids = [store.add(c) for c in cands]
+
+    def run(mode, iters, ransac):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_MODE, mode)
+        out = r.batch_ids(qid, cids, params=capi.default_reg_params(ransac_iters=ransac, icp_iters=iters))
+        corr = [r.debug_corr(j, len(q)) for j in range(2)]
+        r.close()
+        return out, corr
+
+    for iters, ransac in ((1, 0), (2, 0), (3, 0), (6, 0), (12, 0), (4, 300), (9, 300)):
+        ref_out, ref_corr = run(capi.REG_NN_EXHAUSTIVE, iters, ransac)
+        out, corr = run(capi.REG_NN_CULLED, iters, ransac)
+        for j in range(2):
+            assert (corr[j][0] == ref_corr[j][0]).all(), (iters, ransac, j)
+            assert (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), (iters, ransac, j)
+        assert (out["inliers"] == ref_out["inliers"]).all() and np.abs(out["T"] - ref_out["T"]).max() < 2e-6
+    store.close()
+
+
 def test_degenerate_inputs(reg, capi):
     prm = capi.default_reg_params(ransac_iters=50, icp_iters=2)
     two = np.array([[0, 0, 0], [1, 0, 0]], np.float32)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgloc3d.so")
-SOURCES = ["common.hip", "knn.hip", "scan_store.hip", "reg.hip", "vlad.hip", "bev.hip", "ground.hip"]
+SOURCES = ["common.hip", "knn.hip", "scan_store.hip", "reg.hip", "vlad.hip", "bev.hip", "ground.hip", "coarse.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact kernels must reproduce the reference's un-fused fp32 arithmetic
 EXTRA = os.environ.get("GLOC3D_EXTRA_FLAGS", "").split()

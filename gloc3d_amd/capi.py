@@ -62,6 +62,11 @@ BEV_U8_HWC3, BEV_F32_CHW = 0, 1
 GROUND_OPT_KNN_EXHAUSTIVE = 1
 
 
+class CoarseParams(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("cell_px", C.c_uint32), ("n_yaw", C.c_uint32), ("max_shift", C.c_uint32),
+                ("top_yaw", C.c_uint32), ("refine", C.c_uint32), ("min_overlap", C.c_float), ("reserved_", C.c_uint32)]
+
+
 class GroundParams(C.Structure):
     _fields_ = [("near_range2", C.c_float), ("knn", C.c_uint32), ("plane_thresh", C.c_float),
                 ("ransac_iters", C.c_uint32), ("ransac_conf", C.c_float), ("reserved_", C.c_uint32),
@@ -158,6 +163,15 @@ _PROTOS = [
     ("gloc_bev_raw_image", _i, [_vp, _sz, _vp, _sz]),
     ("gloc_bev_set_profile", _i, [_vp, _i]),
     ("gloc_bev_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("gloc_bev_device_flags", _i, [_vp, _sz, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
+    ("gloc_coarse_default_params", _i, [_vp]),
+    ("gloc_coarse_create", _i, [_i, C.POINTER(_vp)]),
+    ("gloc_coarse_destroy", _i, [_vp]),
+    ("gloc_coarse_add_image", _i, [_vp, _vp, _u32, _u32, C.c_float, C.c_float, C.c_float, _vp, C.POINTER(_u32)]),
+    ("gloc_coarse_add_scan", _i, [_vp, _vp, _sz, _sz, _vp, C.POINTER(_u32)]),
+    ("gloc_coarse_release", _i, [_vp, _u32]),
+    ("gloc_coarse_cells", _i, [_vp, _u32, C.POINTER(_u32), _vp, _sz]),
+    ("gloc_coarse_match", _i, [_vp, _u32, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("gloc_ground_default_params", _i, [_vp]),
     ("gloc_ground_create", _i, [_i, C.POINTER(_vp)]),
     ("gloc_ground_destroy", _i, [_vp]),
@@ -687,6 +701,67 @@ class BevProjector:
         ms, n = C.c_double(), C.c_uint64()
         check(lib().gloc_bev_profile(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def default_coarse_params(**over):
+    p = CoarseParams()
+    check(lib().gloc_coarse_default_params(C.byref(p)))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class CoarseMatcher:
+    """Coarse global (x, y, yaw) match on BEV occupancy grids (RpyPCLoopDetector::match on two
+    OccupancyGrids, registration/loop_detector.cpp:186-288)."""
+
+    def __init__(self, device=0, params=None):
+        self._h = C.c_void_p()
+        check(lib().gloc_coarse_create(device, C.byref(self._h)))
+        self.params = params or default_coarse_params()
+
+    def close(self):
+        if self._h:
+            lib().gloc_coarse_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_image(self, occupancy, ox, oy, resolution):
+        img = np.ascontiguousarray(occupancy, np.uint8)
+        gid = C.c_uint32()
+        check(lib().gloc_coarse_add_image(self._h, _np_ptr(img), img.shape[1], img.shape[0], ox, oy, resolution,
+                                          C.byref(self.params), C.byref(gid)))
+        return gid.value
+
+    def add_scan(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        gid = C.c_uint32()
+        check(lib().gloc_coarse_add_scan(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1], C.byref(self.params),
+                                         C.byref(gid)))
+        return gid.value
+
+    def release(self, grid_id):
+        check(lib().gloc_coarse_release(self._h, int(grid_id)))
+
+    def cells(self, grid_id):
+        n = C.c_uint32()
+        check(lib().gloc_coarse_cells(self._h, int(grid_id), C.byref(n), None, 0))
+        out = np.empty(n.value, np.uint32)
+        check(lib().gloc_coarse_cells(self._h, int(grid_id), C.byref(n), _np_ptr(out), n.value))
+        return out
+
+    def match(self, q_grid, db_grids):
+        ids = np.ascontiguousarray(db_grids, np.uint32)
+        n = ids.shape[0]
+        xyyaw, ratio, ok = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        check(lib().gloc_coarse_match(self._h, int(q_grid), _np_ptr(ids), n, C.byref(self.params), _np_ptr(xyyaw),
+                                      _np_ptr(ratio), _np_ptr(ok)))
+        return xyyaw, ratio, ok.astype(bool)
 
 
 def default_ground_params(**over):

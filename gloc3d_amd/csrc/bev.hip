@@ -247,6 +247,16 @@ int gloc_bev_raw_image(gloc_bev* h, size_t scan, uint8_t* out, size_t capacity) 
   return GLOC_OK;
 }
 
+int gloc_bev_device_flags(gloc_bev* h, size_t scan, const uint8_t** d_flags, int* R, int* S) {
+  GLOC_REQUIRE(h && d_flags && R && S, GLOC_ERR_INVALID, "NULL argument");
+  GLOC_REQUIRE(scan < h->last_scans, GLOC_ERR_STATE, "scan %zu is not part of the last projection (%zu scans)",
+               scan, h->last_scans);
+  *d_flags = h->multi.as<uint8_t>() + scan * (size_t)h->last_S * h->last_S;
+  *R = h->last_R;
+  *S = h->last_S;
+  return GLOC_OK;
+}
+
 int gloc_bev_set_profile(gloc_bev* h, int enable) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "handle is NULL");
   h->prof.enabled = enable != 0;

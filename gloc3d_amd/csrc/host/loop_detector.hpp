@@ -3,9 +3,12 @@
 // guards, over the C ABI (include/gloc3d.h).  Differences, all forced by scope:
 //   * the descriptor comes from the caller (the CNN backbone is upstream of the hot path);
 //     get_projected_grid / get_place_input are the BEV projection in front of it;
-//   * match() is the 3-D registration (RANSAC-SVD + ICP) of north_star, not the 2-D SURF match.
+//   * match(scan, db_idx, xy_yaw, scale) is the coarse 2-D match on the BEV grids (an exhaustive yaw x shift
+//     search instead of SURF + FLANN + RANSAC-affine); the batched match() is the 3-D registration
+//     (RANSAC-SVD + ICP) of north_star, seeded by it.
 // Not thread-safe; single caller thread, like the reference.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -26,8 +29,16 @@ class RpyPCLoopDetector {
       throw std::runtime_error(e);
     }
     gloc_reg_default_params(&reg_params_);
+    if (gloc_coarse_create(device, &coarse_) != GLOC_OK) {
+      std::string e = gloc_last_error();
+      gloc_reg_destroy(reg_);
+      gloc_knn_destroy(knn_);
+      throw std::runtime_error(e);
+    }
+    gloc_coarse_default_params(&coarse_params_);
   }
   ~RpyPCLoopDetector() {
+    gloc_coarse_destroy(coarse_);
     gloc_bev_destroy(bev_);
     gloc_reg_destroy(reg_);
     gloc_knn_destroy(knn_);
@@ -44,8 +55,46 @@ class RpyPCLoopDetector {
     uint32_t sid = 0;
     check(gloc_reg_scan_upload(reg_, scan_xyzi, n_pts, 4, &sid));
     db_scan_ids_.push_back(sid);
+    uint32_t gid = 0;  // db_grids_.push_back(grid), loop_detector.cpp:16-19
+    check(gloc_coarse_add_scan(coarse_, scan_xyzi, n_pts, 4, &coarse_params_, &gid));
+    db_grid_ids_.push_back(gid);
     db_size_++;
   }
+
+  // match(q_grid, db_idx, xy_yaw, scale) of the reference (loop_detector.cpp:186-288): the coarse pose of
+  // the query in place db_idx's frame, p_db = R(yaw) p_q + (x, y); the estimated scale is 1 by
+  // construction.  Here the query goes in as its scan (its grid is made on the device).
+  bool match(const float* q_scan_xyzi, size_t n_pts, size_t db_idx, float xy_yaw[3], double& estimated_scale) {
+    std::vector<float> out(3);
+    std::vector<int> ok(1);
+    match_2d(q_scan_xyzi, n_pts, {db_idx}, out, ok);
+    xy_yaw[0] = out[0]; xy_yaw[1] = out[1]; xy_yaw[2] = out[2];
+    estimated_scale = 1.0;
+    return ok[0] != 0;
+  }
+  void match_2d(const float* q_scan_xyzi, size_t n_pts, const std::vector<size_t>& db_indices,
+                std::vector<float>& xy_yaw /* n x 3 */, std::vector<int>& ok) {
+    const size_t n = db_indices.size();
+    xy_yaw.assign(3 * n, 0.f);
+    ok.assign(n, 0);
+    if (n == 0) return;
+    uint32_t qg = 0;
+    check(gloc_coarse_add_scan(coarse_, q_scan_xyzi, n_pts, 4, &coarse_params_, &qg));
+    std::vector<uint32_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = db_grid_ids_.at(db_indices[i]);
+    const int rc = gloc_coarse_match(coarse_, qg, ids.data(), n, &coarse_params_, xy_yaw.data(), nullptr, ok.data());
+    gloc_coarse_release(coarse_, qg);
+    check(rc);
+  }
+  // (x, y, yaw) -> 4x4: R = RollPitchYaw(0, 0, yaw), t = (x, y, 0) (global_localization.cpp:526-530)
+  static Mat4 embed_3d(const float* xy_yaw) {
+    Mat4 T = identity4();
+    const float c = std::cos(xy_yaw[2]), s = std::sin(xy_yaw[2]);
+    T[0] = c; T[1] = -s; T[4] = s; T[5] = c;
+    T[3] = xy_yaw[0]; T[7] = xy_yaw[1];
+    return T;
+  }
+  bool use_coarse_match = true;  // match(): seed the 3-D registration with the 2-D match when no guess is given
 
   // global localization (loop_detector.cpp:22-46).  Leaves the vectors untouched when the
   // database is too small ("Not enough keyframes in database.", :27-30).
@@ -85,6 +134,16 @@ class RpyPCLoopDetector {
   int match(const float* q_scan_xyzi, size_t n_pts, const std::vector<size_t>& db_indices,
             Mat4& pose_in_db, std::vector<Mat4>* all_poses = nullptr, std::vector<int>* all_ok = nullptr,
             const std::vector<Mat4>* init_guess = nullptr) {
+    std::vector<Mat4> coarse_init;
+    if (!init_guess && use_coarse_match && !db_indices.empty()) {
+      std::vector<float> xy_yaw;
+      std::vector<int> ok2d;
+      match_2d(q_scan_xyzi, n_pts, db_indices, xy_yaw, ok2d);
+      coarse_init.resize(db_indices.size());
+      for (size_t i = 0; i < db_indices.size(); ++i)
+        coarse_init[i] = ok2d[i] ? embed_3d(&xy_yaw[3 * i]) : identity4();
+      init_guess = &coarse_init;
+    }
     uint32_t qid = 0;
     check(gloc_reg_scan_upload(reg_, q_scan_xyzi, n_pts, 4, &qid));
     int r;
@@ -202,6 +261,9 @@ class RpyPCLoopDetector {
   gloc_knn* knn_ = nullptr;
   gloc_reg* reg_ = nullptr;
   gloc_bev* bev_ = nullptr;
+  gloc_coarse* coarse_ = nullptr;
+  gloc_coarse_params coarse_params_{};
+  std::vector<uint32_t> db_grid_ids_;
   int device_ = 0;
   gloc_reg_params reg_params_{};
   std::vector<uint32_t> db_scan_ids_;

@@ -30,10 +30,14 @@ class RpyPCLoopDetector:
         self._bev = None                         # created on first use
         self._ground = None
         self._device = device
+        self._coarse = capi.CoarseMatcher(device)  # db_grids_ (loop_detector.h:108) as search grids
+        self._db_grid_ids = []
+        self.use_coarse_match = True             # match(): seed the 3-D registration with the 2-D match
 
     def close(self):
         self._index.close()
         self._reg.close()
+        self._coarse.close()
         if self._bev is not None:
             self._bev.close()
         if self._ground is not None:
@@ -80,6 +84,7 @@ class RpyPCLoopDetector:
         d = np.ascontiguousarray(descriptor, np.float32).reshape(1, self.k_dim_)
         self._index.add(d)
         self._db_scan_ids.append(self._reg.scan_upload(scan))
+        self._db_grid_ids.append(self._coarse.add_scan(scan))   # loop_detector.cpp:16-19: the place's grid
         self._last_descriptor = d
 
     def detect(self, q_descriptor):
@@ -106,14 +111,39 @@ class RpyPCLoopDetector:
             return True, n - 1, int(idx[0, 0])
         return False, None, None
 
-    def match(self, q_scan, db_indices):
+    def match_2d(self, q_scan, db_indices):
+        """RpyPCLoopDetector::match(q_grid, db_idx, xy_yaw, scale) (loop_detector.cpp:186-288) for several
+        places at once: the coarse pose of the query in each place's frame, p_db = R(yaw) p_q + (x, y).
+        Returns (xy_yaw [n, 3], overlap ratio [n], ok [n]); the scale the reference estimates is 1 here."""
+        qg = self._coarse.add_scan(np.ascontiguousarray(q_scan, np.float32))
+        try:
+            return self._coarse.match(qg, [self._db_grid_ids[int(i)] for i in db_indices])
+        finally:
+            self._coarse.release(qg)
+
+    @staticmethod
+    def embed_3d(xy_yaw):
+        """(x, y, yaw) -> 4x4: R = RollPitchYaw(0, 0, yaw), t = (x, y, 0) (global_localization.cpp:526-530)."""
+        x, y, yaw = (float(v) for v in xy_yaw)
+        T = np.eye(4, dtype=np.float32)
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        T[:2, :2] = [[c, -s_], [s_, c]]
+        T[0, 3], T[1, 3] = x, y
+        return T
+
+    def match(self, q_scan, db_indices, init_T=None):
         """Register the query scan against the retrieved places in one batch; returns
-        (rank of the first successful candidate or -1, its 4x4 pose query->db, full result)."""
+        (rank of the first successful candidate or -1, its 4x4 pose query->db, full result).
+        Unless the caller gives initial poses, every candidate whose coarse 2-D match succeeds starts
+        from it (the reference composes its pose from that match, global_localization.cpp:519-572)."""
         ids = [self._db_scan_ids[int(i)] for i in db_indices]
         q = np.ascontiguousarray(q_scan, np.float32)
+        if init_T is None and self.use_coarse_match and len(ids):
+            xy_yaw, _, ok2d = self.match_2d(q, db_indices)
+            init_T = np.stack([self.embed_3d(v) if o else np.eye(4, dtype=np.float32) for v, o in zip(xy_yaw, ok2d)])
         qid = self._reg.scan_upload(q)
         try:
-            res = self._reg.batch_ids(qid, ids, params=self.reg_params)
+            res = self._reg.batch_ids(qid, ids, params=self.reg_params, init_T=init_T)
         finally:
             self._reg.scan_release(qid)  # the query scan is transient: HBM stays flat over a run
         r = capi.reg_select_first_ok(res["ok"].astype(np.int32))

@@ -341,9 +341,57 @@ int gloc_bev_project_batch_device(gloc_bev* h, const float* d_xyz, const uint64_
 /* The uncropped single-channel image of scan `scan` of the last projection (the occupancy_grid
  * get_place_feature hands back, loop_detector.cpp:139-140): [height][width] u8 into `out`. */
 int gloc_bev_raw_image(gloc_bev* h, size_t scan, uint8_t* out, size_t capacity);
+/* Device pointer of the column flags of scan `scan` of the last projection: flags[(iy + R) * S + (ix + R)]
+ * != 0 iff the BEV pixel of voxel column (ix, iy) is occupied (value 0 in the image).  Valid until the
+ * next projection on this handle; used by the coarse matcher to stay on the device. */
+int gloc_bev_device_flags(gloc_bev* h, size_t scan, const uint8_t** d_flags, int* R, int* S);
 int gloc_bev_set_profile(gloc_bev* h, int enable);
 /* kernel families: "bev_clear", "bev_mark", "bev_flag", "bev_image" */
 int gloc_bev_profile(gloc_bev* h, const char* kernel, double* total_ms, uint64_t* launches);
+
+/* ============================ coarse global (x, y, yaw) match (row a-12) =================== *
+ * Replaces RpyPCLoopDetector::match(q_grid, db_idx, xy_yaw, scale) (registration/loop_detector.cpp:186-288):
+ * the coarse pose of the query in a database place's frame from their two BEV occupancy images,
+ * p_db = R(yaw) p_q + (x, y).  The reference finds it with SURF keypoints + FLANN matching + a RANSAC
+ * partial-affine fit (OpenCV + contrib, absent here); this finds it with an exhaustive integer search on
+ * the GPU -- every yaw step x every shift, scored by how many occupied query cells land on occupied
+ * database cells (coarse_kernels.hpp) -- so a reverse-direction revisit is handled as well as a small
+ * offset.  The result seeds the 3-D registration (init_T of gloc_reg_batch*), as the reference seeds its pose
+ * composition (global_localization.cpp:526-570).  Parity: unpinned upstream (third-party arithmetic, no
+ * fixtures); oracle/coarse_oracle.c states the search step by step and the GPU equals it exactly. */
+typedef struct gloc_coarse gloc_coarse;
+
+typedef struct gloc_coarse_params {
+  float resolution;    /* 0.2 m: the BEV pixel (loop_detector.h:116) */
+  uint32_t cell_px;    /* 2: a search cell is cell_px x cell_px pixels (0.4 m) */
+  uint32_t n_yaw;      /* 360 yaw steps */
+  uint32_t max_shift;  /* 64 cells: |x|, |y| <= 25.6 m */
+  uint32_t top_yaw;    /* 12: yaw steps verified in 2-D (the identity is always verified too) */
+  uint32_t refine;     /* 4 cells: 2-D window around the best x / y lags */
+  float min_overlap;   /* 0.25: ok iff overlapping cells >= this x occupied query cells (and >= 16 cells) */
+  uint32_t reserved_;
+} gloc_coarse_params;
+
+int gloc_coarse_default_params(gloc_coarse_params* p);
+int gloc_coarse_create(int device, gloc_coarse** out);
+int gloc_coarse_destroy(gloc_coarse* h);
+/* A place's grid from its occupancy image as get_projected_grid returns it (OccupancyGrid of
+ * loop_detector.h:36-39: [height][width] u8, below 100 = occupied as the reference's threshold,
+ * ox_oy_res) -- what add_keyframe keeps in db_grids_ (loop_detector.cpp:16-19). */
+int gloc_coarse_add_image(gloc_coarse* h, const uint8_t* occupancy, uint32_t width, uint32_t height, float ox,
+                          float oy, float resolution, const gloc_coarse_params* params, uint32_t* grid_id);
+/* The same straight from the scan (BEV projection at 0.2 m / 100 m on the device, no image round trip). */
+int gloc_coarse_add_scan(gloc_coarse* h, const float* xyz, size_t n, size_t stride_floats,
+                         const gloc_coarse_params* params, uint32_t* grid_id);
+int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id);
+/* Occupied cells of a grid ((v << 16) | u, u / v in [0, 512): cell u spans the pixels
+ * (u - 256) cell_px .. + cell_px - 1); out_cells may be NULL to get the count only. */
+int gloc_coarse_cells(gloc_coarse* h, uint32_t grid_id, uint32_t* n_cells, uint32_t* out_cells,
+                      size_t capacity);
+/* One query grid against n_db database grids: out_xy_yaw [n_db][3] = (x, y, yaw in (-pi, pi]),
+ * out_ratio = overlapping / occupied query cells, out_ok (either may be NULL). */
+int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
+                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok);
 
 /* ============================ ground pre-alignment ("next" row N3) ========================= *
  * Replaces GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228),

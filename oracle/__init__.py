@@ -129,6 +129,15 @@ def lib():
                                              _f32p, C.POINTER(GroundInfo)]
         L.oracle_ground_transform_from_plane.argtypes = [_f32p, _f32p]
         L.oracle_jacobi_eig3.argtypes = [_f64p, _f64p]
+        L.oracle_coarse_grid_from_image.restype = C.c_void_p
+        L.oracle_coarse_grid_from_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                                    C.c_float, C.c_uint32]
+        L.oracle_coarse_grid_free.argtypes = [C.c_void_p]
+        L.oracle_coarse_grid_cells.restype = C.c_uint32
+        L.oracle_coarse_grid_cells.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_coarse_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_float, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -357,3 +366,35 @@ def ground_transform_from_plane(plane):
     T = np.empty(16, np.float32)
     lib().oracle_ground_transform_from_plane(np.ascontiguousarray(plane, np.float32), T)
     return T.reshape(4, 4)
+
+
+# ---- coarse global (x, y, yaw) match (row a-12) ---------------------------------------------------
+
+class CoarseGrid:
+    """A scan's coarse search grid from its BEV occupancy image (0 = occupied) and (ox, oy, res)."""
+
+    def __init__(self, img, ox, oy, res, cell_px=2):
+        img = np.ascontiguousarray(img, np.uint8)
+        self._g = lib().oracle_coarse_grid_from_image(img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0],
+                                                      ox, oy, res, cell_px)
+        self.res, self.cell_px = res, cell_px
+
+    def __del__(self):
+        try:
+            lib().oracle_coarse_grid_free(self._g)
+        except Exception:
+            pass
+
+    def cells(self):
+        n = lib().oracle_coarse_grid_cells(self._g, None)
+        out = np.empty(n, np.uint32)
+        lib().oracle_coarse_grid_cells(self._g, out.ctypes.data_as(C.c_void_p))
+        return out
+
+
+def coarse_match(q, d, n_yaw=360, max_shift=64, top_yaw=12, refine=4, min_overlap=0.25):
+    xyyaw = np.empty(3, np.float32)
+    ratio, ok, over, k = C.c_float(), C.c_int(), C.c_uint32(), C.c_uint32()
+    lib().oracle_coarse_match(q._g, d._g, q.res, q.cell_px, n_yaw, max_shift, top_yaw, refine, min_overlap, xyyaw,
+                              C.byref(ratio), C.byref(ok), C.byref(over), C.byref(k))
+    return dict(xy_yaw=xyyaw, ratio=ratio.value, ok=bool(ok.value), overlap=over.value, k=k.value)

@@ -148,6 +148,19 @@ void oracle_reg_many_mt(const float* src_xyz, size_t n_src, const float* const* 
 void oracle_pose_error(const float* T_gt16, const float* T_est16, float* err_rot_deg,
                        float* err_pos);
 
+/* ---- coarse global (x, y, yaw) match on BEV occupancy grids (row a-12; coarse_oracle.c) ---------- */
+typedef struct oracle_coarse_grid oracle_coarse_grid;
+/* img: [h][w] u8, < 100 = occupied (loop_detector.cpp:196); pixel (x, y) at metric (ox + x res, oy + y res) */
+oracle_coarse_grid* oracle_coarse_grid_from_image(const uint8_t* img, uint32_t w, uint32_t h, float ox,
+                                                  float oy, float res, uint32_t cell_px);
+void oracle_coarse_grid_free(oracle_coarse_grid* g);
+/* occupied cells ((v << 16) | u) in row-major order; returns the count (out may be NULL) */
+uint32_t oracle_coarse_grid_cells(const oracle_coarse_grid* g, uint32_t* out);
+void oracle_coarse_match(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float res, uint32_t cell_px,
+                         uint32_t n_yaw, uint32_t max_shift, uint32_t top_yaw, uint32_t refine, float min_overlap,
+                         float* out_xy_yaw, float* out_ratio, int* out_ok, uint32_t* out_overlap,
+                         uint32_t* out_k);
+
 /* ---- BEV occupancy projection ("next" row N1; bev_oracle.c) --------------------------------- */
 
 typedef struct oracle_bev_info {

@@ -181,6 +181,9 @@ def main():
                     help="N > 1: B queries per rank per step (weak scaling) or one query per step "
                          "with its candidates sharded over the ranks (strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--collectives", choices=["capi", "torch"], default="capi",
+                    help="N > 1: the two all-gathers through the C ABI's own RCCL communicator "
+                         "(gloc_knn_search_sharded, gloc_comm_all_gather_device) or through torch.distributed")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each step's queries inline")
@@ -287,8 +290,26 @@ def main():
     params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS,
                                      min_inlier_ratio=MIN_INLIER_RATIO, max_rmse=MAX_RMSE)
 
-    knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank),
-                             comm_device=comm_dev)
+    capi_knn, collectives = None, "none"
+    if world > 1 and args.collectives == "capi" and args.backend == "nccl" and not args.same_device:
+        try:
+            comm = capi.Comm(local_rank, rank, world, sharded.torch_exchange(dev))
+            capi_knn = sharded.CapiShardedKnn(index, comm)
+            collectives = "capi (gloc_knn_search_sharded + gloc_comm_all_gather_device, RCCL)"
+        except Exception as e:   # loud, and recorded in the JSON line: never a silent change of path
+            print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
+    if world > 1:
+        ok_all = torch.tensor([1 if capi_knn is not None else 0], device=comm_dev or dev)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)     # all ranks take the same path
+        if int(ok_all.item()) == 0:
+            capi_knn = None
+    if capi_knn is not None:
+        knn = capi_knn
+    else:
+        knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank),
+                                 comm_device=comm_dev)
+        if world > 1:
+            collectives = f"torch.distributed ({args.backend})"
 
     def scans_of(places):
         """global place ids [.., n] (-1 = none) -> resident scan ids (every rank holds all scans)."""
@@ -359,7 +380,7 @@ def main():
         t2 = time.time()
         a, b = my_slice(i)
         if args.mode == "throughput":
-            tables = qreg.register_many(ids, cand, dev, register_multi)          # [world*B, 20, 19]
+            tables = qreg.register_many(ids, cand, dev, register_multi, capi_knn=capi_knn)   # [world*B, 20, 19]
             sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
         else:
             table = sreg.register(ids[0], cand[0], dev)
@@ -472,7 +493,7 @@ def main():
                                  + ("inline" if args.no_prefetch else "prefetched one step ahead on a second host thread + stream"),
                    "ransac_iters_cap": RANSAC_ITERS, "ransac_confidence": float(params.ransac_confidence),
                    "min_inlier_ratio": MIN_INLIER_RATIO, "max_rmse": MAX_RMSE, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
-                   "nn_mode": args.nn_mode,
+                   "nn_mode": args.nn_mode, "collectives": collectives,
                    "parallelism": (f"1 gpu, {B} queries registered per batch on one stream") if world == 1 else (
                        f"{B} queries per gpu per step; "
                        f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "

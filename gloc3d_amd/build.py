@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgloc3d.so")
-SOURCES = ["common.hip", "knn.hip", "scan_store.hip", "reg.hip", "vlad.hip", "bev.hip", "ground.hip", "coarse.hip"]
+SOURCES = ["common.hip", "comm.hip", "knn.hip", "scan_store.hip", "reg.hip", "vlad.hip", "bev.hip", "ground.hip", "coarse.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the exact kernels must reproduce the reference's un-fused fp32 arithmetic
 EXTRA = os.environ.get("GLOC3D_EXTRA_FLAGS", "").split()
@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
         # Linked WITHOUT a NEEDED entry for libamdhip64: the host process decides which HIP runtime
         # it runs on (PyTorch bundles its own; two runtimes in one process cannot share the GPU).
         # gloc3d_amd.capi preloads one with RTLD_GLOBAL; the C++ command lines link /opt/rocm's.
-        run(["g++", "-shared", "-fPIC", "-o", LIB] + objs)
+        run(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -108,6 +108,14 @@ _PROTOS = [
     ("gloc_knn_search", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     ("gloc_knn_search_device", _i, [_vp, _vp, _sz, _sz, _sz, _sz, _u64, _vp, _vp]),
     ("gloc_topk_merge_device", _i, [_i, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    ("gloc_comm_unique_id", _i, [_vp]),
+    ("gloc_comm_create", _i, [_i, _i, _i, _vp, C.POINTER(_vp)]),
+    ("gloc_comm_destroy", _i, [_vp]),
+    ("gloc_comm_rank", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("gloc_comm_all_gather_device", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("gloc_knn_search_sharded", _i, [_vp, _vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp]),
+    ("gloc_knn_search_sharded_host", _i, [_vp, _vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp]),
+    ("gloc_comm_all_gather_host", _i, [_vp, _vp, _vp, _sz]),
     ("gloc_knn_get_stats", _i, [_vp, C.POINTER(KnnStats)]),
     ("gloc_knn_profile", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     ("gloc_knn_profile_reset", _i, [_vp]),
@@ -319,6 +327,11 @@ class KnnIndex:
         check(lib().gloc_knn_search_device(self._h, C.c_void_p(q_ptr), nq, k, first_row, last,
                                            index_offset, C.c_void_p(idx_ptr), C.c_void_p(d2_ptr)))
 
+    def search_sharded(self, comm, q_ptr, nq, k, idx_ptr, d2_ptr, index_stride=1, index_offset=0):
+        """Collective: top-k over the whole row-sharded database (RCCL all-gather + merge on the device)."""
+        check(lib().gloc_knn_search_sharded(self._h, comm._h, C.c_void_p(q_ptr), nq, k, index_stride, index_offset,
+                                            C.c_void_p(idx_ptr), C.c_void_p(d2_ptr)))
+
     def stats(self):
         s = KnnStats()
         check(lib().gloc_knn_get_stats(self._h, C.byref(s)))
@@ -331,6 +344,37 @@ class KnnIndex:
 
     def profile_reset(self):
         check(lib().gloc_knn_profile_reset(self._h))
+
+
+class Comm:
+    """RCCL communicator of this process's GPU (gloc_comm_*).  `exchange(id_bytes or None) -> id_bytes`
+    broadcasts rank 0's 128-byte id to every rank (e.g. over torch.distributed or a shared file)."""
+
+    def __init__(self, device, rank, world, exchange):
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(lib().gloc_comm_unique_id(uid))
+        data = exchange(bytes(uid) if rank == 0 else None)
+        assert len(data) == 128
+        uid = (C.c_uint8 * 128).from_buffer_copy(data)
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        check(lib().gloc_comm_create(device, rank, world, uid, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().gloc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_device(self, send_ptr, recv_ptr, bytes_per_rank, stream=0):
+        check(lib().gloc_comm_all_gather_device(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), bytes_per_rank,
+                                                C.c_void_p(stream or 0)))
 
 
 def topk_merge_device(device, stream, idx_ptr, d2_ptr, n_lists, nq, k, out_idx_ptr, out_d2_ptr):

@@ -10,10 +10,18 @@
 // valset order.  A 4th argument selects ground alignment as in the reference (:584-588): every db
 // and query scan is pre-aligned by gloc_ground_estimate (:431-436, :495-499), registration runs on
 // the aligned clouds and the pose is carried back with Tdb_l2g^-1 * T * Tq_l2g (:527-541).
+//
+// Multi-GPU (one process per GPU; SURVEY.md 8e -- the reference is single-GPU): start N copies with
+//   GLOC_WORLD=N GLOC_RANK=r GLOC_COMM_ID_FILE=/shared/path [GLOC_DEVICE=ordinal, default r]
+// The descriptor database is interleave-sharded over the ranks; every query's retrieval is collective
+// (local top-k -> RCCL all-gather over xGMI -> merge: gloc_knn_search_sharded); query q is registered by
+// rank q % N against that rank's replica of the scan store; rank 0 gathers the results and reports.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <thread>
 #include <memory>
 #include <stdexcept>
 
@@ -33,10 +41,43 @@ struct GlocEvaluator {
   std::vector<std::pair<size_t, Mat4>> located;  // {db idx, pose in db}
   double time_sum_match = 0, times_call_match = 0;
   bool align_ground = false;
+  int rank = 0, world = 1, device = 0;
+  gloc_comm* comm = nullptr;
   gloc_ground* ground = nullptr;
   std::vector<Mat4> db_rpz_estimates;  // T_l2g per database scan (:393)
 
-  ~GlocEvaluator() { gloc_ground_destroy(ground); }
+  ~GlocEvaluator() {
+    gloc_ground_destroy(ground);
+    det.reset();
+    gloc_comm_destroy(comm);
+  }
+
+  // GLOC_WORLD / GLOC_RANK / GLOC_COMM_ID_FILE: rank 0 publishes the RCCL id through the file
+  void init_comm() {
+    const char* w = std::getenv("GLOC_WORLD");
+    world = w ? std::atoi(w) : 1;
+    rank = std::getenv("GLOC_RANK") ? std::atoi(std::getenv("GLOC_RANK")) : 0;
+    device = std::getenv("GLOC_DEVICE") ? std::atoi(std::getenv("GLOC_DEVICE")) : (w ? rank : 0);
+    if (!w) return;
+    const char* path = std::getenv("GLOC_COMM_ID_FILE");
+    if (world < 1 || rank < 0 || rank >= world || !path) throw std::runtime_error("GLOC_WORLD / GLOC_RANK / GLOC_COMM_ID_FILE");
+    uint8_t id[128];
+    if (rank == 0) {
+      if (gloc_comm_unique_id(id) != GLOC_OK) throw std::runtime_error(gloc_last_error());
+      const std::string tmp = std::string(path) + ".tmp";
+      std::ofstream(tmp, std::ios::binary).write(reinterpret_cast<const char*>(id), 128);
+      if (std::rename(tmp.c_str(), path) != 0) throw std::runtime_error("cannot publish the communicator id");
+    } else {
+      bool got = false;
+      for (int i = 0; i < 1200 && !got; ++i) {  // up to two minutes
+        std::ifstream f(path, std::ios::binary);
+        got = f && f.read(reinterpret_cast<char*>(id), 128) && f.gcount() == 128;
+        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+      if (!got) throw std::runtime_error("timed out waiting for the communicator id file");
+    }
+    if (gloc_comm_create(device, rank, world, id, &comm) != GLOC_OK) throw std::runtime_error(gloc_last_error());
+  }
 
   // EsitmateGroundAndTransform: the scan is replaced by its ground-aligned copy; returns T_l2g
   Mat4 align(std::vector<float>& scan) {
@@ -56,7 +97,8 @@ struct GlocEvaluator {
   }
 
   void construct_db() {  // :419-449
-    det.reset(new RpyPCLoopDetector(dim));
+    det.reset(new RpyPCLoopDetector(dim, device));
+    if (comm) det->attach_comm(comm);
     double t_add = 0, t_align = 0;
     for (size_t i = 0; i < vs.db_files.size(); ++i) {
       std::vector<float> scan = read_lidar_kitti(vs.db_files[i]);
@@ -89,6 +131,7 @@ struct GlocEvaluator {
       t_det += now_ms() - t0;
       queried_idx.push_back(idx);
       if (idx.empty()) continue;
+      if ((int)(q % (size_t)world) != rank) continue;  // registered by another rank
       std::vector<float> scan = read_lidar_kitti(vs.q_files[q]);
       Mat4 Tq_l2g = identity4();
       if (align_ground) Tq_l2g = align(scan);
@@ -112,6 +155,21 @@ struct GlocEvaluator {
       }
     }
     std::printf("Each query cost: %f ms.\n", t_det / std::max<size_t>(1, vs.q_files.size()));
+    if (comm && world > 1) {  // every rank's (db idx, pose) rows -> all ranks; row q is valid on rank q % world
+      const size_t nq = vs.q_files.size(), row = 17;
+      std::vector<float> mine(nq * row, 0.f), all(nq * row * (size_t)world);
+      for (size_t q = 0; q < nq; ++q) {
+        mine[q * row] = (float)located[q].first;  // < 2^24: exact
+        std::copy(located[q].second.begin(), located[q].second.end(), mine.begin() + q * row + 1);
+      }
+      if (gloc_comm_all_gather_host(comm, mine.data(), all.data(), mine.size() * sizeof(float)) != GLOC_OK)
+        throw std::runtime_error(gloc_last_error());
+      for (size_t q = 0; q < nq; ++q) {
+        const float* r = all.data() + ((q % (size_t)world) * nq + q) * row;
+        located[q].first = (size_t)r[0];
+        std::copy(r + 1, r + 17, located[q].second.begin());
+      }
+    }
   }
 
   void recognition_recalls() {  // :221-268
@@ -205,13 +263,16 @@ int main(int argc, char* argv[]) {
     return 1;
   }
   try {
+    g.init_comm();
     g.construct_db();
     g.locate_all_query();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "fatal: %s\n", e.what());
     return 1;
   }
-  g.recognition_recalls();
-  g.registration_recalls();
+  if (g.rank == 0) {  // the report (and the two failure files) once
+    g.recognition_recalls();
+    g.registration_recalls();
+  }
   return 0;
 }

@@ -48,10 +48,24 @@ class RpyPCLoopDetector {
 
   const int NUM_EXCLUDE_RECENT = 30;  // loop_detector.h:77
 
+  // Multi-GPU (the reference is single-GPU): with a communicator attached BEFORE the first
+  // add_keyframe, place g's descriptor lives on rank g % world (interleaved row shards), every rank keeps
+  // all scans and grids, and detect() is collective: local top-k -> RCCL all-gather -> merge, the same
+  // result on every rank as on one GPU.  The SLAM-mode detect is not available in this mode.
+  void attach_comm(gloc_comm* comm) {
+    if (db_size_) throw std::runtime_error("attach_comm: the database is not empty");
+    comm_ = comm;
+    rank_ = 0;
+    world_ = 1;
+    if (comm && gloc_comm_rank(comm, &rank_, &world_) != GLOC_OK) throw std::runtime_error(gloc_last_error());
+  }
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+
   // add_keyframe (loop_detector.cpp:10-20): one descriptor + its scan (x,y,z,i quadruples).
   void add_keyframe(const std::vector<float>& descriptor, const float* scan_xyzi, size_t n_pts) {
     if (descriptor.size() != k_dim_) throw std::runtime_error("descriptor length != k_dim_");
-    check(gloc_knn_add(knn_, descriptor.data(), 1));
+    if (!comm_ || (int)(db_size_ % (size_t)world_) == rank_) check(gloc_knn_add(knn_, descriptor.data(), 1));
     uint32_t sid = 0;
     check(gloc_reg_scan_upload(reg_, scan_xyzi, n_pts, 4, &sid));
     db_scan_ids_.push_back(sid);
@@ -111,6 +125,7 @@ class RpyPCLoopDetector {
   // tree_making_period_ calls the searchable window is refreshed to db[0 : end-30]; a loop is
   // accepted iff the best SQUARED distance is below 0.8 (:54, loop_detector.h:103).
   bool detect(size_t& q_idx, size_t& loop_idx, const std::vector<float>& last_descriptor) {
+    if (comm_) throw std::runtime_error("SLAM-mode detect is not available with a sharded database");
     if (db_size_ <= num_exclude_recent_ + top_k_) return false;
     if (tree_making_period_counter_ % tree_making_period_ == 0)
       searchable_end_ = db_size_ - num_exclude_recent_;
@@ -245,7 +260,11 @@ class RpyPCLoopDetector {
     std::vector<uint64_t> i64(top_k_);
     idx.resize(top_k_);   // loop_detector.cpp:42-43
     d2.resize(top_k_);
-    check(gloc_knn_search(knn_, q, 1, top_k_, first, last, i64.data(), d2.data()));
+    if (comm_)
+      check(gloc_knn_search_sharded_host(knn_, comm_, q, 1, top_k_, (uint64_t)world_, (uint64_t)rank_, i64.data(),
+                                         d2.data()));
+    else
+      check(gloc_knn_search(knn_, q, 1, top_k_, first, last, i64.data(), d2.data()));
     for (size_t i = 0; i < top_k_; ++i) idx[i] = (size_t)i64[i];
   }
 
@@ -262,6 +281,8 @@ class RpyPCLoopDetector {
   gloc_reg* reg_ = nullptr;
   gloc_bev* bev_ = nullptr;
   gloc_coarse* coarse_ = nullptr;
+  gloc_comm* comm_ = nullptr;
+  int rank_ = 0, world_ = 1;
   gloc_coarse_params coarse_params_{};
   std::vector<uint32_t> db_grid_ids_;
   int device_ = 0;

@@ -7,6 +7,7 @@
 #include <vector>
 #include <new>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "knn_kernels.hpp"
 #include "synth_kernels.hpp"
@@ -25,6 +26,7 @@ struct gloc_knn {
   DevBuf dn_max;    // 1 x uint32 (bits of the largest row norm)
   DevBuf dist;      // exact: [nq][ld]; mfma: [splits][Qpad][ld]
   DevBuf keys;      // select output [nq][K]
+  DevBuf shard_ws;  // gloc_knn_search_sharded: local + gathered lists
   DevBuf klists, klists2;  // per-chunk K-lists during selection
   DevBuf exact;     // rerank: reference-order distances [nq][KC]
   DevBuf keys2;     // rerank output [nq][k]
@@ -270,7 +272,8 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 }
 
 int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_t first_row,
-                       size_t last_row, uint64_t index_offset, uint64_t* d_idx, float* d_d2) {
+                       size_t last_row, uint64_t index_offset, uint64_t* d_idx, float* d_d2,
+                       uint64_t index_stride = 1) {
   GLOC_REQUIRE(h && d_q && d_idx && d_d2, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(k >= 1 && k <= 256, GLOC_ERR_INVALID, "k = %zu outside [1,256]", k);
   GLOC_REQUIRE(nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "nq = %zu outside [1,2^20]", nq);
@@ -310,7 +313,7 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
     ProfScope ps(h->prof, "finalize", h->stream);
     const size_t total = nq * k;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       h->stream, keys_out, total, index_offset, d_idx, d_d2);
+                       h->stream, keys_out, total, index_offset, index_stride, d_idx, d_d2);
     GLOC_HIP(hipGetLastError());
   }
   return GLOC_OK;
@@ -350,6 +353,7 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->dn_max.release();
   h->dist.release();
   h->keys.release();
+  h->shard_ws.release();
   h->klists.release();
   h->klists2.release();
   h->exact.release();
@@ -553,6 +557,60 @@ int gloc_knn_search_device(gloc_knn* h, const float* d_queries, size_t nq, size_
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   return search_device_impl(h, d_queries, nq, k, first_row, last_row, index_offset, d_out_idx,
                             d_out_d2);
+}
+
+int gloc_knn_search_sharded(gloc_knn* h, gloc_comm* comm, const float* d_queries, size_t nq, size_t k,
+                            uint64_t index_stride, uint64_t index_offset, uint64_t* d_out_idx,
+                            float* d_out_d2) {
+  GLOC_REQUIRE(h && comm && d_queries && d_out_idx && d_out_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(comm->device == h->device, GLOC_ERR_INVALID, "communicator on device %d, index on %d", comm->device,
+               h->device);
+  GLOC_REQUIRE(index_stride >= 1, GLOC_ERR_INVALID, "index_stride must be >= 1");
+  GLOC_REQUIRE((size_t)comm->world * k <= 1024, GLOC_ERR_INVALID, "shards x k = %zu exceeds 1024",
+               (size_t)comm->world * k);
+  const size_t G = (size_t)comm->world, cnt = nq * k;
+  // [local idx | local d2 | gathered idx | gathered d2]
+  GLOC_TRY(h->shard_ws.ensure(cnt * 12 + G * cnt * 12 + 64, h->stream));
+  uint64_t* li = h->shard_ws.as<uint64_t>();
+  uint64_t* gi = li + cnt;
+  float* ld = reinterpret_cast<float*>(gi + G * cnt);
+  float* gd = ld + cnt;
+  // this shard's top-k with GLOBAL row indices ...
+  GLOC_TRY(search_device_impl(h, d_queries, nq, k, 0, (size_t)-1, index_offset, li, ld, index_stride));
+  if (G == 1) {
+    GLOC_HIP(hipMemcpyAsync(d_out_idx, li, cnt * sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream));
+    GLOC_HIP(hipMemcpyAsync(d_out_d2, ld, cnt * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return GLOC_OK;
+  }
+  // ... all-gathered over xGMI: one fused launch for the two small arrays ([shard][nq][k], what K3 reads) ...
+  GLOC_TRY(gloc::comm::group_begin());
+  int rc = gloc::comm::all_gather(comm, li, gi, cnt * sizeof(uint64_t), h->stream);
+  if (rc == GLOC_OK) rc = gloc::comm::all_gather(comm, ld, gd, cnt * sizeof(float), h->stream);
+  const int rc2 = gloc::comm::group_end();
+  GLOC_TRY(rc);
+  GLOC_TRY(rc2);
+  // ... and merged on every rank in the same (d2, idx) order: a replicated result, equal to the one-GPU search
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(64), 0, h->stream, gi, gd, (int)G, (int)nq, (int)k,
+                     d_out_idx, d_out_d2);
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
+int gloc_knn_search_sharded_host(gloc_knn* h, gloc_comm* comm, const float* queries, size_t nq, size_t k,
+                                 uint64_t index_stride, uint64_t index_offset, uint64_t* out_idx, float* out_d2) {
+  GLOC_REQUIRE(h && queries && out_idx && out_d2, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(k >= 1 && k <= 256 && nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "bad nq / k");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_TRY(h->stage_q.ensure(nq * h->dim * sizeof(float), h->stream));
+  GLOC_TRY(h->stage_idx.ensure(nq * k * sizeof(uint64_t), h->stream));
+  GLOC_TRY(h->stage_d2.ensure(nq * k * sizeof(float), h->stream));
+  GLOC_HIP(hipMemcpyAsync(h->stage_q.p, queries, nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GLOC_TRY(gloc_knn_search_sharded(h, comm, h->stage_q.as<float>(), nq, k, index_stride, index_offset,
+                                   h->stage_idx.as<uint64_t>(), h->stage_d2.as<float>()));
+  GLOC_HIP(hipMemcpyAsync(out_idx, h->stage_idx.p, nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  GLOC_HIP(hipMemcpyAsync(out_d2, h->stage_d2.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  return GLOC_OK;
 }
 
 int gloc_knn_search(gloc_knn* h, const float* queries, size_t nq, size_t k, size_t first_row,

@@ -515,8 +515,9 @@ __global__ __launch_bounds__(64) void rerank_final_kernel(
   if (lane == 0) flags[q] = complete ? 0 : 1;
 }
 
-// keys -> (u64 index + offset, f32 d2); sentinel -> (UINT64_MAX, FLT_MAX)
-__global__ void finalize_kernel(const uint64_t* __restrict__ keys, size_t n, uint64_t offset,
+// keys -> (u64 index * stride + offset, f32 d2); sentinel -> (UINT64_MAX, FLT_MAX).  stride / offset place a
+// shard's local rows in the global database (contiguous shards: stride 1; interleaved: stride = shards).
+__global__ void finalize_kernel(const uint64_t* __restrict__ keys, size_t n, uint64_t offset, uint64_t stride,
                                 uint64_t* __restrict__ out_idx, float* __restrict__ out_d2) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -525,7 +526,7 @@ __global__ void finalize_kernel(const uint64_t* __restrict__ keys, size_t n, uin
     out_idx[i] = ~0ull;
     out_d2[i] = 3.402823466e+38f;
   } else {
-    out_idx[i] = (uint64_t)(uint32_t)k + offset;
+    out_idx[i] = (uint64_t)(uint32_t)k * stride + offset;
     out_d2[i] = ord2f((uint32_t)(k >> 32));
   }
 }

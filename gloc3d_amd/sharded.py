@@ -69,6 +69,47 @@ class ShardedKnn:
         return self.merge(all_i, all_d)
 
 
+class CapiShardedKnn:
+    """The same search with the collective BELOW the C ABI (gloc_knn_search_sharded): local search ->
+    one fused RCCL all-gather of the per-shard lists -> merge on the device, all on one stream, no host
+    hop.  `comm` is a gloc3d_amd.capi.Comm; the index holds this rank's interleaved shard."""
+
+    def __init__(self, index, comm):
+        self.index, self.comm = index, comm
+        self.side = torch.cuda.Stream()
+        index.set_stream(self.side.cuda_stream)
+
+    def search(self, q, k):
+        Q = q.shape[0]
+        idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+        d2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        self.index.search_sharded(self.comm, q.data_ptr(), Q, k, idx.data_ptr(), d2.data_ptr(),
+                                  index_stride=self.comm.world, index_offset=self.comm.rank)
+        cur.wait_stream(self.side)
+        return idx, d2
+
+    def all_gather_tables(self, tables):
+        """tables: this rank's [K, n, RESULT_COLS] float32 device tensor -> [world * K, n, RESULT_COLS]."""
+        t = tables.contiguous()
+        out = torch.empty((self.comm.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        cur = torch.cuda.current_stream()
+        self.comm.all_gather_device(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), cur.cuda_stream)
+        return out.view((self.comm.world * t.shape[0],) + tuple(t.shape[1:]))
+
+
+def torch_exchange(device):
+    """exchange() for capi.Comm over an initialised torch.distributed group: broadcast of rank 0's id."""
+    def fn(data):
+        t = torch.zeros(128, dtype=torch.uint8, device=device)
+        if data is not None:
+            t.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return fn
+
+
 class ShardedRegistrar:
     """Candidate-sharded registration: each rank registers the candidates whose scans it owns."""
 
@@ -128,7 +169,7 @@ class QueryParallelRegistrar:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out.to(device).view(self.world, n, RESULT_COLS)
 
-    def register_many(self, my_queries, cand_global_all, device, register_multi):
+    def register_many(self, my_queries, cand_global_all, device, register_multi, capi_knn=None):
         """K queries per rank in flight (K = len(my_queries)): a step handles G*K queries, rank r owning
         rows r*K .. r*K+K-1 of cand_global_all [G*K, n].  register_multi(query handles [K], global place
         ids [K, n] (-1 = none)) -> float32 [K, n, RESULT_COLS] registers them in ONE batch (every kernel
@@ -142,6 +183,8 @@ class QueryParallelRegistrar:
         t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
         if self.world == 1:
             return t.to(device).view(K, n, RESULT_COLS)
+        if capi_knn is not None:   # the all-gather through the C ABI's communicator
+            return capi_knn.all_gather_tables(t.to(device).view(K, n, RESULT_COLS))
         t = t.to(self.comm_device or device)
         out = torch.empty((self.world * K * n, RESULT_COLS), dtype=torch.float32, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)

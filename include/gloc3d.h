@@ -117,6 +117,35 @@ int gloc_topk_merge_device(int device, void* hip_stream, const uint64_t* d_idx, 
                            size_t n_lists, size_t nq, size_t k, uint64_t* d_out_idx,
                            float* d_out_d2);
 
+/* ---- multi-GPU through the C ABI (one process per GPU, RCCL over xGMI) ------------ *
+ * The descriptor database is row-sharded over the ranks of a communicator; queries are replicated.
+ * librccl is bound at run time (the copy already in the process -- PyTorch's -- else GLOC3D_RCCL, else
+ * /opt/rocm/lib).  Rank 0 makes the 128-byte id and hands it to the others by any channel (a file,
+ * MPI, torch.distributed); every rank then calls gloc_comm_create (ncclCommInitRank: collective). */
+typedef struct gloc_comm gloc_comm;
+int gloc_comm_unique_id(uint8_t* id128);
+int gloc_comm_create(int device, int rank, int world, const uint8_t* id128, gloc_comm** out);
+int gloc_comm_destroy(gloc_comm* c);
+int gloc_comm_rank(const gloc_comm* c, int* rank, int* world);
+/* d_recv[r * bytes_per_rank ..] = rank r's d_send; enqueued on hip_stream (result tables of a step). */
+int gloc_comm_all_gather_device(gloc_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank,
+                                void* hip_stream);
+/* Top-k over the WHOLE row-sharded database, replicated on every rank and bit-equal to the one-GPU
+ * search: this rank's shard is searched (local row l is global row l * index_stride + index_offset:
+ * stride = world, offset = rank for the interleaved layout; stride 1, offset = first row for contiguous
+ * shards), the per-shard (d2, idx) lists are all-gathered in ONE fused RCCL launch on the handle's
+ * stream, and merged by (d2, idx) on the device (K3).  No host hop, no host synchronisation beyond the
+ * search's own.  Collective: every rank calls it with the same nq and k. */
+int gloc_knn_search_sharded(gloc_knn* h, gloc_comm* comm, const float* d_queries, size_t nq, size_t k,
+                            uint64_t index_stride, uint64_t index_offset, uint64_t* d_out_idx,
+                            float* d_out_d2);
+
+/* Host-buffer forms (the C++ command line's sharded mode): staged through the device, synchronous. */
+int gloc_knn_search_sharded_host(gloc_knn* h, gloc_comm* comm, const float* queries, size_t nq, size_t k,
+                                 uint64_t index_stride, uint64_t index_offset, uint64_t* out_idx,
+                                 float* out_d2);
+int gloc_comm_all_gather_host(gloc_comm* c, const void* send, void* recv, size_t bytes_per_rank);
+
 /* Counters since creation: searches on each path, queries that needed the exact fallback. */
 typedef struct gloc_knn_stats {
   uint64_t searches_exact, searches_mfma, queries_total, queries_fallback;

@@ -171,6 +171,35 @@ def test_merge_eight_lists(capi, oracle_mod):
     assert (bits(md.cpu().numpy()) == bits(od)).all()
 
 
+def test_sharded_search_through_the_c_abi_world_1(capi, oracle_mod):
+    """gloc_comm_* + gloc_knn_search_sharded on the one GPU of this box (an RCCL communicator of one rank):
+    the collective path runs end to end and equals the plain search; interleaved global indices."""
+    import torch
+    from gloc3d_amd import sharded, synth
+    N, D, Q, k = 3000, 128, 19, 20
+    db = synth.descriptors_iid(41, 0, N, D)
+    q = synth.descriptors_iid(42, 0, Q, D)
+    comm = capi.Comm(0, 0, 1, lambda data: data)
+    ix = _index(capi, db, 0)
+    knn = sharded.CapiShardedKnn(ix, comm)
+    idx, d2 = knn.search(torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    oi, od = oracle_mod.knn_search(db, q, k)
+    assert (idx.cpu().numpy().astype(np.uint64) == oi).all() and (bits(d2.cpu().numpy()) == bits(od)).all()
+    # stride / offset: what rank 3 of 8 would report for its local rows
+    di = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+    dd = torch.empty((Q, k), dtype=torch.float32, device="cuda")
+    ix.search_sharded(comm, torch.from_numpy(q).cuda().data_ptr(), Q, k, di.data_ptr(), dd.data_ptr(), 8, 3)
+    ix.synchronize()
+    assert (di.cpu().numpy().astype(np.uint64) == oi * 8 + 3).all()
+    t = torch.arange(2 * 5 * 19, dtype=torch.float32, device="cuda").view(2, 5, 19)
+    g = knn.all_gather_tables(t)
+    torch.cuda.synchronize()
+    assert (g == t).all()
+    ix.close()
+    comm.close()
+
+
 def test_on_device_generator_matches_numpy(capi):
     import torch
     from gloc3d_amd import synth

@@ -104,6 +104,14 @@ def test_command_lines(dataset):
     errs = re.findall(r"err_pos, err_rot: ([\d.eE+-]+), ([\d.eE+-]+)", out)
     assert len(errs) == 3 * N_Q
     assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) > 0.9
+    # sharded mode below the C ABI (gloc_comm_* + gloc_knn_search_sharded), on the one GPU of this box: a
+    # communicator of one rank, the collective path end to end, the same report
+    env = dict(os.environ, GLOC_WORLD="1", GLOC_RANK="0", GLOC_COMM_ID_FILE=str(d / "comm.id"))
+    p = subprocess.run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
+                        str(d / "desc.bin")], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rec1 = dict((int(k), float(v)) for k, v in re.findall(r"Recall @ (\d+): ([\d.eE+-]+)", p.stdout))
+    assert rec1 == rec and float(re.search(r"Success rate: ([\d.eE+-]+)", p.stdout).group(1)) == 1.0
     # a TorchScript model path instead of descriptors: explained, not crashed
     p = subprocess.run([os.path.join(bindir, "global_localization"), str(d / "valset.txt"), str(d / "poses.txt"),
                         str(d / "valset.txt")], cwd=d, capture_output=True, text=True)

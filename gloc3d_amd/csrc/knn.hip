@@ -26,6 +26,7 @@ struct gloc_knn {
   DevBuf dn_max;    // 1 x uint32 (bits of the largest row norm)
   DevBuf dist;      // exact: [nq][ld]; mfma: [splits][Qpad][ld]
   DevBuf keys;      // select output [nq][K]
+  DevBuf n_incomplete;  // 1 x u64: queries the MFMA path sent to the exact fallback (device counter)
   DevBuf shard_ws;  // gloc_knn_search_sharded: local + gathered lists
   DevBuf klists, klists2;  // per-chunk K-lists during selection
   DevBuf exact;     // rerank: reference-order distances [nq][KC]
@@ -68,10 +69,26 @@ int update_norms(gloc_knn* h, size_t first, size_t count) {
 
 // ---- exact path ------------------------------------------------------------------------------
 int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n_range,
-                      size_t ld) {
+                      size_t ld, const int* only_flagged = nullptr) {
   ProfScope ps(h->prof, "dist_exact", h->stream);
-  const int QT = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  const int QT = only_flagged ? 1 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1)));
   const int qgroups = (nq + QT - 1) / QT;
+  if (nq <= 2 && !getenv("GLOC3D_KNN_NO_SMALL")) {
+    // one or two queries: the streaming form (one wave per work-group, all group sums before the chains);
+    // measured against the general kernel at 4541 x 4096: Q = 1 18.6 vs 33 us, Q = 2 equal, Q = 4 / 8 slower
+    const int G = (int)h->dim >> 2, Gs = std::min(G, EXS_G);
+    float* dist = h->dist.as<float>();
+    const float* db = h->rows.as<float>();
+#define LAUNCH_SMALL(QT_, RW_)                                                                             \
+  hipLaunchKernelGGL((dist_exact_small_kernel<QT_, RW_>), dim3((unsigned)((n_range + RW_ - 1) / RW_), (unsigned)qgroups), \
+                     dim3(64), sizeof(float) * (QT_ * RW_) * (Gs + 4), h->stream, db, d_q, dist, (int)h->dim, \
+                     first, n_range, nq, ld, only_flagged)
+    if (QT == 2) LAUNCH_SMALL(2, 4);
+    else LAUNCH_SMALL(1, 4);
+#undef LAUNCH_SMALL
+    GLOC_HIP(hipGetLastError());
+    return GLOC_OK;
+  }
   // rows per wave: fill the chip with >= ~2048 waves when the window is small, up to 64/QT
   int RW = 64 / QT;
   while (RW > 4 && (long long)((n_range + RW - 1) / RW) * qgroups < 2048) RW >>= 1;
@@ -82,7 +99,7 @@ int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n
   const float* db = h->rows.as<float>();
 #define LAUNCH_EXACT(QT_)                                                                      \
   hipLaunchKernelGGL(dist_exact_kernel<QT_>, grid, block, 0, h->stream, db, d_q, dist,         \
-                     (int)h->dim, first, n_range, nq, RW, ld)
+                     (int)h->dim, first, n_range, nq, RW, ld, only_flagged)
   switch (QT) {
     case 8: LAUNCH_EXACT(8); break;
     case 4: LAUNCH_EXACT(4); break;
@@ -95,20 +112,27 @@ int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n
 }
 
 // Per-query top-K of h->dist: chunked threshold selection + merge(s).  MODE as select_chunk_kernel.
+constexpr int SELECT_ONE_BLOCK_MAX = 16384;  // rows one work-group per query selects from in one launch
+
 template <int MODE>
-int run_select(gloc_knn* h, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
-               int n_splits, uint64_t* d_keys_out) {
+int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
+               int n_splits, uint64_t* d_keys_out, const int* only_flagged = nullptr) {
   ProfScope ps(h->prof, "select", h->stream);
   const int per_group = SEL_LIST / K;  // lists one merge can take
   int E = (n_range + 256 * per_group - 1) / (256 * per_group);
   E = std::max(E, 8);
   E = std::min(E, std::max(1, SEL_LIST / K));
+  // the device-side fallback (only_flagged) selects with ONE work-group per query, so that no merge
+  // launch is needed (measured for the main path: one work-group per query over 10 000 rows takes 47 us,
+  // five chunks + one merge 18 + 10 us -- the main path keeps its chunks)
+  const int e_one = (n_range + 255) / 256;
+  if (only_flagged && n_range <= SELECT_ONE_BLOCK_MAX && e_one <= std::max(1, SEL_LIST / K)) E = std::max(e_one, 1);
   int nlists = (n_range + 256 * E - 1) / (256 * E);
   GLOC_TRY(h->klists.ensure((size_t)nq * nlists * K * sizeof(uint64_t), h->stream));
   uint64_t* cur = nlists == 1 ? d_keys_out : h->klists.as<uint64_t>();
   hipLaunchKernelGGL(select_chunk_kernel<MODE>, dim3(nlists, nq), dim3(256), 0, h->stream,
-                     h->dist.as<float>(), ld, strideP, n_splits, h->qnorm.as<float>(),
-                     h->norms.as<float>(), first, n_range, K, E, cur);
+                     h->dist.as<float>(), ld, strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim,
+                     h->norms.as<float>(), first, n_range, K, E, cur, only_flagged);
   GLOC_HIP(hipGetLastError());
   bool flip = false;
   while (nlists > 1) {
@@ -136,7 +160,7 @@ int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_
   const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
   GLOC_TRY(h->dist.ensure((size_t)nq * ld * sizeof(float), h->stream));
   GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld));
-  return run_select<0>(h, nq, k, first, n_range, ld, 0, 1, d_keys_out);
+  return run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out);
 }
 
 // ---- MFMA path -------------------------------------------------------------------------------
@@ -208,11 +232,9 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   GLOC_TRY(h->qnorm.ensure((size_t)nq * sizeof(float), h->stream));
   GLOC_TRY(h->keys.ensure((size_t)nq * KC * sizeof(uint64_t), h->stream));
   GLOC_TRY(h->flags.ensure((size_t)nq * sizeof(int), h->stream));
-  {
-    ProfScope ps(h->prof, "norms", h->stream);
-    hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 3) / 4), dim3(256), 0, h->stream, d_q,
-                       (size_t)nq, (int)h->dim, h->qnorm.as<float>(), (uint32_t*)nullptr);
-    GLOC_HIP(hipGetLastError());
+  if (!h->n_incomplete.p) {
+    GLOC_TRY(h->n_incomplete.ensure(sizeof(unsigned long long), h->stream));
+    GLOC_HIP(hipMemsetAsync(h->n_incomplete.p, 0, sizeof(unsigned long long), h->stream));
   }
   {
     ProfScope ps(h->prof, "dist_mfma", h->stream);
@@ -227,7 +249,8 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 #undef MF
     GLOC_HIP(hipGetLastError());
   }
-  GLOC_TRY(run_select<1>(h, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));
+  // (the query norms of the coarse form are made by the select kernel, which leaves them in h->qnorm)
+  GLOC_TRY(run_select<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));
   {
     // rounding bound of the coarse distance against the reference-order distance:
     //   reference chain          (D/4 + 4) u d2
@@ -245,13 +268,22 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     hipLaunchKernelGGL(rerank_final_kernel, dim3(nq), dim3(64), 0, h->stream,
                        h->keys.as<uint64_t>(), h->exact.as<float>(), KC, k, n_range,
                        h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n,
-                       d_keys_out, h->flags.as<int>());
+                       d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>());
     GLOC_HIP(hipGetLastError());
   }
   h->stats.last_n_tile = (uint32_t)p.BN;
   h->stats.last_k_split = (uint32_t)p.KS;
   h->stats.last_candidates = (uint32_t)KC;
-  // completeness flags -> host; incomplete queries are redone on the exact path
+  if (n_range <= SELECT_ONE_BLOCK_MAX && k <= 2048 / std::max(1, (n_range + 255) / 256)) {
+    // Incomplete queries are redone on the exact path ON THE DEVICE: the two kernels are always
+    // launched and leave at once unless the query's flag is set -- no read-back, no host synchronisation.
+    // (The coarse partial dots in h->dist are dead by now: the exact distances of the flagged queries
+    // reuse the buffer, row q at q * ld.)
+    GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld, h->flags.as<int>()));
+    GLOC_TRY(run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out, h->flags.as<int>()));
+    return GLOC_OK;
+  }
+  // large windows: completeness flags -> host; incomplete queries are redone on the exact path
   if (h->h_flags_cap < (size_t)nq) {
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     h->h_flags = nullptr;
@@ -263,7 +295,6 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   GLOC_HIP(hipStreamSynchronize(h->stream));
   for (int q = 0; q < nq; ++q) {
     if (h->h_flags[q]) {
-      h->stats.queries_fallback++;
       GLOC_TRY(run_exact(h, d_q + (size_t)q * h->dim, 1, k, first, n_range,
                          d_keys_out + (size_t)q * k));
     }
@@ -353,6 +384,7 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->dn_max.release();
   h->dist.release();
   h->keys.release();
+  h->n_incomplete.release();
   h->shard_ws.release();
   h->klists.release();
   h->klists2.release();
@@ -651,6 +683,13 @@ int gloc_topk_merge_device(int device, void* hip_stream, const uint64_t* d_idx, 
 int gloc_knn_get_stats(const gloc_knn* h, gloc_knn_stats* out) {
   GLOC_REQUIRE(h && out, GLOC_ERR_INVALID, "null argument");
   *out = h->stats;
+  if (h->n_incomplete.p) {  // the fallback count lives on the device (no read-back on the search path)
+    unsigned long long c = 0;
+    GLOC_HIP(hipSetDevice(h->device));
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+    GLOC_HIP(hipMemcpy(&c, h->n_incomplete.p, sizeof(c), hipMemcpyDeviceToHost));
+    out->queries_fallback = c;
+  }
   return GLOC_OK;
 }
 

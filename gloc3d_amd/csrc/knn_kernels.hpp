@@ -82,10 +82,11 @@ __device__ __forceinline__ float exact_pairs_wave(const float* __restrict__ db,
       else
         qv[t] = f4u{0.f, 0.f, 0.f, 0.f};
     }
-    for (int r0 = 0; r0 < RW; r0 += 4) {
-      f4u dv[4];
+    constexpr int RU = 4;  // rows in flight per lane (8 and 16 measured slower: fewer waves per SIMD)
+    for (int r0 = 0; r0 < RW; r0 += RU) {
+      f4u dv[RU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RU; ++u) {
         const int r = r0 + u;
         const long long row = (r < RW) ? row_of(r) : -1;
         if (gv && row >= 0)
@@ -94,7 +95,7 @@ __device__ __forceinline__ float exact_pairs_wave(const float* __restrict__ db,
           dv[u] = f4u{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RU; ++u) {
         const int r = r0 + u;
         if (r < RW) {
 #pragma unroll
@@ -146,12 +147,15 @@ __global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict
                                                          const float* __restrict__ queries,
                                                          float* __restrict__ dist, int dim,
                                                          size_t first_row, int n_range, int nq,
-                                                         int RW, size_t ld) {
+                                                         int RW, size_t ld,
+                                                         const int* __restrict__ only_flagged /* QT = 1: run only
+                                                         for queries whose flag is set (device-side fallback) */) {
   __shared__ __attribute__((aligned(16))) float S_all[4 * 64 * S_PITCH];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* S = S_all + w * 64 * S_PITCH;
   const int row0 = (blockIdx.x * 4 + w) * RW;  // relative to first_row
   const int q0 = blockIdx.y * QT;
+  if (only_flagged && !only_flagged[q0]) return;  // uniform over the work-group
   const int nvq = (nq - q0) < QT ? (nq - q0) : QT;
   auto row_of = [&](int r) -> long long {
     const int rr = row0 + r;
@@ -162,6 +166,95 @@ __global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict
   if (lane < QT * RW) {
     const int t = lane / RW, r = lane % RW;
     if (t < nvq && row0 + r < n_range) dist[(size_t)(q0 + t) * ld + (size_t)(row0 + r)] = acc;
+  }
+}
+
+// K1 (exact form, few queries -- the reference's own pattern: kdtree_->query one descriptor at a time,
+// loop_detector.cpp:45).  One wave per work-group, QT queries x RW rows = P <= 8 pairs.  The group sums
+// of ALL dims are formed first, with no barrier in the loop, so the row reads pipeline (a wave keeps
+// (QT + RW) x U 16-byte loads in flight); then P lanes run the reference's sequential chain over them
+// from LDS.  The general kernel above interleaves the two per 64 groups and pays a dependent memory
+// round trip plus two barriers sixteen times per row: 33 us for 1 x 4541 x 4096, 28 % of the HBM rate.
+// Dynamic LDS: P x (Gs + 4) floats, Gs = min(dim / 4, EXS_G) groups per pass.
+constexpr int EXS_G = 2048;
+
+template <int QT, int RW>
+__global__ __launch_bounds__(64) void dist_exact_small_kernel(const float* __restrict__ db,
+                                                              const float* __restrict__ queries,
+                                                              float* __restrict__ dist, int dim, size_t first_row,
+                                                              int n_range, int nq, size_t ld,
+                                                              const int* __restrict__ only_flagged) {
+  extern __shared__ __attribute__((aligned(16))) float S_dyn[];
+  constexpr int P = QT * RW;
+  constexpr int U = (QT + RW) <= 5 ? 4 : 2;
+  const int lane = threadIdx.x;
+  const int row0 = blockIdx.x * RW;  // relative to first_row
+  const int q0 = blockIdx.y * QT;
+  if (only_flagged && !only_flagged[q0]) return;
+  const int nvq = (nq - q0) < QT ? (nq - q0) : QT;
+  const int G = dim >> 2;
+  const int Gs = G < EXS_G ? G : EXS_G, pitch = Gs + 4;
+  const float* rp[RW];
+  const float* qp[QT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int rr = (row0 + r) < n_range ? (row0 + r) : (n_range - 1);  // clamped: unconditional loads
+    rp[r] = db + (first_row + (size_t)rr) * dim;
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) qp[t] = queries + (size_t)(q0 + (t < nvq ? t : 0)) * dim;
+  float acc = 0.f;  // lanes 0..P-1: pair (t = lane / RW, r = lane % RW)
+  for (int g0 = 0; g0 < G; g0 += Gs) {
+    const int gn = (G - g0) < Gs ? (G - g0) : Gs;
+    for (int gb = 0; gb < gn; gb += 64 * U) {
+      f4u qv[QT][U], dv[RW][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = gb + u * 64 + lane, gc = g < gn ? g : gn - 1;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) qv[t][u] = *reinterpret_cast<const f4u*>(qp[t] + 4 * (size_t)(g0 + gc));
+#pragma unroll
+        for (int r = 0; r < RW; ++r) dv[r][u] = *reinterpret_cast<const f4u*>(rp[r] + 4 * (size_t)(g0 + gc));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = gb + u * 64 + lane;
+        if (g < gn) {
+#pragma unroll
+          for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+              const float e0 = qv[t][u].x - dv[r][u].x, e1 = qv[t][u].y - dv[r][u].y;
+              const float e2 = qv[t][u].z - dv[r][u].z, e3 = qv[t][u].w - dv[r][u].w;
+              S_dyn[(t * RW + r) * pitch + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA
+            }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane < P) {
+      const float* sp = S_dyn + lane * pitch;
+      int i = 0;
+      for (; i + 4 <= gn; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + i);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+      }
+      for (; i < gn; ++i) acc += sp[i];
+    }
+    __syncthreads();
+  }
+  if (lane < P) {
+    const int t = lane / RW, r = lane % RW;
+    if (t < nvq && row0 + r < n_range) {
+      for (int d = 4 * G; d < dim; ++d) {  // scalar tail (nanoflann.hpp:480-485)
+        const float e = qp[t][d] - rp[r][d];
+        acc += e * e;
+      }
+      dist[(size_t)(q0 + t) * ld + (size_t)(row0 + r)] = acc;
+    }
   }
 }
 
@@ -369,18 +462,37 @@ __device__ __forceinline__ uint64_t select_key(const float* __restrict__ row, si
   return make_key(d, (uint32_t)(first_row + (size_t)j));
 }
 
+// MODE 1 forms the query's squared norm itself (any summation order: it only feeds the coarse form; each
+// thread a chain of dim / 256 products, then a fixed tree) and leaves it in qn[q] for the re-rank kernels.
+// only_flagged (MODE 0): run only for queries whose flag is set (device-side fallback).
 template <int MODE>
 __global__ __launch_bounds__(256) void select_chunk_kernel(
     const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits,
-    const float* __restrict__ qn, const float* __restrict__ dn, size_t first_row, int n_range,
-    int K, int E, uint64_t* __restrict__ out_keys /* [nq][chunks][K] */) {
+    float* __restrict__ qn, const float* __restrict__ queries, int dim, const float* __restrict__ dn,
+    size_t first_row, int n_range, int K, int E, uint64_t* __restrict__ out_keys /* [nq][chunks][K] */,
+    const int* __restrict__ only_flagged) {
   __shared__ uint64_t buf[SEL_LIST];
   __shared__ int cnt;
+  __shared__ float qred[256];
   const int tid = threadIdx.x;
   const int q = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  if (only_flagged && !only_flagged[q]) return;  // uniform over the work-group
   const int j0 = chunk * 256 * E;
   const float* row = dist + (size_t)q * ld;
-  const float qnv = (MODE == 1) ? qn[q] : 0.f;
+  float qnv = 0.f;
+  if (MODE == 1) {
+    const float* qr = queries + (size_t)q * dim;
+    float s = 0.f;
+    for (int d = tid; d < dim; d += 256) s += qr[d] * qr[d];
+    qred[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) qred[tid] += qred[tid + o];
+      __syncthreads();
+    }
+    qnv = qred[0];
+    if (chunk == 0 && tid == 0) qn[q] = qnv;
+  }
   // pass A: thread minima
   uint64_t mn = KEY_SENTINEL;
   for (int e = 0; e < E; ++e) {
@@ -451,12 +563,17 @@ __device__ __forceinline__ float rerank_theta(float dk, float qnv, float dn_max,
   return dk + 2.f * eps;
 }
 
+// Group sums of ALL dims first (no barrier in the loop: the row loads pipeline), then the reference's
+// sequential chain over them by RR lanes: the first form (one chunk of 64 groups at a time, a dependent
+// global load per chunk) spent 22 us of a 152-us search waiting for sixteen round trips.
+constexpr int RR_G = 2048;  // groups held in LDS per pass: dim <= 8192 in one pass
+
 __global__ __launch_bounds__(64) void rerank_dist_kernel(
     const float* __restrict__ db, const float* __restrict__ queries, int dim,
     const uint64_t* __restrict__ cand, int KC, int k, const float* __restrict__ qn,
     const uint32_t* __restrict__ dn_max_bits, float eps_rel_d, float eps_rel_n,
     float* __restrict__ exact /* [nq][KC] */) {
-  __shared__ __attribute__((aligned(16))) float S[64 * S_PITCH];
+  __shared__ __attribute__((aligned(16))) float S[RR][RR_G];
   const int lane = threadIdx.x;
   const int q = blockIdx.y, p0 = blockIdx.x * RR;
   const uint64_t key = (lane < KC) ? cand[(size_t)q * KC + lane] : KEY_SENTINEL;
@@ -470,24 +587,65 @@ __global__ __launch_bounds__(64) void rerank_dist_kernel(
   const int m = __popcll(__ballot(valid && dco <= theta));
   if (p0 >= m) return;  // wave-uniform
   const int rw = (m - p0) < RR ? (m - p0) : RR;
-  uint32_t rows[RR];
+  const float* rowp[RR];
 #pragma unroll
-  for (int r = 0; r < RR; ++r) rows[r] = (uint32_t)__shfl((int)(uint32_t)key, (p0 + r) & 63);
-  auto row_of = [&](int r) -> long long {
-    if (r >= rw) return -1;
-    uint32_t v = rows[0];
+  for (int r = 0; r < RR; ++r) {
+    const uint32_t row = (uint32_t)__shfl((int)(uint32_t)key, (p0 + (r < rw ? r : 0)) & 63);
+    rowp[r] = db + (size_t)row * dim;
+  }
+  const float* qp = queries + (size_t)q * dim;
+  const int G = dim >> 2;
+  float acc = 0.f;  // lanes 0..rw-1: the chain of pair (q, row r = lane)
+  for (int g0 = 0; g0 < G; g0 += RR_G) {
+    const int gn = (G - g0) < RR_G ? (G - g0) : RR_G;
+    // four groups per lane and step, all (RR + 1) x 4 loads issued before the first use (clamped, so
+    // that they are unconditional): a wave is alone on its work-group and must hide the latency itself
+    for (int gb = 0; gb < gn; gb += 256) {
+      f4u qv[4], dv[RR][4];
 #pragma unroll
-    for (int i = 1; i < RR; ++i) v = (r == i) ? rows[i] : v;
-    return (long long)v;
-  };
-  const float d2 = exact_pairs_wave<1>(db, queries + (size_t)q * dim, dim, RR, row_of, 1, S);
-  if (lane < rw) exact[(size_t)q * KC + p0 + lane] = d2;
+      for (int u = 0; u < 4; ++u) {
+        const int g = gb + u * 64 + lane, gc = g < gn ? g : gn - 1;
+        qv[u] = *reinterpret_cast<const f4u*>(qp + 4 * (size_t)(g0 + gc));
+#pragma unroll
+        for (int r = 0; r < RR; ++r) dv[r][u] = *reinterpret_cast<const f4u*>(rowp[r] + 4 * (size_t)(g0 + gc));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = gb + u * 64 + lane;
+        if (g < gn) {
+#pragma unroll
+          for (int r = 0; r < RR; ++r) {
+            const float e0 = qv[u].x - dv[r][u].x, e1 = qv[u].y - dv[r][u].y, e2 = qv[u].z - dv[r][u].z,
+                        e3 = qv[u].w - dv[r][u].w;
+            S[r][g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA (as exact_pairs_wave)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane < rw) {
+      const float* sp = S[lane];
+      int i = 0;
+      for (; i + 4 <= gn; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + i);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+      }
+      for (; i < gn; ++i) acc += sp[i];
+    }
+    __syncthreads();
+  }
+  // (no scalar tail: the MFMA path, the only caller, requires dim % 4 == 0)
+  if (lane < rw) exact[(size_t)q * KC + p0 + lane] = acc;
 }
 
 __global__ __launch_bounds__(64) void rerank_final_kernel(
     const uint64_t* __restrict__ cand, const float* __restrict__ exact, int KC, int k, int n_range,
     const float* __restrict__ qn, const uint32_t* __restrict__ dn_max_bits, float eps_rel_d,
-    float eps_rel_n, uint64_t* __restrict__ out_keys, int* __restrict__ flags) {
+    float eps_rel_n, uint64_t* __restrict__ out_keys, int* __restrict__ flags,
+    unsigned long long* __restrict__ n_incomplete) {
   const int lane = threadIdx.x;
   const int q = blockIdx.x;
   const uint64_t key = (lane < KC) ? cand[(size_t)q * KC + lane] : KEY_SENTINEL;
@@ -512,7 +670,10 @@ __global__ __launch_bounds__(64) void rerank_final_kernel(
   }
   if (lane < m && rank < k) out_keys[(size_t)q * k + rank] = ek;
   for (int i = m + lane; i < k; i += 64) out_keys[(size_t)q * k + i] = KEY_SENTINEL;
-  if (lane == 0) flags[q] = complete ? 0 : 1;
+  if (lane == 0) {
+    flags[q] = complete ? 0 : 1;
+    if (!complete && n_incomplete) atomicAdd(n_incomplete, 1ull);
+  }
 }
 
 // keys -> (u64 index * stride + offset, f32 d2); sentinel -> (UINT64_MAX, FLT_MAX).  stride / offset place a

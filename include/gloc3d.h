@@ -105,7 +105,9 @@ int gloc_knn_search(gloc_knn* h, const float* queries, size_t nq, size_t k, size
 
 /* Same with device buffers, enqueued on the handle's stream; `index_offset` is added to every
  * returned index (a shard's first global row, for row-sharded databases).  Returns after the work
- * is enqueued and -- on the MFMA path -- after its completeness flag has been read back. */
+ * is enqueued: for windows of up to 16384 rows there is no host synchronisation at all (queries whose
+ * candidate set the MFMA path cannot prove complete are redone on the exact path by kernels that are
+ * always enqueued and leave at once otherwise); larger windows read the completeness flags back. */
 int gloc_knn_search_device(gloc_knn* h, const float* d_queries, size_t nq, size_t k,
                            size_t first_row, size_t last_row, uint64_t index_offset,
                            uint64_t* d_out_idx, float* d_out_d2);

@@ -93,6 +93,25 @@ def test_forced_fallback_still_exact(capi, oracle_mod):
     oi, od = oracle_mod.knn_search(db, q, 52)
     assert (idx == oi).all() and (bits(d2) == bits(od)).all()
     ix.close()
+    # rows that differ by less than the coarse form can resolve: the candidate set cannot be proven complete, the
+    # queries are redone on the exact path -- on the device, without a flag read-back (<= 16384 rows)
+    base = synth.descriptors_iid(35, 0, 1, 256)
+    db = (base + np.float32(2e-4) * synth.descriptors_iid(36, 0, 3000, 256)).astype(np.float32)
+    q = (base + np.float32(2e-4) * synth.descriptors_iid(37, 0, 24, 256)).astype(np.float32)
+    ix = _index(capi, db, 2)
+    idx, d2 = ix.search(q, 20)
+    oi, od = oracle_mod.knn_search(db, q, 20)
+    assert (bits(d2) == bits(od)).all() and (idx == oi).all()
+    assert ix.stats()["queries_fallback"] > 0
+    ix.close()
+    # the same above the device-side limit (flags read back, exact path per flagged query)
+    db = synth.descriptors_iid(33, 0, 17000, 64)
+    q = synth.descriptors_iid(34, 0, 12, 64)
+    ix = _index(capi, db, 2)
+    idx, d2 = ix.search(q, 52)
+    oi, od = oracle_mod.knn_search(db, q, 52)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    ix.close()
 
 
 def test_invalid_arguments(capi):

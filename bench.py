@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
     ap.add_argument("--scan-store", type=int, default=0,
                     help="distinct resident scans (0 = one per place up to 4541; places beyond alias modulo)")
+    ap.add_argument("--no-lone-query", action="store_true", help="skip the one-query-alone launches after the timed region (profiling runs)")
     ap.add_argument("--views-cache", default=None, help="npz cache of the ray-cast base views (profiling runs)")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-job-group", type=int, default=0, help="culled 1-NN tuning: jobs interleaved in the launch order")
@@ -472,6 +473,17 @@ def main():
                             "brute-force nn_kernel north_star names runs at 35.7 % of the fp32 peak "
                             "(--nn-mode exhaustive)"}
 
+    # one query alone (20 jobs per launch): the latency-bound end of the same kernel
+    if world == 1 and args.mode == "throughput" and not args.no_lone_query:
+        reg.profile_reset()
+        for j in range(3):
+            sid = store.add(q_scan_host[j].numpy())
+            ci, _ = knn.search(q_desc_host[j:j + 1].to(dev), TOP_K)
+            reg.batch_multi([sid], scans_of(ci.cpu().numpy()), params=params)
+            reg.scan_release(sid)
+        ms1, n1 = reg.profile("nn")
+        roofline["launch_ms_one_query_20_jobs"] = ms1 / max(n1, 1)
+
     q_per_rep = n_steps * per_step
     out = {
         "metric": "localization queries/sec (kNN+top-20 reg), KITTI-00-sized DB",
@@ -508,7 +520,8 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU checker (bounded sample) ...")
-        g_pos, g_neg = int(q_place[0]), int(q_place[0]) - (int(q_place[0]) % NEG_EVERY) + 1
+        g_pos = int(q_place[0]) + (1 if is_negative(int(q_place[0])) else 0)     # a same-world neighbour of query 0
+        g_neg = int(q_place[0]) - (int(q_place[0]) % NEG_EVERY) + 1               # the different-world place next to it
         sample = {"query": q_scan_host[0].numpy(), "positive": store.download(int(place_scan[g_pos])),
                   "negative": store.download(int(place_scan[g_neg]))}
         out["cpu_baseline"] = cpu_baseline(sample, n_places, MIN_INLIER_RATIO,

@@ -188,6 +188,10 @@ def main():
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each step's queries inline")
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
+    ap.add_argument("--coarse", action="store_true",
+                    help="also run the reference's 2-D step: the coarse (x, y, yaw) match of every (query, candidate) "
+                         "pair on their BEV grids seeds the 3-D registration (gloc_coarse_*); not part of the metric's "
+                         "default configuration")
     ap.add_argument("--scan-store", type=int, default=0,
                     help="distinct resident scans (0 = one per place up to 4541; places beyond alias modulo)")
     ap.add_argument("--no-lone-query", action="store_true", help="skip the one-query-alone launches after the timed region (profiling runs)")
@@ -312,6 +316,28 @@ def main():
         if world > 1:
             collectives = f"torch.distributed ({args.backend})"
 
+    # optional: the coarse 2-D match (one grid per place, made on the device from the resident scans)
+    cm, place_grid, cm_lock, cur_qgrids = None, None, threading.Lock(), {}
+    if args.coarse:
+        cm = capi.CoarseMatcher(local_rank)
+        place_grid = np.array([cm.add_store_scan(store, int(sid)) for sid in place_scan], np.uint32)
+        log(f"coarse grids: {n_store} places")
+
+    def coarse_init(q_ids, places):
+        """init_T [B, n, 4, 4] from the 2-D match of every (query, candidate) pair; identity where it fails."""
+        p = np.asarray(places, np.int64)
+        Bq, n = p.shape
+        qg = np.repeat(np.array([cur_qgrids[int(q)] for q in q_ids], np.uint32), n)
+        dg = place_grid[np.clip(p, 0, None).reshape(-1) % n_store]
+        with cm_lock:
+            xy_yaw, _, ok2 = cm.match_pairs(qg, dg)
+        T = np.tile(np.eye(4, dtype=np.float32), (Bq * n, 1, 1))
+        c, s_ = np.cos(xy_yaw[:, 2]), np.sin(xy_yaw[:, 2])
+        use = ok2 & (p.reshape(-1) >= 0)
+        T[use, 0, 0], T[use, 0, 1], T[use, 1, 0], T[use, 1, 1] = c[use], -s_[use], s_[use], c[use]
+        T[use, 0, 3], T[use, 1, 3] = xy_yaw[use, 0], xy_yaw[use, 1]
+        return T.reshape(Bq, n, 4, 4)
+
     def scans_of(places):
         """global place ids [.., n] (-1 = none) -> resident scan ids (every rank holds all scans)."""
         p = np.asarray(places, np.int64)
@@ -320,7 +346,8 @@ def main():
         return out
 
     def register_multi(q_ids, places):
-        r = reg.batch_multi(q_ids, scans_of(places), params=params)
+        init = coarse_init(q_ids, places) if cm is not None else None
+        r = reg.batch_multi(q_ids, scans_of(places), params=params, init_T=init)
         return sharded.pack_results(r, np.asarray(places).shape)
 
     def local_register(q_id, local_rows, ranks):   # latency mode: this rank's share of one query's candidates
@@ -344,6 +371,10 @@ def main():
         t0 = time.time()
         a, b = my_slice(i)
         ids = [store.add(q_scan_host[j].numpy()) for j in range(a, b)]
+        if cm is not None:
+            with cm_lock:
+                for sid in ids:
+                    cur_qgrids[sid] = cm.add_store_scan(store, sid)
         q0 = i * per_step
         qd = q_desc_host[q0:q0 + per_step].to(dev, non_blocking=True)
         return ids, qd, time.time() - t0
@@ -388,6 +419,9 @@ def main():
             sel = [sreg.select_first_ok(table)]
         for sid in ids:
             reg.scan_release(sid)
+            if cm is not None:
+                with cm_lock:
+                    cm.release(cur_qgrids.pop(sid))
         t3 = time.time()
         if record:
             stage["prep_wait"] += t1 - t0
@@ -505,7 +539,7 @@ def main():
                                  + ("inline" if args.no_prefetch else "prefetched one step ahead on a second host thread + stream"),
                    "ransac_iters_cap": RANSAC_ITERS, "ransac_confidence": float(params.ransac_confidence),
                    "min_inlier_ratio": MIN_INLIER_RATIO, "max_rmse": MAX_RMSE, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
-                   "nn_mode": args.nn_mode, "collectives": collectives,
+                   "nn_mode": args.nn_mode, "collectives": collectives, "coarse_2d_match": bool(args.coarse),
                    "parallelism": (f"1 gpu, {B} queries registered per batch on one stream") if world == 1 else (
                        f"{B} queries per gpu per step; "
                        f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "

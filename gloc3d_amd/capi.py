@@ -177,6 +177,8 @@ _PROTOS = [
     ("gloc_coarse_destroy", _i, [_vp]),
     ("gloc_coarse_add_image", _i, [_vp, _vp, _u32, _u32, C.c_float, C.c_float, C.c_float, _vp, C.POINTER(_u32)]),
     ("gloc_coarse_add_scan", _i, [_vp, _vp, _sz, _sz, _vp, C.POINTER(_u32)]),
+    ("gloc_coarse_add_store_scan", _i, [_vp, _vp, _u32, _vp, C.POINTER(_u32)]),
+    ("gloc_coarse_match_pairs", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("gloc_coarse_release", _i, [_vp, _u32]),
     ("gloc_coarse_cells", _i, [_vp, _u32, C.POINTER(_u32), _vp, _sz]),
     ("gloc_coarse_match", _i, [_vp, _u32, _vp, _sz, _vp, _vp, _vp, _vp]),
@@ -788,6 +790,21 @@ class CoarseMatcher:
         check(lib().gloc_coarse_add_scan(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1], C.byref(self.params),
                                          C.byref(gid)))
         return gid.value
+
+    def add_store_scan(self, store, scan_id):
+        gid = C.c_uint32()
+        check(lib().gloc_coarse_add_store_scan(self._h, store._h, int(scan_id), C.byref(self.params), C.byref(gid)))
+        return gid.value
+
+    def match_pairs(self, q_grids, db_grids):
+        qs = np.ascontiguousarray(q_grids, np.uint32).reshape(-1)
+        ds = np.ascontiguousarray(db_grids, np.uint32).reshape(-1)
+        n = qs.shape[0]
+        assert ds.shape[0] == n
+        xyyaw, ratio, ok = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        check(lib().gloc_coarse_match_pairs(self._h, _np_ptr(qs), _np_ptr(ds), n, C.byref(self.params), _np_ptr(xyyaw),
+                                            _np_ptr(ratio), _np_ptr(ok)))
+        return xyyaw, ratio, ok.astype(bool)
 
     def release(self, grid_id):
         check(lib().gloc_coarse_release(self._h, int(grid_id)))

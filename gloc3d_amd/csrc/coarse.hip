@@ -11,6 +11,7 @@
 
 #include "coarse_kernels.hpp"
 #include "common.hpp"
+#include "scan_store.hpp"
 
 using namespace gloc;
 using namespace gloc::coarse;
@@ -22,7 +23,7 @@ struct gloc_coarse {
   std::vector<GridDev> grids;     // host copies of the device views
   std::vector<uint32_t> counts;   // occupied cells per grid
   std::vector<uint32_t> free_ids;
-  DevBuf scratch_bits, scratch_cnt, stage_img;
+  DevBuf scratch_bits, scratch_cnt, stage_img, tiny_img;
   DevBuf d_grids, d_pq, d_pd, d_trig, d_yaw, d_yawout, d_cand, d_verify, d_out;
   bool grids_dirty = true;
   uint32_t trig_n = 0;
@@ -134,7 +135,7 @@ int gloc_coarse_destroy(gloc_coarse* h) {
   (void)hipStreamSynchronize(h->stream);
   for (void* b : h->blocks)
     if (b) (void)hipFree(b);
-  for (DevBuf* b : {&h->scratch_bits, &h->scratch_cnt, &h->stage_img, &h->d_grids, &h->d_pq, &h->d_pd, &h->d_trig,
+  for (DevBuf* b : {&h->scratch_bits, &h->scratch_cnt, &h->stage_img, &h->tiny_img, &h->d_grids, &h->d_pq, &h->d_pd, &h->d_trig,
                     &h->d_yaw, &h->d_yawout, &h->d_cand, &h->d_verify, &h->d_out})
     b->release();
   if (h->bev) (void)gloc_bev_destroy(h->bev);
@@ -229,18 +230,65 @@ int gloc_coarse_cells(gloc_coarse* h, uint32_t grid_id, uint32_t* n_cells, uint3
   return GLOC_OK;
 }
 
-int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
-                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok) {
-  GLOC_REQUIRE(h && db_grids && out_xy_yaw, GLOC_ERR_INVALID, "null argument");
-  GLOC_REQUIRE(n_db >= 1 && n_db <= 4096, GLOC_ERR_INVALID, "n_db = %zu outside [1,4096]", n_db);
+int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t scan_id,
+                               const gloc_coarse_params* params, uint32_t* grid_id) {
+  GLOC_REQUIRE(h && store && grid_id, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(store->device == h->device, GLOC_ERR_INVALID, "store on device %d, matcher on %d", store->device,
+               h->device);
   GLOC_TRY(check_params(params));
-  GLOC_REQUIRE(q_grid < h->blocks.size() && h->blocks[q_grid], GLOC_ERR_INVALID, "unknown grid id %u", q_grid);
-  for (size_t i = 0; i < n_db; ++i)
-    GLOC_REQUIRE(db_grids[i] < h->blocks.size() && h->blocks[db_grids[i]], GLOC_ERR_INVALID, "unknown grid id %u",
-                 db_grids[i]);
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  const uint32_t n_pairs = (uint32_t)n_db, n_yaw = params->n_yaw, n_cand = params->top_yaw + 1;
+  DevScan sc;
+  GLOC_TRY(gloc::reg::store_get(store, scan_id, 2, &sc));
+  if (!h->bev) {
+    GLOC_TRY(gloc_bev_create(h->device, &h->bev));
+    GLOC_TRY(gloc_bev_set_stream(h->bev, (void*)s));
+  }
+  gloc_bev_params bp;
+  gloc_bev_default_params(&bp);
+  bp.resolution = params->resolution;
+  bp.out_width = 4;
+  bp.out_height = 4;
+  GLOC_TRY(h->tiny_img.ensure(64, s));
+  const uint64_t offsets[2] = {0, (uint64_t)sc.n};
+  gloc_bev_info info;  // requested: the call then synchronises and tells whether the scan projects to nothing
+  GLOC_TRY(gloc_bev_project_batch_device(h->bev, sc.xyz, offsets, 1, 3, &bp, h->tiny_img.p, &info));
+  const uint8_t* d_flags = nullptr;
+  int R = 0, S = 0;
+  GLOC_TRY(gloc_bev_device_flags(h->bev, 0, &d_flags, &R, &S));
+  GLOC_TRY(h->scratch_bits.ensure(sizeof(uint32_t) * G * GW, s));
+  GLOC_HIP(hipMemsetAsync(h->scratch_bits.p, 0, sizeof(uint32_t) * G * GW, s));
+  if (!info.empty) {
+    const size_t px = (size_t)S * S;
+    hipLaunchKernelGGL(mark_from_flags_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, d_flags, R, S,
+                       (int)params->cell_px, h->scratch_bits.as<uint32_t>());
+    GLOC_HIP(hipGetLastError());
+  }
+  return finish_grid(h, grid_id);
+}
+
+int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
+                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok) {
+  GLOC_REQUIRE(h && db_grids, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_db >= 1 && n_db <= 65536, GLOC_ERR_INVALID, "n_db = %zu outside [1,65536]", n_db);
+  std::vector<uint32_t> q(n_db, q_grid);
+  return gloc_coarse_match_pairs(h, q.data(), db_grids, n_db, params, out_xy_yaw, out_ratio, out_ok);
+}
+
+int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint32_t* db_grids, size_t n_pairs_in,
+                            const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok) {
+  GLOC_REQUIRE(h && q_grids && db_grids && out_xy_yaw, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_pairs_in >= 1 && n_pairs_in <= 65536, GLOC_ERR_INVALID, "n_pairs = %zu outside [1,65536]", n_pairs_in);
+  GLOC_TRY(check_params(params));
+  for (size_t i = 0; i < n_pairs_in; ++i) {
+    GLOC_REQUIRE(q_grids[i] < h->blocks.size() && h->blocks[q_grids[i]], GLOC_ERR_INVALID, "unknown grid id %u",
+                 q_grids[i]);
+    GLOC_REQUIRE(db_grids[i] < h->blocks.size() && h->blocks[db_grids[i]], GLOC_ERR_INVALID, "unknown grid id %u",
+                 db_grids[i]);
+  }
+  GLOC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const uint32_t n_pairs = (uint32_t)n_pairs_in, n_yaw = params->n_yaw, n_cand = params->top_yaw + 1;
   if (h->grids_dirty) {
     GLOC_TRY(h->d_grids.ensure(sizeof(GridDev) * h->grids.size(), s));
     GLOC_HIP(hipMemcpyAsync(h->d_grids.p, h->grids.data(), sizeof(GridDev) * h->grids.size(), hipMemcpyHostToDevice, s));
@@ -262,7 +310,7 @@ int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids,
     GLOC_HIP(hipStreamSynchronize(s));  // the vectors go out of scope
     h->trig_n = n_yaw;
   }
-  std::vector<uint32_t> pq(n_pairs, q_grid), pd(db_grids, db_grids + n_db);
+  std::vector<uint32_t> pq(q_grids, q_grids + n_pairs), pd(db_grids, db_grids + n_pairs);
   GLOC_TRY(h->d_pq.ensure(sizeof(uint32_t) * n_pairs, s));
   GLOC_TRY(h->d_pd.ensure(sizeof(uint32_t) * n_pairs, s));
   GLOC_TRY(h->d_yawout.ensure(sizeof(YawOut) * (size_t)n_pairs * n_yaw, s));

@@ -45,8 +45,13 @@ int DevBuf::ensure(size_t bytes, hipStream_t s, bool keep, size_t used) {
   void* np = nullptr;
   GLOC_HIP(hipMalloc(&np, ncap));
   if (keep && p && used) {
-    GLOC_HIP(hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, s));
-    GLOC_HIP(hipStreamSynchronize(s));
+    hipError_t e = hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      (void)hipFree(np);  // the old buffer stays valid
+      set_err("device buffer growth failed: %s", hipGetErrorString(e));
+      return GLOC_ERR_HIP;
+    }
   }
   if (p) GLOC_HIP(hipFree(p));
   p = np;

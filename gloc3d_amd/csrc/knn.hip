@@ -566,8 +566,23 @@ int gloc_knn_load(gloc_knn* h, const char* path) {
     set_err("%s holds %u-D rows, the index is %zu-D", path, hdr[1], h->dim);
     return GLOC_ERR_INVALID;
   }
+  // the header must agree with the file's size before a single row is added
+  const long pos = ftell(f);
+  if (pos < 0 || fseek(f, 0, SEEK_END) != 0) {
+    fclose(f);
+    set_err("cannot size %s", path);
+    return GLOC_ERR_INVALID;
+  }
+  const long end = ftell(f);
+  if (end < 0 || (unsigned long long)(end - pos) < (unsigned long long)hdr[0] * h->dim * sizeof(float)) {
+    fclose(f);
+    set_err("%s is truncated: the header announces %u rows", path, hdr[0]);
+    return GLOC_ERR_INVALID;
+  }
+  (void)fseek(f, pos, SEEK_SET);
   std::vector<float> buf;
   const size_t chunk = std::max<size_t>(1, (64u << 20) / (h->dim * sizeof(float)));
+  const size_t n0 = h->n;  // on any failure below the index is rolled back to this many rows
   int rc = GLOC_OK;
   for (size_t r = 0; rc == GLOC_OK && r < hdr[0]; r += chunk) {
     const size_t cnt = std::min<size_t>(chunk, hdr[0] - r);
@@ -580,6 +595,7 @@ int gloc_knn_load(gloc_knn* h, const char* path) {
     }
   }
   fclose(f);
+  if (rc != GLOC_OK) h->n = n0;  // (the running maximum norm may stay larger: it only widens the re-rank window)
   return rc;
 }
 

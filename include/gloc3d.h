@@ -414,6 +414,9 @@ int gloc_coarse_add_image(gloc_coarse* h, const uint8_t* occupancy, uint32_t wid
 /* The same straight from the scan (BEV projection at 0.2 m / 100 m on the device, no image round trip). */
 int gloc_coarse_add_scan(gloc_coarse* h, const float* xyz, size_t n, size_t stride_floats,
                          const gloc_coarse_params* params, uint32_t* grid_id);
+/* ... or from a scan resident in a scan store on the same device (no host copy of the points needed). */
+int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t scan_id,
+                               const gloc_coarse_params* params, uint32_t* grid_id);
 int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id);
 /* Occupied cells of a grid ((v << 16) | u, u / v in [0, 512): cell u spans the pixels
  * (u - 256) cell_px .. + cell_px - 1); out_cells may be NULL to get the count only. */
@@ -423,6 +426,10 @@ int gloc_coarse_cells(gloc_coarse* h, uint32_t grid_id, uint32_t* n_cells, uint3
  * out_ratio = overlapping / occupied query cells, out_ok (either may be NULL). */
 int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
                       const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok);
+/* n independent (query grid, database grid) pairs in one launch sequence (several queries in flight). */
+int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint32_t* db_grids, size_t n_pairs,
+                            const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio,
+                            int* out_ok);
 
 /* ============================ ground pre-alignment ("next" row N3) ========================= *
  * Replaces GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228),

@@ -43,6 +43,18 @@ def test_grids_and_matches_equal_the_oracle(capi, oracle_mod, scans):
             o = oracle_mod.coarse_match(og[q], og[d])
             assert (bits(xyyaw[j]) == bits(o["xy_yaw"])).all(), (q, d, xyyaw[j], o)
             assert bits(np.float32(ratio[j])) == bits(np.float32(o["ratio"])) and bool(ok[j]) == o["ok"], (q, d)
+    # from a scan resident in a scan store (bench.py --coarse): the same grid; pairs in one launch sequence
+    store = capi.ScanStore()
+    sid = store.add(scans["A"])
+    g_st = cm.add_store_scan(store, sid)
+    assert (np.sort(cm.cells(g_st)) == og["A"].cells()).all()
+    qs = [gid[CASES[1]], gid[CASES[2]], gid["other"]]
+    ds = [g_st, gid["A"], gid[CASES[3]]]
+    xy_p, ratio_p, ok_p = cm.match_pairs(qs, ds)
+    for j in range(3):
+        xy1, r1, ok1 = cm.match(qs[j], [ds[j]])
+        assert (bits(xy_p[j]) == bits(xy1[0])).all() and ok_p[j] == ok1[0] and bits(np.float32(ratio_p[j])) == bits(np.float32(r1[0]))
+    store.close()
     # an empty grid as query and as database
     e = cm.add_image(np.full((8, 8), 255, np.uint8), -0.8, -0.8, 0.2)
     xyyaw, ratio, ok = cm.match(e, [gid["A"]])

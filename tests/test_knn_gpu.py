@@ -290,5 +290,15 @@ def test_save_load_round_trip(capi, oracle_mod, tmp_path):
         c.load(tmp_path / "db.desc")       # dimension mismatch
     with pytest.raises(capi.GlocError):
         c.load(tmp_path / "missing.desc")
+    # a truncated file is refused before a single row is added: the index keeps its rows
+    raw = (tmp_path / "db.desc").read_bytes()
+    (tmp_path / "cut.desc").write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(capi.GlocError):
+        b.load(tmp_path / "cut.desc")
+    assert len(b) == 900
+    idx, d2 = b.search(q, 20)
+    assert (idx == oi).all()
+    b.load(tmp_path / "db.desc")           # load appends
+    assert len(b) == 1800
     b.close()
     c.close()

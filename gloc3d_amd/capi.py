@@ -155,6 +155,7 @@ _PROTOS = [
     ("gloc_reg_profile_reset", _i, [_vp]),
     ("gloc_reg_nn_stats", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("gloc_vlad_create", _i, [_i, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    ("gloc_vlad_set_gating", _i, [_vp, _vp, _vp, _vp]),
     ("gloc_vlad_destroy", _i, [_vp]),
     ("gloc_vlad_set_stream", _i, [_vp, _vp]),
     ("gloc_vlad_forward", _i, [_vp, _vp, _sz, _sz, _vp]),
@@ -647,6 +648,17 @@ class NetVladFC:
             self.close()
         except Exception:
             pass
+
+    def set_gating(self, gating_w=None, scale=None, shift=None):
+        """GatingContext after the FC: y * sigmoid((y W) * scale + shift); None switches it off."""
+        if gating_w is None:
+            check(lib().gloc_vlad_set_gating(self._h, None, None, None))
+            return
+        gw = np.ascontiguousarray(gating_w, np.float32)
+        sc = np.ascontiguousarray(scale, np.float32)
+        sh = np.ascontiguousarray(shift, np.float32)
+        assert gw.shape == (self.out_dim, self.out_dim) and sc.shape == (self.out_dim,) == sh.shape
+        check(lib().gloc_vlad_set_gating(self._h, _np_ptr(gw), _np_ptr(sc), _np_ptr(sh)))
 
     def forward(self, feat):
         x = np.ascontiguousarray(feat, np.float32)

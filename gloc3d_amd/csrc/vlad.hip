@@ -17,6 +17,8 @@ struct gloc_vlad {
   bool has_bias = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf conv_w, conv_b, centroids, fc_w;       // parameters, resident
+  DevBuf gate_w, gate_scale, gate_shift, gate_tmp;  // optional GatingContext
+  bool gating = false;
   DevBuf partV, partS, vlad, nrm2, fc_part;     // workspace
   DevBuf stage_in, stage_out;                   // host-pointer API staging
   Profiler prof;
@@ -64,6 +66,15 @@ int forward_device(gloc_vlad* h, const float* d_feat, size_t n, size_t hw, float
                          h->fc_part.as<float>(), nslabs, (int)n0, nb, OD, h->nrm2.as<float>(), K, d_out);
     }
     GLOC_HIP(hipGetLastError());
+  }
+  if (h->gating) {
+    ProfScope ps(h->prof, "vlad_gate", s);
+    GLOC_TRY(h->gate_tmp.ensure(sizeof(float) * n * OD, s));
+    hipLaunchKernelGGL(vlad_gate_kernel, dim3((OD + 63) / 64, (unsigned)n), dim3(64), sizeof(float) * OD, s, d_out,
+                       (int)n, OD, h->gate_w.as<float>(), h->gate_scale.as<float>(), h->gate_shift.as<float>(),
+                       h->gate_tmp.as<float>());
+    GLOC_HIP(hipGetLastError());
+    GLOC_HIP(hipMemcpyAsync(d_out, h->gate_tmp.p, sizeof(float) * n * OD, hipMemcpyDeviceToDevice, s));
   }
   return GLOC_OK;
 }
@@ -115,12 +126,30 @@ int gloc_vlad_create(int device, size_t dim, size_t clusters, size_t out_dim, co
   return GLOC_OK;
 }
 
+int gloc_vlad_set_gating(gloc_vlad* h, const float* gating_w, const float* scale, const float* shift) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  if (!gating_w) {
+    h->gating = false;
+    return GLOC_OK;
+  }
+  GLOC_REQUIRE(scale && shift, GLOC_ERR_INVALID, "scale and shift are required with gating weights");
+  GLOC_REQUIRE(h->out_dim <= 16384, GLOC_ERR_INVALID, "gating needs out_dim <= 16384");
+  GLOC_TRY(upload(h, h->gate_w, gating_w, h->out_dim * h->out_dim));
+  GLOC_TRY(upload(h, h->gate_scale, scale, h->out_dim));
+  GLOC_TRY(upload(h, h->gate_shift, shift, h->out_dim));
+  GLOC_HIP(hipStreamSynchronize(h->stream));
+  h->gating = true;
+  return GLOC_OK;
+}
+
 int gloc_vlad_destroy(gloc_vlad* h) {
   if (!h) return GLOC_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->prof.destroy();
-  for (DevBuf* b : {&h->conv_w, &h->conv_b, &h->centroids, &h->fc_w, &h->partV, &h->partS, &h->vlad,
+  for (DevBuf* b : {&h->gate_w, &h->gate_scale, &h->gate_shift, &h->gate_tmp, &h->conv_w, &h->conv_b, &h->centroids, &h->fc_w, &h->partV, &h->partS, &h->vlad,
                     &h->nrm2, &h->fc_part, &h->stage_in, &h->stage_out})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

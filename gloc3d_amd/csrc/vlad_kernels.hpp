@@ -267,5 +267,25 @@ __global__ void vlad_fc_reduce_kernel(const float* __restrict__ part, int nslabs
   out[(size_t)(n0 + i) * out_dim + o] = s * sc;
 }
 
+// GatingContext (model/netvlad_fc.py:120-146): gates = x W; BatchNorm1d in eval mode or + bias, both as
+// gates * scale + shift (the caller folds running_mean / running_var / weight / bias into scale and shift);
+// sigmoid; out = x * gates.  One wave per (image, 64 outputs): lanes <-> outputs, the image's descriptor
+// broadcast from LDS.  In place: `io` is read completely before it is written.
+__global__ __launch_bounds__(64) void vlad_gate_kernel(float* __restrict__ io, int n, int dim,
+                                                       const float* __restrict__ gw /* [dim][dim] */,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ out) {
+  extern __shared__ float xs[];
+  const int img = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+  for (int i = threadIdx.x; i < dim; i += 64) xs[i] = io[(size_t)img * dim + i];
+  __syncthreads();
+  if (j >= dim) return;
+  float acc = 0.f;
+  for (int i = 0; i < dim; ++i) acc += xs[i] * gw[(size_t)i * dim + j];  // coalesced over j
+  const float g = acc * scale[j] + shift[j];
+  const float sg = 1.0f / (1.0f + expf(-g));
+  out[(size_t)img * dim + j] = xs[j] * sg;
+}
+
 }  // namespace vlad
 }  // namespace gloc

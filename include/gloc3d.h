@@ -314,12 +314,17 @@ typedef struct gloc_vlad gloc_vlad;
 int gloc_vlad_create(int device, size_t dim, size_t clusters, size_t out_dim, const float* conv_w,
                      const float* conv_b, const float* centroids, const float* fc_w,
                      int normalize_input, gloc_vlad** out);
+/* Optional GatingContext after the FC (model/netvlad_fc.py:106-107,120-146; off in the reference's constructor
+ * call, main.py:594): out = y * sigmoid((y W) * scale + shift), W [out_dim][out_dim] = gating_weights.  With
+ * add_batch_norm (eval mode) scale = bn.weight / sqrt(bn.running_var + eps), shift = bn.bias -
+ * bn.running_mean * scale; without, scale = 1, shift = gating_biases.  gating_w = NULL switches it off. */
+int gloc_vlad_set_gating(gloc_vlad* h, const float* gating_w, const float* scale, const float* shift);
 int gloc_vlad_destroy(gloc_vlad* h);
 int gloc_vlad_set_stream(gloc_vlad* h, void* hip_stream);
 int gloc_vlad_forward(gloc_vlad* h, const float* feat, size_t n, size_t hw, float* out);
 int gloc_vlad_forward_device(gloc_vlad* h, const float* d_feat, size_t n, size_t hw, float* d_out);
 int gloc_vlad_set_profile(gloc_vlad* h, int enable);
-/* kernel families: "vlad_tile", "vlad_cluster", "vlad_fc" */
+/* kernel families: "vlad_tile", "vlad_cluster", "vlad_fc", "vlad_gate" */
 int gloc_vlad_profile(gloc_vlad* h, const char* kernel, double* total_ms, uint64_t* launches);
 
 /* ============================ BEV occupancy projection ("next" row N1) ==================== *

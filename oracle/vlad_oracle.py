@@ -6,7 +6,9 @@
   :88-96   vlad[k,c] = sum_p soft[k,p] * (x[c,p] - centroid[k,c])
   :99      intra-normalisation: vlad[k,:] / max(||vlad[k,:]||, 1e-12)
   :101-102 flatten [K*C], L2-normalise
-  :105     @ hidden1_weights [K*C, out]            (gating is off in main.py:594)
+  :105     @ hidden1_weights [K*C, out]
+  :106-107 optional GatingContext (:120-146; off in main.py:594): y * sigmoid((y W) * scale + shift) with
+           BatchNorm1d in eval mode folded into scale / shift (gating_forward)
 
 PINNED: checked against the reference module itself (imported in the build container by
 tests/golden/make_vlad_goldens.py) through the committed fixtures tests/golden/vlad_*.npz.
@@ -38,3 +40,15 @@ def netvlad_fc_forward(x, conv_w, conv_b, centroids, fc_w, normalize_input=True)
     n2 = np.sqrt((vlad * vlad).sum(axis=1, keepdims=True, dtype=np.float32))
     vlad = vlad / np.maximum(n2, np.float32(1e-12))
     return (vlad @ fc_w.astype(np.float32)).astype(np.float32)
+
+
+def gating_forward(y, gating_w, scale, shift):
+    """GatingContext.forward (model/netvlad_fc.py:136-146) in eval mode; see gloc_vlad_set_gating."""
+    y = np.asarray(y, np.float32)
+    g = (y @ gating_w.astype(np.float32)).astype(np.float32) * scale.astype(np.float32) + shift.astype(np.float32)
+    return (y * (np.float32(1) / (np.float32(1) + np.exp(-g, dtype=np.float32)))).astype(np.float32)
+
+
+def fold_batch_norm(weight, bias, running_mean, running_var, eps=1e-5):
+    scale = (weight / np.sqrt(running_var + eps)).astype(np.float32)
+    return scale, (bias - running_mean * scale).astype(np.float32)

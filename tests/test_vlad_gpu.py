@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from test_oracle_vlad import CASES, load
+from test_oracle_vlad import CASES, load, load_gating
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5  # absolute, on descriptors of norm ~1 (fp32 everywhere; summation orders differ)
@@ -14,7 +14,13 @@ TOL = 2e-5  # absolute, on descriptors of norm ~1 (fp32 everywhere; summation or
 def test_matches_reference_goldens(capi, case):
     x, w, b, c, fc, y = load(case)
     m = capi.NetVladFC(w, c, fc, conv_b=b)
+    gate = load_gating(case)
+    if gate is not None:          # GatingContext after the FC (model/netvlad_fc.py:106-107)
+        m.set_gating(*gate)
     got = m.forward(x)
+    if gate is not None:          # and off again: the un-gated descriptor differs
+        m.set_gating(None)
+        assert np.abs(m.forward(x) - y).max() > 1e-3
     m.close()
     assert got.shape == y.shape
     assert np.abs(got - y).max() < TOL * max(1.0, np.abs(y).max())

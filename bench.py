@@ -300,8 +300,14 @@ def main():
         try:
             comm = capi.Comm(local_rank, rank, world, sharded.torch_exchange(dev))
             capi_knn = sharded.CapiShardedKnn(index, comm)
+            probe = torch.full((1, 1, sharded.RESULT_COLS), float(rank), dtype=torch.float32, device=dev)
+            got = capi_knn.all_gather_tables(probe)     # self-test: every rank's row must arrive in rank order
+            torch.cuda.synchronize()
+            if not (got[:, 0, 0].cpu() == torch.arange(world, dtype=torch.float32)).all():
+                raise RuntimeError("all-gather self-test returned the wrong rows")
             collectives = "capi (gloc_knn_search_sharded + gloc_comm_all_gather_device, RCCL)"
         except Exception as e:   # loud, and recorded in the JSON line: never a silent change of path
+            capi_knn = None
             print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
     if world > 1:
         ok_all = torch.tensor([1 if capi_knn is not None else 0], device=comm_dev or dev)

@@ -491,8 +491,23 @@ def main():
     kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_compact_kernel"
     traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), same workload
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_nn_compact.json")
+    issue_model = None
     if args.nn_mode == "culled" and world == 1 and os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        pj = json.load(open(pmc))
+        traffic = pj.get("hbm_bytes_per_launch")
+        if pj.get("jobs_per_launch") and abs(pj["jobs_per_launch"] - jobs_per_launch) > 1e-6:
+            traffic = traffic * jobs_per_launch / pj["jobs_per_launch"]      # PMC passes ran at another batch size
+        # instruction-issue model: the committed per-wave instruction counts (PMC) x the waves of a launch over the
+        # live launch time, against the vector pipes' issue rate (157.3 TFLOP/s counts an FMA as two: 78.65 T lane-ops/s)
+        pw = pj.get("per_wave", {})
+        if pw.get("valu") and avg_launch_s > 0:
+            waves = jobs_per_launch * np.ceil(pts_q / 128.0)
+            lane_ops = pw["valu"] * 64.0 * waves / avg_launch_s
+            issue_model = {"valu_per_wave": pw["valu"], "salu_per_wave": pw.get("salu"), "lds_per_wave": pw.get("lds"),
+                           "vmem_per_wave": pw.get("vmem_rd"), "waves_per_launch": waves,
+                           "vector_lane_ops_per_s": lane_ops, "frac_of_vector_issue_peak": lane_ops / (PEAK_FP32_TFLOPS * 1e12 / 2),
+                           "source": "profiles/r02_pmc_traffic_nn_compact.json (SQ_INSTS_* / SQ_WAVES); SQ_ACTIVE_INST_VALU puts the "
+                                     "vector pipe at 65-77 % busy: most instructions are 2.3-4.2-cycle forms, not 1-per-clock"}
     if args.nn_mode == "exhaustive":
         ach = FLOP_PER_PAIR * all_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -506,6 +521,7 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes, "jobs_per_launch": jobs_per_launch,
                     "launch_ms": avg_launch_s * 1e3, "launches": nn_launches,
                     "pairs_evaluated_per_launch": eval_pairs, "pairs_exhaustive_per_launch": all_pairs,
+                    "issue_model": issue_model,
                     "note": "the culled search evaluates ~1e-3 of the pairs SURVEY 8d's flop count assumes, so its "
                             "floor is reading each scan once: (16 B x (query + candidate points) + 8 B x query "
                             "points) x jobs per launch over the HIP-event duration of the launch (one stream, "

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgloc3d.so")
+LIB_PATH = os.environ.get("GLOC3D_LIB_PATH") or os.path.join(HERE, "lib", "libgloc3d.so")  # (override: dev builds)
 
 GLOC_OK = 0
 ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "GLOC_ERR_NODEVICE",

@@ -6,7 +6,7 @@ from gloc3d_amd import capi, synth
 w = synth.make_world(1001)
 A = synth.lidar_scan(w, None, seed=1001)[:, :3]
 B = synth.lidar_scan(w, synth.se3(5.0, (0.5, -0.3, 0.1)), seed=1002)[:, :3]
-for mode, name in ((0, "compact"), (2, "broadcast")):
+for mode, name in ((0, "culled"), (1, "exhaustive")):
     for cs in (1, 2, 4):
         reg = capi.Registrar(); reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, cs); reg.set_option(capi.REG_OPT_NN_MODE, mode)
         ids = [reg.scan_upload(A), reg.scan_upload(B)]

@@ -147,6 +147,8 @@ _PROTOS = [
                             C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
     ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
                                 _vp]),
+    ("gloc_reg_first_success_multi", _i, [_vp, _sz, _vp, _vp, _sz, _vp, C.POINTER(RegParams), _vp, _vp, _vp, _vp,
+                                          C.POINTER(_u64)]),
     ("gloc_reg_select_first_ok", _i, [_vp, _sz]),
     ("gloc_reg_nn", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     ("gloc_reg_ransac_hypotheses", _i, [_vp, _vp, _vp, _vp, _sz, _u64, _u32, _u32, _vp, _vp, _vp,
@@ -571,6 +573,22 @@ class Registrar:
                                        None if it is None else _np_ptr(it), C.byref(prm),
                                        _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
         return dict(T=T, rmse=rmse, inliers=inl, ok=ok.astype(bool))
+
+    def first_success_multi(self, q_ids, cand_ids, init_T=None, params=None):
+        """The reference's stop-at-the-first-success loop for several queries: returns rank [Q] (-1: none),
+        T [Q, 4, 4], rmse [Q], inliers [Q] and the number of registrations actually run."""
+        q = np.ascontiguousarray(q_ids, np.uint32).reshape(-1)
+        ids = np.ascontiguousarray(cand_ids, np.uint32).reshape(q.shape[0], -1)
+        Q, n = ids.shape
+        prm = params or default_reg_params()
+        it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(Q * n, 16)
+        rank = np.empty(Q, np.int32)
+        T, rmse, inl = np.empty((Q, 4, 4), np.float32), np.empty(Q, np.float32), np.empty(Q, np.uint32)
+        jobs = C.c_uint64()
+        check(lib().gloc_reg_first_success_multi(self._h, Q, _np_ptr(q), _np_ptr(ids), n,
+                                                 None if it is None else _np_ptr(it), C.byref(prm), _np_ptr(rank),
+                                                 _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), C.byref(jobs)))
+        return dict(rank=rank, T=T, rmse=rmse, inliers=inl, jobs_run=jobs.value)
 
     def nn(self, src, tgt, T=None):
         s = np.ascontiguousarray(src, np.float32).reshape(-1, 3)

@@ -186,9 +186,24 @@ class RpyPCLoopDetector {
     if (n == 0) return -1;
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = db_scan_ids_.at(db_indices[i]);
+    std::vector<float> init;
+    if (!all_poses && !all_ok) {
+      // nobody asked for every candidate's pose: walk the candidates as the reference does, stopping at the
+      // first success (global_localization.cpp:519-572) -- the same rank and pose, fewer registrations
+      if (init_guess) {
+        if (init_guess->size() != n) throw std::runtime_error("one initial guess per candidate expected");
+        init.resize(16 * n);
+        for (size_t i = 0; i < n; ++i) std::copy((*init_guess)[i].begin(), (*init_guess)[i].end(), init.begin() + 16 * i);
+      }
+      int rank = -1;
+      float Tq[16];
+      check(gloc_reg_first_success_multi(reg_, 1, &q_scan_id, ids.data(), n, init_guess ? init.data() : nullptr,
+                                         &reg_params_, &rank, Tq, nullptr, nullptr, nullptr));
+      if (rank >= 0) std::copy(Tq, Tq + 16, pose_in_db.begin());
+      return rank;
+    }
     std::vector<float> T(16 * n);
     std::vector<int> ok(n);
-    std::vector<float> init;
     if (init_guess) {
       if (init_guess->size() != n) throw std::runtime_error("one initial guess per candidate expected");
       init.resize(16 * n);

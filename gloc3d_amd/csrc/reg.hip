@@ -518,6 +518,80 @@ int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_i
   return GLOC_OK;
 }
 
+int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
+                                 const uint32_t* cand_scan_ids, size_t n_cand, const float* init_T,
+                                 const gloc_reg_params* params, int* out_rank, float* out_T, float* out_rmse,
+                                 uint32_t* out_inliers, uint64_t* out_jobs_run) {
+  GLOC_REQUIRE(h && q_scan_ids && cand_scan_ids && out_rank && out_T, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n_queries >= 1 && n_cand >= 1 && n_queries * n_cand <= 65536, GLOC_ERR_INVALID,
+               "n_queries x n_cand = %zu x %zu outside [1, 65536]", n_queries, n_cand);
+  GLOC_REQUIRE(h->store, GLOC_ERR_INVALID, "no scan store: upload scans or attach a store first");
+  GLOC_TRY(check_params(params));
+  GLOC_HIP(hipSetDevice(h->device));
+  std::vector<DevScan> src(n_queries);
+  for (size_t q = 0; q < n_queries; ++q) {
+    GLOC_TRY(store_get(h->store, q_scan_ids[q], h->nn_src_per_lane, &src[q]));
+    out_rank[q] = -1;
+    float* T = out_T + 16 * q;
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (out_rmse) out_rmse[q] = 0.f;
+    if (out_inliers) out_inliers[q] = 0;
+  }
+  std::vector<size_t> pending(n_queries);
+  for (size_t q = 0; q < n_queries; ++q) pending[q] = q;
+  uint64_t jobs_run = 0;
+  std::vector<JobHost> jh;
+  std::vector<size_t> who;
+  std::vector<float> T, rm;
+  std::vector<uint32_t> inl;
+  std::vector<int> ok;
+  // rank by rank, as GlocEvaluator::global_registraion walks a query's candidates
+  // (registration/global_localization.cpp:519-572), but for all pending queries at once
+  for (size_t r = 0; r < n_cand && !pending.empty(); ++r) {
+    jh.clear();
+    who.clear();
+    for (size_t q : pending) {
+      const size_t o = q * n_cand + r;
+      if (cand_scan_ids[o] == 0xFFFFFFFFu) continue;
+      JobHost j;
+      j.src = src[q];
+      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 2, &j.tgt));
+      j.stream_id = (uint32_t)r;  // the RANSAC stream of retrieval rank r: the same job as in gloc_reg_batch_multi
+      j.init_T = init_T ? init_T + 16 * o : nullptr;
+      jh.push_back(j);
+      who.push_back(q);
+    }
+    if (jh.empty()) continue;
+    const size_t nj = jh.size();
+    T.resize(16 * nj);
+    rm.resize(nj);
+    inl.resize(nj);
+    ok.resize(nj);
+    GLOC_TRY(run_jobs(h, jh, params, T.data(), rm.data(), inl.data(), ok.data()));
+    jobs_run += nj;
+    std::vector<size_t> still;
+    size_t k = 0;
+    for (size_t q : pending) {
+      if (k < nj && who[k] == q) {
+        if (ok[k]) {
+          out_rank[q] = (int)r;
+          std::copy(T.begin() + 16 * k, T.begin() + 16 * (k + 1), out_T + 16 * q);
+          if (out_rmse) out_rmse[q] = rm[k];
+          if (out_inliers) out_inliers[q] = inl[k];
+        } else {
+          still.push_back(q);
+        }
+        ++k;
+      } else {
+        still.push_back(q);  // no candidate at this rank
+      }
+    }
+    pending.swap(still);
+  }
+  if (out_jobs_run) *out_jobs_run = jobs_run;
+  return GLOC_OK;
+}
+
 int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_scan_ids,
                        size_t n_cand, const uint32_t* cand_stream_ids, const float* init_T,
                        const gloc_reg_params* params, float* out_T, float* out_rmse,

@@ -281,6 +281,18 @@ int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_i
                          const gloc_reg_params* params, float* out_T, float* out_rmse,
                          uint32_t* out_inliers, int* out_ok);
 
+/* The reference's candidate loop as it is written -- stop at the first match()==true
+ * (registration/global_localization.cpp:519-572) -- for several queries at once: rank by rank, the
+ * rank-r candidates of all queries still without a success are registered in one batch.  Every job is the
+ * one gloc_reg_batch_multi runs for that (query, rank), so out_rank / out_T equal
+ * gloc_reg_select_first_ok over its result, bit for bit; only the candidates behind a success are never
+ * touched.  out_rank: -1 where no candidate succeeded (out_T = identity); out_jobs_run (may be NULL):
+ * registrations actually run. */
+int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
+                                 const uint32_t* cand_scan_ids, size_t n_cand, const float* init_T,
+                                 const gloc_reg_params* params, int* out_rank, float* out_T,
+                                 float* out_rmse, uint32_t* out_inliers, uint64_t* out_jobs_run);
+
 /* The reference's selection rule: lowest-rank candidate whose registration succeeded
  * (registration/global_localization.cpp:519-572 stops at the first match()==true).
  * Returns the rank or -1. */

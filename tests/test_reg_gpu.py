@@ -342,6 +342,34 @@ def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
     store.close()
 
 
+def test_first_success_equals_select_over_the_full_batch(capi, scans):
+    """The reference's stop-at-first-success loop (global_localization.cpp:519-572) for several queries at once:
+    the same rank and pose, bit for bit, as registering all candidates and selecting afterwards -- with fewer
+    registrations run."""
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qs = [store.add(np.ascontiguousarray(B[::20])), store.add(np.ascontiguousarray(A[5::33])),
+          store.add(np.ascontiguousarray(Cc[3::25]))]
+    a0, a1, c0 = (store.add(np.ascontiguousarray(x)) for x in (A[::6], A[1::7], Cc[::6]))
+    cand = np.array([[c0, a0, a1], [c0, capi.NO_SCAN, a1], [a0, a1, capi.NO_SCAN]], np.uint32)
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6, max_rmse=1.0)
+    r = capi.Registrar(store=store)
+    full = r.batch_multi(qs, cand, params=prm)
+    fs = r.first_success_multi(qs, cand, params=prm)
+    for qi in range(3):
+        want = capi.reg_select_first_ok(full["ok"][qi].astype(np.int32))
+        assert fs["rank"][qi] == want
+        if want >= 0:
+            assert (bits(fs["T"][qi]) == bits(full["T"][qi, want])).all()
+            assert fs["inliers"][qi] == full["inliers"][qi, want] and bits(fs["rmse"][qi]) == bits(full["rmse"][qi, want])
+        else:
+            assert (fs["T"][qi] == np.eye(4)).all()
+    assert list(fs["rank"]) == [1, 2, -1]            # a different scene first; a missing slot; a lost query
+    assert fs["jobs_run"] == 2 + 2 + 2 < 7            # of the 7 real (query, candidate) pairs
+    r.close()
+    store.close()
+
+
 def test_degenerate_inputs(reg, capi):
     prm = capi.default_reg_params(ransac_iters=50, icp_iters=2)
     two = np.array([[0, 0, 0], [1, 0, 0]], np.float32)

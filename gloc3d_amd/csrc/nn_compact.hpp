@@ -34,6 +34,10 @@ namespace reg {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GPTR(T) const T __attribute__((address_space(1)))*
+#ifndef GLOC_NN_WPB
+#define GLOC_NN_WPB 1  // waves per work-group; waves never synchronise with each other, and 1 measured 4 % faster than 4
+#endif
+constexpr int NN_WPB = GLOC_NN_WPB;
 
 // grid = n_wg * n_jobs work-groups of 4 independent waves.  Jobs are taken `job_group` at a time; within
 // a group the job index runs fastest (every job's widest source groups -- `order` lists them widest
@@ -43,7 +47,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
 template <int CS, bool PAIRS>
-__global__ __launch_bounds__(256) void nn_compact_kernel(
+__global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
@@ -68,14 +72,14 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
     uint16_t queue[S * NSB];        // work items: (source slot << 3) | sub-block within the chunk
   };
   static_assert(SB % 16 == 0 && NSB == 8, "items pack the sub-block into 3 bits");
-  __shared__ WaveLds lds_all[4];
+  __shared__ WaveLds lds_all[NN_WPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   WaveLds& L = lds_all[w];
   const uint32_t per = n_wg * job_group, grp = blockIdx.x / per, rem = blockIdx.x % per;
   const uint32_t left_jobs = n_jobs - grp * job_group, gsize = left_jobs < job_group ? left_jobs : job_group;
   const uint32_t job = grp * job_group + rem % gsize, wg = rem / gsize;
   const Job& J = jobs[job];
-  const uint32_t gi = wg * 4 + w;
+  const uint32_t gi = wg * NN_WPB + w;
   const uint32_t n_src = J.n_src;
   if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
   struct IndexView {
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void nn_compact_kernel(
     }
   }
   if (trace && lane == 0) {
-    const size_t wid = (size_t)blockIdx.x * 4 + w;
+    const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
     trace[4 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
     trace[4 * wid + 1] = n_cand_chunks;
     trace[4 * wid + 2] = n_processed;

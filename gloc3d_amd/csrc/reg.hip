@@ -85,15 +85,15 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
                          h->pairs.as<f32x4>());
   } else {
     const int cs = h->nn_src_per_lane;
-    const uint32_t n_wg = (bd.max_groups + 3) / 4;
+    const uint32_t n_wg = (bd.max_groups + NN_WPB - 1) / NN_WPB;
     const unsigned grid = n_wg * bd.n_jobs;
     if (h->trace_on) {
-      h->trace_waves = (size_t)grid * 4;
+      h->trace_waves = (size_t)grid * NN_WPB;
       if (h->trace.ensure(h->trace_waves * 16, h->stream)) return GLOC_ERR_NOMEM;
       GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 16, h->stream));
     }
 #define LAUNCH_COMPACT(CS_, P_)                                                                          \
-  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_>), dim3(grid), dim3(256), 0, h->stream, h->jobs.as<Job>(), \
+  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, (uint32_t)h->nn_job_group, n_wg, h->states.as<CandState>(),              \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), h->partials.as<double>(), bd.n_part, bd.ld, \

@@ -38,6 +38,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define GLOC_NN_WPB 1  // waves per work-group; waves never synchronise with each other, and 1 measured 4 % faster than 4
 #endif
 constexpr int NN_WPB = GLOC_NN_WPB;
+constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evaluated statistic
+#ifndef GLOC_NN_WAVES_PER_EU
+#define GLOC_NN_WAVES_PER_EU 4
+#endif
 
 // grid = n_wg * n_jobs work-groups of 4 independent waves.  Jobs are taken `job_group` at a time; within
 // a group the job index runs fastest (every job's widest source groups -- `order` lists them widest
@@ -47,13 +51,13 @@ constexpr int NN_WPB = GLOC_NN_WPB;
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
 template <int CS, bool PAIRS>
-__global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
+__global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLOC_NN_WAVES_PER_EU))) void nn_compact_kernel(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
-    size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* pairs evaluated */,
-    uint32_t* __restrict__ trace /* dev only: [wave][4] = cycles, candidate chunks, chunks, rounds */) {
+    size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
+    uint32_t* __restrict__ trace /* dev only: [wave][8] = cycles, candidate chunks, chunks, rounds, items, listed sources, job, group */) {
   constexpr int S = 64 * CS;        // sources per wave
   constexpr int NSB = CH / SB;      // sub-blocks per chunk
   // The staged chunk is kept as PAIRS of targets, structure-of-arrays: pair i of a sub-block is
@@ -67,9 +71,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     f32x4 src[S];                   // moved source points
     unsigned long long key[S];      // (bits(best d2) << 32) | sub-block holding it
     uint8_t tie[S];                 // (sizes are chosen so that CS = 2 stays under 8 KB per wave: 5 work-groups per CU)
-    f32x4 sblo[NSB], sbhi[NSB];     // the chunk's sub-block boxes
     uint16_t list[S];               // source slots that passed the chunk-level test
     uint16_t queue[S * NSB];        // work items: (source slot << 3) | sub-block within the chunk
+#ifdef GLOC_NN_LDS_PAD
+    uint8_t pad_[GLOC_NN_LDS_PAD];  // dev: occupancy experiments
+#endif
   };
   static_assert(SB % 16 == 0 && NSB == 8, "items pack the sub-block into 3 bits");
   __shared__ WaveLds lds_all[NN_WPB];
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   const uint32_t n_src = J.n_src;
   if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
   struct IndexView {
-    GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb_lo; GPTR(f32x4) sb_hi;
+    GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb2;
     GPTR(uint32_t) keys; GPTR(ScanHeader) hdr;
     uint32_t n, nchunks;
     GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // treat as generic (flat_load): view them in the global address space explicitly.
   const ScanIndexDev ixg = J.tgt;
   const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
-                     (GPTR(f32x4))ixg.sb_lo, (GPTR(f32x4))ixg.sb_hi, (GPTR(uint32_t))ixg.keys,
+                     (GPTR(f32x4))ixg.sb2, (GPTR(uint32_t))ixg.keys,
                      (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
                      (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup};
   GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0;
+  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0, n_listed = 0;
   unsigned long long n_items = 0;
 
   float px[CS], py[CS], pz[CS], best[CS];
@@ -172,6 +178,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     return m;
   };
   float wmax = wave_max_best();
+  const unsigned long long t_pro = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long t_chunks = 0;
 
   // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
   auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
@@ -233,23 +241,19 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       }
       if (!__any(any_need)) continue;
       n_processed++;
+      const unsigned long long t_c0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
 #pragma unroll
       for (int u = 0; u < CH / 64; ++u) {
-        const uint32_t tl = u * 64 + lane, j = c * CH + tl;
-        f32x4 v = {NN_FAR, NN_FAR, NN_FAR, 0.f};
-        if (j < ix.n) v = ix.pts[j];
+        const uint32_t tl = u * 64 + lane;
+        const f32x4 v = ix.pts[c * CH + tl];  // the store pads the last chunk with far sentinels
         float* d = &L.stage[(tl / SB) * SB_STRIDE + ((tl % SB) >> 1) * 8 + (tl & 1)];
         d[0] = v.x; d[2] = v.y; d[4] = v.z;
       }
-      f32x4 sbl = {0.f, 0.f, 0.f, 0.f}, sbh = {0.f, 0.f, 0.f, 0.f};
-      {
-        const uint32_t blk_l = c * NSB + (lane & 7);
-        if (blk_l * SB < ix.n) {
-          sbl = ix.sb_lo[blk_l];
-          sbh = ix.sb_hi[blk_l];
-        }
-      }
+      // the boxes of the two sub-blocks this lane will test (2q, 2q + 1, q = lane % 4), straight into
+      // registers; sub-blocks past the end of the scan have empty, inverted boxes: their bound is +inf
+      GPTR(f32x4) bp = ix.sb2 + ((size_t)c * (NSB / 2) + (lane & 3)) * 3;
+      const f32x4 bA = bp[0], bB = bp[1], bC = bp[2];
       // sources that passed the chunk-level test, compacted
       uint32_t k = 0;
 #pragma unroll
@@ -260,32 +264,27 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
               (uint16_t)(s * 64 + lane);
         k += (uint32_t)__popcll(m);
       }
-      if (lane < NSB) {
-        L.sblo[lane] = sbl;
-        L.sbhi[lane] = sbh;
-      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // sub-block tests, one (source, sub-block) pair per lane: only the listed sources are tested,
-      // against their CURRENT bound; the passing pairs become the work items
-      const uint32_t left = ix.n - c * CH;  // > 0: the chunk exists
-      const uint32_t nsb_valid = left >= (uint32_t)CH ? (uint32_t)NSB : (left + SB - 1) / SB;
+      // sub-block tests: a lane takes one listed source and TWO sub-blocks (packed fp32: both boxes per
+      // instruction), against the source's CURRENT bound; the passing pairs become the work items
+      const f32x2 lox = {bA.x, bA.y}, loy = {bA.z, bA.w}, loz = {bB.x, bB.y};
+      const f32x2 hix = {bB.z, bB.w}, hiy = {bC.x, bC.y}, hiz = {bC.z, bC.w};
+      const uint32_t sb0 = (lane & 3) * 2;
       uint32_t total = 0;
-      // four steps of 64 pairs at a time: their LDS reads and box tests are independent, so a wave
+      // four steps of 16 sources at a time: their LDS reads and box tests are independent, so a wave
       // (latency-bound when few share the SIMD) overlaps them; only the queue positions are serial
       constexpr int TU = 4;
-      for (uint32_t t0 = 0; t0 < k * NSB; t0 += 64 * TU) {
+      for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
         uint32_t si[TU];
         bool act[TU];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
           const uint32_t t = t0 + u * 64 + lane;
-          act[u] = t < k * NSB;
-          si[u] = L.list[act[u] ? (t >> 3) : 0];
+          act[u] = t < k * (NSB / 2);
+          si[u] = L.list[act[u] ? (t >> 2) : 0];
         }
-        const uint32_t sb = lane & 7;  // (t & 7): t0 and u * 64 are multiples of 8
-        const f32x4 slo = L.sblo[sb], shi = L.sbhi[sb];
         f32x4 p[TU];
         float bst[TU];
 #pragma unroll
@@ -295,18 +294,30 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-          const bool nd = act[u] && sb < nsb_valid && (box_lb(p[u].x, p[u].y, p[u].z, slo, shi) <= bst[u]);
-          const unsigned long long m = __ballot(nd);
-          if (nd)
-            L.queue[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                (uint16_t)((si[u] << 3) | sb);
-          total += (uint32_t)__popcll(m);
+          // box_lb() for both boxes at once
+          const f32x2 qx = {p[u].x, p[u].x}, qy = {p[u].y, p[u].y}, qz = {p[u].z, p[u].z};
+          const f32x2 ax = lox - qx, bx = qx - hix, ay = loy - qy, by = qy - hiy, az = loz - qz, bz = qz - hiz;
+          const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
+          const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
+          const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
+          const f32x2 lb = ((ex * ex + ey * ey) + ez * ez) * f32x2{0.99999905f, 0.99999905f};
+          const bool nd0 = act[u] && lb.x <= bst[u], nd1 = act[u] && lb.y <= bst[u];
+          const unsigned long long m0 = __ballot(nd0), m1 = __ballot(nd1);
+          const uint32_t c0n = (uint32_t)__popcll(m0);
+          if (nd0)
+            L.queue[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] =
+                (uint16_t)((si[u] << 3) | sb0);
+          if (nd1)
+            L.queue[total + c0n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] =
+                (uint16_t)((si[u] << 3) | (sb0 + 1));
+          total += c0n + (uint32_t)__popcll(m1);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       n_items += total;
+      n_listed += k;
       for (uint32_t r = 0; r < total; r += 64) {
         n_rounds++;
         const uint32_t it = r + lane;
@@ -344,10 +355,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         best[s] = nb;
       }
       if (__any(changed)) wmax = wave_max_best();
+      if (trace) t_chunks += __builtin_amdgcn_s_memtime() - t_c0;
     }
     }  // batches of this super-chunk group
   }
-  if (stat_pairs && lane == 0) atomicAdd(stat_pairs, n_items * (unsigned long long)SB);
+  // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
+  // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
+  if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
+  const unsigned long long t_sweep = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
@@ -361,19 +376,27 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const bool tie = L.tie[slot] != 0;
     uint32_t bj = 0xFFFFFFFFu;
     if (!tie) {
-      // all 16 loads in flight at once (clamped, so that they are unconditional): one memory
-      // round trip instead of sixteen -- a lone wave is latency-bound here
-      const uint32_t j0 = bch * SB;
-      f32x4 t[SB];
+      // (the store pads the scan to whole chunks, so the loads are unconditional)
+      // eight loads in flight at a time (sixteen would cost the 5th wave per SIMD its registers)
+      GPTR(f32x4) tp = ix.pts + (size_t)bch * SB;
+      const f32x2 pxy = {px[s], py[s]};
 #pragma unroll
-      for (int u = 0; u < SB; ++u) t[u] = ix.pts[(j0 + u) < ix.n ? (j0 + u) : (ix.n - 1)];
+      for (int u0 = 0; u0 < SB; u0 += 8) {
+        f32x4 t[8];
 #pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        if ((j0 + u) < ix.n && dist2(px[s], py[s], pz[s], t[u].x, t[u].y, t[u].z) == best[s]) {
-          const uint32_t o = __float_as_uint(t[u].w);
-          if (o < bj) {
+        for (int u = 0; u < 8; ++u) t[u] = tp[u0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          // dist2(): x and y share one packed instruction (a loaded point's x, y are a register pair);
+          // same roundings as the scalar form
+          const f32x2 dxy = pxy - f32x2{t[u].x, t[u].y};
+          const f32x2 sxy = dxy * dxy;
+          const float dz = pz[s] - t[u].z;
+          const float d2 = (sxy.x + sxy.y) + dz * dz;
+          const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
+          if (d2 == best[s] && o < bj) {
             bj = o;
-            bpos[s] = j0 + u;
+            bpos[s] = bch * SB + u0 + u;
           }
         }
       }
@@ -442,10 +465,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   }
   if (trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
-    trace[4 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
-    trace[4 * wid + 1] = n_cand_chunks;
-    trace[4 * wid + 2] = n_processed;
-    trace[4 * wid + 3] = n_rounds;
+    trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+    trace[8 * wid + 1] = (uint32_t)t_chunks;  // cycles inside chunk processing
+    trace[8 * wid + 2] = n_processed;
+    trace[8 * wid + 3] = n_rounds;
+    trace[8 * wid + 4] = (uint32_t)n_items;
+    trace[8 * wid + 5] = (uint32_t)(t_pro - t_start);  // prologue cycles
+    trace[8 * wid + 6] = job;
+    trace[8 * wid + 7] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_sweep);  // recovery + outputs
   }
 }
 

@@ -26,7 +26,7 @@ struct gloc_reg {
   DevBuf Rt, valid, inliers;     // RANSAC hypotheses
   DevBuf partials;               // [job][n_part][ACC_NV] fp64
   DevBuf export_idx, export_d2;  // gloc_reg_nn: results in the caller's index space
-  DevBuf counters;               // [0] = pairs evaluated by the culled search
+  DevBuf counters;               // pairs evaluated by the culled search: NN_STAT_SLOTS partial counts (profiling only)
   std::vector<CandState> h_states;
   int nn_mode = 0;        // 0 culled + compacted (default), 1 exhaustive
   bool trace_on = false;  // dev only: per-wave trace of the culled kernel
@@ -89,8 +89,8 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     const unsigned grid = n_wg * bd.n_jobs;
     if (h->trace_on) {
       h->trace_waves = (size_t)grid * NN_WPB;
-      if (h->trace.ensure(h->trace_waves * 16, h->stream)) return GLOC_ERR_NOMEM;
-      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 16, h->stream));
+      if (h->trace.ensure(h->trace_waves * 32, h->stream)) return GLOC_ERR_NOMEM;
+      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 32, h->stream));
     }
 #define LAUNCH_COMPACT(CS_, P_)                                                                          \
   hipLaunchKernelGGL((nn_compact_kernel<CS_, P_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
@@ -149,8 +149,8 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   }
   GLOC_TRY(h->jobs.ensure(sizeof(Job) * n_jobs, s));
   if (!h->counters.p) {
-    GLOC_TRY(h->counters.ensure(64, s));
-    GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 64, s));
+    GLOC_TRY(h->counters.ensure(8 * NN_STAT_SLOTS, s));
+    GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 8 * NN_STAT_SLOTS, s));
   }
   GLOC_TRY(h->states.ensure(sizeof(CandState) * n_jobs, s));
   GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * std::max<size_t>(bd.ld, 1) * n_jobs, s));
@@ -633,7 +633,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   if (h->jobs.ensure(sizeof(Job), s) || h->states.ensure(sizeof(CandState), s) ||
       h->corr.ensure(sizeof(uint32_t) * bd.ld, s) || h->d2.ensure(sizeof(float) * bd.ld, s) ||
       h->export_idx.ensure(sizeof(uint32_t) * bd.ld, s) || h->export_d2.ensure(sizeof(float) * bd.ld, s) ||
-      h->partials.ensure(sizeof(double) * ACC_NV * bd.n_part, s) || h->counters.ensure(64, s))
+      h->partials.ensure(sizeof(double) * ACC_NV * bd.n_part, s))
     return done(GLOC_ERR_NOMEM);
   const DevScan &sc = tmp.scans[0], &tg = tmp.scans[1];
   Job jd{sc.idx.pts, sc.order, sc.idx.inv, tg.xyz, tg.idx, (uint32_t)n_src, ng, 0u, 0u};
@@ -712,8 +712,10 @@ int gloc_reg_nn_stats(gloc_reg* h, uint64_t* pairs_evaluated, uint64_t* launches
   GLOC_HIP(hipSetDevice(h->device));
   unsigned long long c = 0;
   if (h->counters.p) {
-    GLOC_HIP(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    std::vector<unsigned long long> part(NN_STAT_SLOTS);
+    GLOC_HIP(hipMemcpyAsync(part.data(), h->counters.p, 8 * NN_STAT_SLOTS, hipMemcpyDeviceToHost, h->stream));
     GLOC_HIP(hipStreamSynchronize(h->stream));
+    for (unsigned long long v : part) c += v;
   }
   if (pairs_evaluated) *pairs_evaluated = c;
   if (launches) *launches = h->nn_launches;
@@ -750,7 +752,7 @@ int gloc_reg_debug_trace(gloc_reg* h, int enable, uint32_t* out, size_t cap_wave
   if (n_waves) *n_waves = h->trace_waves;
   if (out && h->trace.p) {
     const size_t n = std::min(cap_waves, h->trace_waves);
-    GLOC_HIP(hipMemcpyAsync(out, h->trace.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    GLOC_HIP(hipMemcpyAsync(out, h->trace.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     GLOC_HIP(hipStreamSynchronize(h->stream));
   }
   return GLOC_OK;
@@ -772,7 +774,7 @@ int gloc_reg_profile_reset(gloc_reg* h) {
   GLOC_HIP(hipStreamSynchronize(h->stream));
   h->prof.reset();
   h->nn_launches = 0;
-  if (h->counters.p) GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 64, h->stream));
+  if (h->counters.p) GLOC_HIP(hipMemsetAsync(h->counters.p, 0, 8 * NN_STAT_SLOTS, h->stream));
   return GLOC_OK;
 }
 

@@ -30,8 +30,11 @@ struct ScanIndexDev {
   const f32x4* pts;      // Hilbert order: x, y, z, bits(original index)
   const f32x4* box_lo;   // per chunk of CH points
   const f32x4* box_hi;
-  const f32x4* sb_lo;    // per sub-block of SB points
-  const f32x4* sb_hi;
+  // boxes of the sub-blocks of SB points, two sub-blocks (2q, 2q+1) interleaved in 3 float4:
+  // (lo0.x lo1.x lo0.y lo1.y) (lo0.z lo1.z hi0.x hi1.x) (hi0.y hi1.y hi0.z hi1.z) -- a lane tests one
+  // point against both with packed fp32 instructions, the pairs being register pairs as loaded
+  const f32x4* sb2;
+  const void* reserved_;
   const uint32_t* keys;  // sorted curve keys
   const uint32_t* inv;   // original index -> sorted position
   const ScanHeader* hdr;

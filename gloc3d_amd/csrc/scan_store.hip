@@ -116,10 +116,14 @@ __global__ void morton_keys_kernel(const float* __restrict__ xyz, uint32_t n,
 }
 
 __global__ void gather_sorted_kernel(const float* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                     uint32_t n, f32x4* __restrict__ pts,
+                                     uint32_t n, uint32_t n_pad, f32x4* __restrict__ pts,
                                      uint32_t* __restrict__ inv) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+  if (s >= n_pad) return;
+  if (s >= n) {  // padding of the last chunk: farther than any real point, an index that never wins a tie
+    pts[s] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
+    return;
+  }
   const uint32_t o = perm[s];
   pts[s] = f32x4{xyz[3 * (size_t)o], xyz[3 * (size_t)o + 1], xyz[3 * (size_t)o + 2],
                  __uint_as_float(o)};
@@ -175,22 +179,30 @@ __global__ __launch_bounds__(64) void super_boxes_kernel(const f32x4* __restrict
 }
 
 // one thread per sub-block of SB points
-__global__ void subblock_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n, uint32_t nsb,
-                                      f32x4* __restrict__ lo, f32x4* __restrict__ hi) {
+// one thread per PAIR of sub-blocks; a sub-block past the end of the scan gets an empty (inverted) box
+__global__ void subblock_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n, uint32_t npairs,
+                                      f32x4* __restrict__ sb2) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nsb) return;
-  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-  for (uint32_t t = 0; t < SB; ++t) {
-    const uint32_t j = b * SB + t;
-    if (j < n) {
-      const f32x4 p = pts[j];
-      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  if (b >= npairs) return;
+  float mn[2][3], mx[2][3];
+  for (int h = 0; h < 2; ++h) {
+    for (int a = 0; a < 3; ++a) {
+      mn[h][a] = 3.4e38f;
+      mx[h][a] = -3.4e38f;
+    }
+    for (uint32_t t = 0; t < SB; ++t) {
+      const uint32_t j = (2 * b + h) * SB + t;
+      if (j < n) {
+        const f32x4 p = pts[j];
+        mn[h][0] = fminf(mn[h][0], p.x); mx[h][0] = fmaxf(mx[h][0], p.x);
+        mn[h][1] = fminf(mn[h][1], p.y); mx[h][1] = fmaxf(mx[h][1], p.y);
+        mn[h][2] = fminf(mn[h][2], p.z); mx[h][2] = fmaxf(mx[h][2], p.z);
+      }
     }
   }
-  lo[b] = f32x4{mn[0], mn[1], mn[2], 0.f};
-  hi[b] = f32x4{mx[0], mx[1], mx[2], 0.f};
+  sb2[3 * (size_t)b + 0] = f32x4{mn[0][0], mn[1][0], mn[0][1], mn[1][1]};
+  sb2[3 * (size_t)b + 1] = f32x4{mn[0][2], mn[1][2], mx[0][0], mx[1][0]};
+  sb2[3 * (size_t)b + 2] = f32x4{mx[0][1], mx[1][1], mx[0][2], mx[1][2]};
 }
 
 // Spatial extent of every group of `group` consecutive (Hilbert-sorted) points: the squared diagonal
@@ -247,18 +259,21 @@ __global__ void scan_variant_kernel(const float* __restrict__ xyz, uint32_t n, c
 namespace {
 
 struct Layout {
-  size_t bytes, n1, c1, b1, u1, g1;
+  size_t bytes, n1, np, c1, b1, u1, g1;
 };
 Layout layout_for(size_t n) {
   Layout L;
-  const size_t nch = (n + CH - 1) / CH, nsb = (n + SB - 1) / SB, nsup = (nch + 63) / 64;
+  const size_t nch = (n + CH - 1) / CH, nsup = (nch + 63) / 64;
   L.n1 = std::max<size_t>(n, 1);
   L.c1 = std::max<size_t>(nch, 1);
-  L.b1 = std::max<size_t>(nsb, 1);
+  // the sorted points and the sub-block boxes are padded to whole chunks (far sentinels / empty boxes),
+  // so that the search kernel stages a chunk and re-reads a sub-block without bounds checks
+  L.np = L.c1 * CH;
+  L.b1 = L.c1 * (CH / SB / 2) * 3;  // float4 per scan of the paired sub-block boxes
   L.u1 = std::max<size_t>(nsup, 1);
   L.g1 = (L.n1 + 63) / 64;
-  // header | pts4 | box_lo | box_hi | sb_lo | sb_hi | sup_lo | sup_hi | xyz | keys | inv | order
-  L.bytes = sizeof(ScanHeader) + sizeof(f32x4) * (L.n1 + 2 * L.c1 + 2 * L.b1 + 2 * L.u1) +
+  // header | pts4 | box_lo | box_hi | sb2 | sup_lo | sup_hi | xyz | keys | inv | order
+  L.bytes = sizeof(ScanHeader) + sizeof(f32x4) * (L.np + 2 * L.c1 + L.b1 + 2 * L.u1) +
             sizeof(float) * 3 * L.n1 + sizeof(uint32_t) * (2 * L.n1 + L.g1);
   return L;
 }
@@ -325,21 +340,20 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
   DevScan s;
   s.n = n;
   const Layout L = layout_for(n);
-  const size_t nch = (n + CH - 1) / CH, nsb = (n + SB - 1) / SB, nsup = (nch + 63) / 64;
+  const size_t nch = (n + CH - 1) / CH, nsup = (nch + 63) / 64;
   GLOC_TRY(take_block(st, L.bytes, &s.block, &s.block_bytes));
   ScanHeader* hdr = reinterpret_cast<ScanHeader*>(s.block);
   f32x4* p4 = reinterpret_cast<f32x4*>(hdr + 1);
-  f32x4* lo = p4 + L.n1;
+  f32x4* lo = p4 + L.np;
   f32x4* hi = lo + L.c1;
-  f32x4* slo = hi + L.c1;
-  f32x4* shi = slo + L.b1;
-  f32x4* ulo = shi + L.b1;
+  f32x4* sb2 = hi + L.c1;
+  f32x4* ulo = sb2 + L.b1;
   f32x4* uhi = ulo + L.u1;
   s.xyz = reinterpret_cast<float*>(uhi + L.u1);
   uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * L.n1);
   uint32_t* inv = keys + L.n1;
   s.order = inv + L.n1;
-  s.idx = ScanIndexDev{p4, lo, hi, slo, shi, keys, inv, hdr, ulo, uhi, (uint32_t)n, (uint32_t)nch,
+  s.idx = ScanIndexDev{p4, lo, hi, sb2, nullptr, keys, inv, hdr, ulo, uhi, (uint32_t)n, (uint32_t)nch,
                        (uint32_t)nsup, 0u};
   hipStream_t q = st->stream;
   auto fail = [&](int code) {
@@ -380,11 +394,11 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
                                            st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
                                            (int)n, 0, 30, q) != hipSuccess)
       return fail(GLOC_ERR_HIP);
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nb), dim3(256), 0, q, s.xyz, st->sort_perm.as<uint32_t>(),
-                       (uint32_t)n, p4, inv);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, q, s.xyz,
+                       st->sort_perm.as<uint32_t>(), (uint32_t)n, (uint32_t)L.np, p4, inv);
     hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, q, p4, (uint32_t)n, lo, hi);
-    hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, q, p4,
-                       (uint32_t)n, (uint32_t)nsb, slo, shi);
+    hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((L.b1 / 3 + 255) / 256)), dim3(256), 0, q, p4,
+                       (uint32_t)n, (uint32_t)(L.b1 / 3), sb2);
     hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, q, lo, hi, (uint32_t)nch, ulo, uhi);
     if (hipGetLastError() != hipSuccess) {
       set_err("scan indexing failed: %s", hipGetErrorString(hipGetLastError()));

@@ -21,12 +21,13 @@ f(reg._h, 1, None, 0, None)
 prm = capi.default_reg_params(ransac_iters=3000, icp_iters=int(sys.argv[1]) if len(sys.argv) > 1 else 20, max_rmse=1.0)
 r = reg.batch_ids(qid, cands, params=prm)
 n = C.c_size_t(); f(reg._h, 1, None, 0, C.byref(n))
-tr = np.zeros((n.value, 4), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
-# block b -> job b % 20 (one group of 20 jobs), wg b // 20; 4 waves per block
-nb = n.value // 4
-job = (np.arange(nb) % 20).repeat(4)
+tr = np.zeros((n.value, 8), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+job = tr[:, 6]
 ok = tr[:, 0] > 0
 print("ok", r["ok"], "rmse", np.round(r["rmse"], 2))
 for name, sel in (("positives", np.isin(job, [c for c in range(20) if c % 4 != 1])), ("negatives", np.isin(job, [c for c in range(20) if c % 4 == 1]))):
     t = tr[ok & sel].astype(np.float64)
-    print(f"{name}: waves {len(t)} cycles mean {t[:,0].mean():.0f} p50 {np.percentile(t[:,0],50):.0f} p99 {np.percentile(t[:,0],99):.0f} max {t[:,0].max():.0f} | cand chunks {t[:,1].mean():.1f} processed {t[:,2].mean():.1f} rounds {t[:,3].mean():.1f}")
+    tot, chunks, pro, epi = t[:, 0], t[:, 1], t[:, 5], t[:, 7]
+    sweep = tot - chunks - pro - epi
+    print(f"{name}: waves {len(t)} cycles mean {tot.mean():.0f} p50 {np.percentile(tot,50):.0f} p99 {np.percentile(tot,99):.0f} max {tot.max():.0f}")
+    print(f"   prologue {pro.mean():.0f}  sweep outside chunks {sweep.mean():.0f}  chunk processing {chunks.mean():.0f} ({t[:,2].mean():.1f} chunks, {t[:,3].mean():.1f} rounds, {t[:,4].mean():.0f} items)  recovery+outputs {epi.mean():.0f}")

@@ -43,6 +43,67 @@ constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evalu
 #define GLOC_NN_WAVES_PER_EU 4
 #endif
 
+// Wave-wide min / max without the LDS crossbar: four DPP steps inside every row of 16 lanes (quad
+// swaps, then the half-row and row mirrors: after each step the lanes already paired hold one value,
+// so a mirror reaches the same partner set as an xor), then the four row values through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float x) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  x = op(x, dpp_f32<0xB1>(x));   // quad_perm [1,0,3,2]
+  x = op(x, dpp_f32<0x4E>(x));   // quad_perm [2,3,0,1]
+  x = op(x, dpp_f32<0x141>(x));  // row_half_mirror
+  x = op(x, dpp_f32<0x140>(x));  // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+  return op(op(r0, r1), op(r2, r3));
+}
+
+// Lane exchanges of fp64 values without the LDS crossbar (ds_bpermute kept the LDS pipe busy and was
+// worth 6 % of the launch).  xor_lane<O>(x) = x of lane (l ^ O) for O < 16, through DPP:
+template <int O>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t x) {
+  static_assert(O == 1 || O == 2 || O == 4 || O == 8, "inside a row of 16 lanes");
+  if (O == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  if (O == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  if (O == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);  // row_ror:8
+  // xor 4: row_ror:12 for the banks whose lanes have bit 2 clear (they read lane + 4), row_ror:4 for the others
+  const int a = __builtin_amdgcn_update_dpp(0, (int)x, 0x12C, 0xF, 0x5, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)x, 0x124, 0xF, 0xA, false);
+}
+template <int O>
+__device__ __forceinline__ double xor_lane(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned long long r = ((unsigned long long)xor_lane_u32<O>((uint32_t)(u >> 32)) << 32) | xor_lane_u32<O>((uint32_t)u);
+  return __builtin_bit_cast(double, r);
+}
+// The reduce-scatter exchange at distance 32 (16): a lane with that bit clear keeps x and hands y to its
+// partner, a lane with it set keeps y and hands x over.  gfx950's v_permlane32_swap (v_permlane16_swap)
+// moves the handed-over halves in place: afterwards EVERY lane holds (kept, received) in some order in
+// (x, y), so the node's sum is x + y (addition commutes: same bits as kept + received).
+template <int O>
+__device__ __forceinline__ double exchange_add(double x, double y) {
+  static_assert(O == 32 || O == 16, "whole rows");
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned long long ux = __builtin_bit_cast(unsigned long long, x), uy = __builtin_bit_cast(unsigned long long, y);
+  u32x2 lo, hi;
+  if (O == 32) {
+    lo = __builtin_amdgcn_permlane32_swap((unsigned)ux, (unsigned)uy, false, false);
+    hi = __builtin_amdgcn_permlane32_swap((unsigned)(ux >> 32), (unsigned)(uy >> 32), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap((unsigned)ux, (unsigned)uy, false, false);
+    hi = __builtin_amdgcn_permlane16_swap((unsigned)(ux >> 32), (unsigned)(uy >> 32), false, false);
+  }
+  const double nx = __builtin_bit_cast(double, ((unsigned long long)hi.x << 32) | lo.x);
+  const double ny = __builtin_bit_cast(double, ((unsigned long long)hi.y << 32) | lo.y);
+  return nx + ny;
+}
+
 // grid = n_wg * n_jobs work-groups of 4 independent waves.  Jobs are taken `job_group` at a time; within
 // a group the job index runs fastest (every job's widest source groups -- `order` lists them widest
 // first -- start together and finish under cover of the bulk), so that at any time the work-groups in
@@ -126,12 +187,11 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     wlo[2] = fminf(wlo[2], pz[s]); whi[2] = fmaxf(whi[2], pz[s]);
     best[s] = 3.402823466e+38f;
   }
-  for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      wlo[a] = fminf(wlo[a], __shfl_xor(wlo[a], o));
-      whi[a] = fmaxf(whi[a], __shfl_xor(whi[a], o));
-    }
+  for (int a = 0; a < 3; ++a) {
+    wlo[a] = wave_minmax<false>(wlo[a]);
+    whi[a] = wave_minmax<true>(whi[a]);
+  }
 
   // ---- upper bounds -> LDS state -----------------------------------------------------------------
   // warm: the previous pass's correspondence (a sorted position: one coherent 16-byte gather);
@@ -174,8 +234,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     float m = -1.f;
 #pragma unroll
     for (int s = 0; s < CS; ++s) m = fmaxf(m, valid[s] ? best[s] : -1.f);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return m;
+    return wave_minmax<true>(m);
   };
   float wmax = wave_max_best();
   const unsigned long long t_pro = trace ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -455,13 +514,41 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     }
   }
   if (partials) {
+    // Sum over the 64 lanes in the order of the xor butterfly (o = 32, 16, ..., 1), but as a
+    // reduce-scatter: at every step a lane keeps half of its values and hands the other half to its
+    // partner, so 16 values cost 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6.  value[l] + value[l ^ o]
+    // is what both forms compute at every node of the tree: the results are bit-identical to the
+    // plain butterfly of rounds 1-2.  Lane l ends with moment (l >> 2) & 15 (all four lanes of a quad).
+    static_assert(ACC_NV == 17, "16 scattered moments + the d2 sum");
     double* out = partials + ((size_t)job * n_part + gi) * ACC_NV;
 #pragma unroll
-    for (int k = 0; k < ACC_NV; ++k) {
-      double x = v[k];
-      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);  // butterfly: a fixed order
-      if (lane == 0) out[k] = x;
+    for (int k = 0; k < 8; ++k) v[k] = exchange_add<32>(v[k], v[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = exchange_add<16>(v[k], v[k + 4]);
+    {
+      const bool up = (lane & 8) != 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double keep = up ? v[k + 2] : v[k], send = up ? v[k] : v[k + 2];
+        v[k] = keep + xor_lane<8>(send);
+      }
     }
+    {
+      const bool up = (lane & 4) != 0;
+      const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+      v[0] = keep + xor_lane<4>(send);
+    }
+    double x = v[0], y = v[16];
+    x += xor_lane<2>(x);
+    x += xor_lane<1>(x);
+    y = exchange_add<32>(y, y);
+    y = exchange_add<16>(y, y);
+    y += xor_lane<8>(y);
+    y += xor_lane<4>(y);
+    y += xor_lane<2>(y);
+    y += xor_lane<1>(y);
+    if ((lane & 3) == 0) out[(lane >> 2) & 15] = x;
+    if (lane == 0) out[16] = y;
   }
   if (trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;

@@ -39,6 +39,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int NN_WPB = GLOC_NN_WPB;
 constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evaluated statistic
+#ifndef GLOC_NN_TU
+#define GLOC_NN_TU 1  // sub-block test steps unrolled together (4 measured 6 % slower: most chunks list < 16 sources)
+#endif
 #ifndef GLOC_NN_WAVES_PER_EU
 #define GLOC_NN_WAVES_PER_EU 4
 #endif
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0, n_listed = 0;
+  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0, n_listed = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0;
   unsigned long long n_items = 0;
 
   float px[CS], py[CS], pz[CS], best[CS];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
       lbs = box_box_lb(ulo, uhi);
     }
-    unsigned long long smask = __ballot(lbs <= wmax);
+    unsigned long long smask = __builtin_amdgcn_ballot_w64(lbs <= wmax);
     // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
     f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
     int cur = -1;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
     float lbw = 3.402823466e+38f;
     if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
-    unsigned long long mask = __ballot(lbw <= wmax);
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
     while (mask) {
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
@@ -293,12 +296,26 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       hi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.y), b));
       hi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.z), b));
       bool need[CS], any_need = false;
+      if constexpr (CS == 2) {  // box_lb() of the lane's two points per packed instruction
+        const f32x2 qx = {px[0], px[1]}, qy = {py[0], py[1]}, qz = {pz[0], pz[1]};
+        const f32x2 ax = f32x2{lo.x, lo.x} - qx, bx = qx - f32x2{hi.x, hi.x};
+        const f32x2 ay = f32x2{lo.y, lo.y} - qy, by = qy - f32x2{hi.y, hi.y};
+        const f32x2 az = f32x2{lo.z, lo.z} - qz, bz = qz - f32x2{hi.z, hi.z};
+        const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
+        const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
+        const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
+        const f32x2 lb = ((ex * ex + ey * ey) + ez * ez) * f32x2{0.99999905f, 0.99999905f};
+        need[0] = valid[0] && lb.x <= best[0];
+        need[1] = valid[1] && lb.y <= best[1];
+        any_need = need[0] || need[1];
+      } else {
 #pragma unroll
-      for (int s = 0; s < CS; ++s) {
-        need[s] = valid[s] && (box_lb(px[s], py[s], pz[s], lo, hi) <= best[s]);
-        any_need |= need[s];
+        for (int s = 0; s < CS; ++s) {
+          need[s] = valid[s] && (box_lb(px[s], py[s], pz[s], lo, hi) <= best[s]);
+          any_need |= need[s];
+        }
       }
-      if (!__any(any_need)) continue;
+      if (__builtin_amdgcn_ballot_w64(any_need) == 0ull) continue;
       n_processed++;
       const unsigned long long t_c0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       uint32_t k = 0;
 #pragma unroll
       for (int s = 0; s < CS; ++s) {
-        const unsigned long long m = __ballot(need[s]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(need[s]);
         if (need[s])
           L.list[k + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
               (uint16_t)(s * 64 + lane);
@@ -331,10 +348,10 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       const f32x2 lox = {bA.x, bA.y}, loy = {bA.z, bA.w}, loz = {bB.x, bB.y};
       const f32x2 hix = {bB.z, bB.w}, hiy = {bC.x, bC.y}, hiz = {bC.z, bC.w};
       const uint32_t sb0 = (lane & 3) * 2;
-      uint32_t total = 0;
+      uint32_t total = 0, sbmask = 0;
       // four steps of 16 sources at a time: their LDS reads and box tests are independent, so a wave
       // (latency-bound when few share the SIMD) overlaps them; only the queue positions are serial
-      constexpr int TU = 4;
+      constexpr int TU = GLOC_NN_TU;
       for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
         uint32_t si[TU];
         bool act[TU];
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
           const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
           const f32x2 lb = ((ex * ex + ey * ey) + ez * ez) * f32x2{0.99999905f, 0.99999905f};
           const bool nd0 = act[u] && lb.x <= bst[u], nd1 = act[u] && lb.y <= bst[u];
-          const unsigned long long m0 = __ballot(nd0), m1 = __ballot(nd1);
+          const unsigned long long m0 = __builtin_amdgcn_ballot_w64(nd0), m1 = __builtin_amdgcn_ballot_w64(nd1);
           const uint32_t c0n = (uint32_t)__popcll(m0);
           if (nd0)
             L.queue[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] =
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
             L.queue[total + c0n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] =
                 (uint16_t)((si[u] << 3) | (sb0 + 1));
           total += c0n + (uint32_t)__popcll(m1);
+          if (trace) sbmask |= (nd0 ? (1u << sb0) : 0u) | (nd1 ? (2u << sb0) : 0u);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -377,6 +395,13 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       n_items += total;
       n_listed += k;
+      if (trace) {
+        uint32_t lm = 0;
+        for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;
+        n_live_sb += (uint32_t)__popc(lm);
+        n_live_pairs += (uint32_t)__popc((lm | (lm >> 1)) & 0x55u);
+        n_steps += (k + 15) / 16;
+      }
       for (uint32_t r = 0; r < total; r += 64) {
         n_rounds++;
         const uint32_t it = r + lane;
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
         changed |= nb < best[s];
         best[s] = nb;
       }
-      if (__any(changed)) wmax = wave_max_best();
+      if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax = wave_max_best();
       if (trace) t_chunks += __builtin_amdgcn_s_memtime() - t_c0;
     }
     }  // batches of this super-chunk group
@@ -559,7 +584,8 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     trace[8 * wid + 4] = (uint32_t)n_items;
     trace[8 * wid + 5] = (uint32_t)(t_pro - t_start);  // prologue cycles
     trace[8 * wid + 6] = job;
-    trace[8 * wid + 7] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_sweep);  // recovery + outputs
+    trace[8 * wid + 7] = (n_live_sb << 20) | (n_live_pairs << 10) | n_steps;  // per wave: live sub-blocks, live pairs, test steps
+    (void)t_sweep;
   }
 }
 

@@ -27,7 +27,11 @@ ok = tr[:, 0] > 0
 print("ok", r["ok"], "rmse", np.round(r["rmse"], 2))
 for name, sel in (("positives", np.isin(job, [c for c in range(20) if c % 4 != 1])), ("negatives", np.isin(job, [c for c in range(20) if c % 4 == 1]))):
     t = tr[ok & sel].astype(np.float64)
-    tot, chunks, pro, epi = t[:, 0], t[:, 1], t[:, 5], t[:, 7]
-    sweep = tot - chunks - pro - epi
+    tot, chunks, pro = t[:, 0], t[:, 1], t[:, 5]
+    w7 = tr[ok & sel][:, 7]
+    live_sb, live_pairs, steps = (w7 >> 20), (w7 >> 10) & 1023, w7 & 1023
+    epi = 0 * tot
+    sweep = tot - chunks - pro
     print(f"{name}: waves {len(t)} cycles mean {tot.mean():.0f} p50 {np.percentile(tot,50):.0f} p99 {np.percentile(tot,99):.0f} max {tot.max():.0f}")
-    print(f"   prologue {pro.mean():.0f}  sweep outside chunks {sweep.mean():.0f}  chunk processing {chunks.mean():.0f} ({t[:,2].mean():.1f} chunks, {t[:,3].mean():.1f} rounds, {t[:,4].mean():.0f} items)  recovery+outputs {epi.mean():.0f}")
+    print(f"   prologue {pro.mean():.0f}  sweep outside chunks {sweep.mean():.0f}  chunk processing {chunks.mean():.0f} ({t[:,2].mean():.1f} chunks, {t[:,3].mean():.1f} rounds, {t[:,4].mean():.0f} items)  ")
+    print(f"   per processed chunk: listed {t[:,5].sum() and 0 or 0} live sub-blocks {live_sb.sum()/t[:,2].sum():.2f} of 8, live pairs {live_pairs.sum()/t[:,2].sum():.2f} of 4, test steps {steps.sum()/t[:,2].sum():.2f}, items {t[:,4].sum()/t[:,2].sum():.1f}")

@@ -520,8 +520,10 @@ def main():
             issue_model = {"valu_per_wave": pw["valu"], "salu_per_wave": pw.get("salu"), "lds_per_wave": pw.get("lds"),
                            "vmem_per_wave": pw.get("vmem_rd"), "waves_per_launch": waves,
                            "vector_lane_ops_per_s": lane_ops, "frac_of_vector_issue_peak": lane_ops / (PEAK_FP32_TFLOPS * 1e12 / 2),
-                           "source": "profiles/r02_pmc_traffic_nn_compact.json (SQ_INSTS_* / SQ_WAVES); SQ_ACTIVE_INST_VALU puts the "
-                                     "vector pipe at 65-77 % busy: most instructions are 2.3-4.2-cycle forms, not 1-per-clock"}
+                           "valu_busy_frac_under_pmc": pj.get("valu_busy_frac"),
+                           "source": "profiles/r02_pmc_traffic_nn_compact.json (SQ_INSTS_* / SQ_WAVES; busy = SQ_ACTIVE_INST_VALU "
+                                     "over SQ_BUSY_CYCLES): the vector pipes are busy for that fraction of the launch, a wave64 "
+                                     "instruction holding its SIMD for 4 cycles (8 for fp64 and the packed-fp32 forms)"}
     if args.nn_mode == "exhaustive":
         ach = FLOP_PER_PAIR * all_pairs / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         roofline = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -32,6 +32,7 @@ struct gloc_knn {
   DevBuf exact;     // rerank: reference-order distances [nq][KC]
   DevBuf keys2;     // rerank output [nq][k]
   DevBuf qnorm;     // [nq]
+  DevBuf dev_trace; // developer aid: phase stamps of the fused select + re-rank kernel (null unless enabled)
   DevBuf flags;     // [nq] int
   DevBuf stage_q;   // host-API staging: queries
   DevBuf stage_idx, stage_d2;
@@ -118,6 +119,14 @@ template <int MODE>
 int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
                int n_splits, uint64_t* d_keys_out, const int* only_flagged = nullptr) {
   ProfScope ps(h->prof, "select", h->stream);
+  static const bool no_selq = getenv("GLOC3D_KNN_NO_SELECT_QUERY") != nullptr;  // developer switch: the chunked form
+  if (n_range <= SELQ_MAX_ROWS && K <= 64 && !no_selq) {  // one launch, one work-group per query
+    hipLaunchKernelGGL(select_query_kernel<MODE>, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
+                       strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, h->norms.as<float>(), first, n_range,
+                       K, d_keys_out, only_flagged);
+    GLOC_HIP(hipGetLastError());
+    return GLOC_OK;
+  }
   const int per_group = SEL_LIST / K;  // lists one merge can take
   int E = (n_range + 256 * per_group - 1) / (256 * per_group);
   E = std::max(E, 8);
@@ -221,8 +230,10 @@ void launch_mfma_inst(gloc_knn* h, const MfmaPlan& p, const float* d_q, int nq, 
                        nq, kps, ld, strideP);
 }
 
+// *finalized: the result (indices, distances) has been written through `fo` already -- no finalize launch
 int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
-             uint64_t* d_keys_out) {
+             uint64_t* d_keys_out, const FinalOut& fo, bool* finalized) {
+  *finalized = false;
   const MfmaPlan p = plan_mfma(nq, n_range, (int)h->dim);
   const int KC = std::max(h->candidates, std::min(64, k + 12));
   const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
@@ -249,6 +260,36 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 #undef MF
     GLOC_HIP(hipGetLastError());
   }
+  // rounding bound of the coarse distance against the reference-order distance:
+  //   reference chain          (D/4 + 4) u d2
+  //   MFMA chains of <= 64 fma, nch partial sums, KS split sums, norms (D/64 + 6), 3 final ops
+  const float u = 5.9604645e-8f;
+  const int kps = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+  const float eps_rel_d = 1.05f * u * (float)(h->dim / 4 + 4);
+  const float eps_rel_n = 1.05f * u * (float)(64 + (kps + 63) / 64 + p.KS + h->dim / 64 + 6 + 3 + 4);
+  static const bool no_fused = getenv("GLOC3D_KNN_NO_FUSED_RERANK") != nullptr;  // developer switch: the three launches
+  const bool fused = n_range <= SELQ_MAX_ROWS && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
+  if (fused) {
+    // select + re-rank + completeness check in one launch, one work-group per query
+    ProfScope ps(h->prof, "select_rerank", h->stream);
+    hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
+                       strideP, p.KS, d_q, (int)h->dim, h->norms.as<float>(), first, n_range, KC, k,
+                       h->rows.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n, h->qnorm.as<float>(),
+                       d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo,
+                       h->dev_trace.as<unsigned long long>());
+    GLOC_HIP(hipGetLastError());
+    // incomplete queries (rare) are redone exactly ON THE DEVICE by one more launch whose work-groups leave
+    // at once unless their query's flag is set: no read-back, no host synchronisation.  (The coarse partial
+    // dots in h->dist are dead by now: the exact distances of a flagged query reuse the buffer, row q at q * ld.)
+    hipLaunchKernelGGL(fallback_exact_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->flags.as<int>(),
+                       h->rows.as<float>(), d_q, (int)h->dim, first, n_range, k, h->dist.as<float>(), ld, d_keys_out, fo);
+    GLOC_HIP(hipGetLastError());
+    h->stats.last_n_tile = (uint32_t)p.BN;
+    h->stats.last_k_split = (uint32_t)p.KS;
+    h->stats.last_candidates = (uint32_t)KC;
+    *finalized = fo.idx != nullptr;
+    return GLOC_OK;
+  } else {
   // (the query norms of the coarse form are made by the select kernel, which leaves them in h->qnorm)
   GLOC_TRY(run_select<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));
   {
@@ -256,10 +297,6 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     //   reference chain          (D/4 + 4) u d2
     //   MFMA chains of <= 64 fma, nch partial sums, KS split sums, norms (D/64 + 6), 3 final ops
     ProfScope ps(h->prof, "rerank", h->stream);
-    const float u = 5.9604645e-8f;
-    const int kps = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
-    const float eps_rel_d = 1.05f * u * (float)(h->dim / 4 + 4);
-    const float eps_rel_n = 1.05f * u * (float)(64 + (kps + 63) / 64 + p.KS + h->dim / 64 + 6 + 3 + 4);
     GLOC_TRY(h->exact.ensure((size_t)nq * KC * sizeof(float), h->stream));
     hipLaunchKernelGGL(rerank_dist_kernel, dim3((KC + RR - 1) / RR, nq), dim3(64), 0, h->stream,
                        h->rows.as<float>(), d_q, (int)h->dim, h->keys.as<uint64_t>(), KC, k,
@@ -270,6 +307,7 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
                        h->qnorm.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n,
                        d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>());
     GLOC_HIP(hipGetLastError());
+  }
   }
   h->stats.last_n_tile = (uint32_t)p.BN;
   h->stats.last_k_split = (uint32_t)p.KS;
@@ -315,7 +353,9 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
   GLOC_REQUIRE(range < (1ull << 31), GLOC_ERR_INVALID, "row window too large");
   GLOC_TRY(h->keys2.ensure(nq * k * sizeof(uint64_t), h->stream));
   uint64_t* keys_out = h->keys2.as<uint64_t>();
+  bool all_final = true;  // every block of queries left its result in d_idx / d_d2 itself
   if (range == 0) {
+    all_final = false;
     GLOC_HIP(hipMemsetAsync(keys_out, 0xFF, nq * k * sizeof(uint64_t), h->stream));
   } else {
     int algo = h->algo;
@@ -330,17 +370,20 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
       const int cnt = (int)std::min(qblk, nq - q0);
       if (algo == GLOC_KNN_ALGO_MFMA) {
         h->stats.searches_mfma++;
-        GLOC_TRY(run_mfma(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range,
-                          keys_out + q0 * k));
+        bool fin = false;
+        const FinalOut fo{d_idx + q0 * k, d_d2 + q0 * k, index_offset, index_stride};
+        GLOC_TRY(run_mfma(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range, keys_out + q0 * k, fo, &fin));
+        all_final = all_final && fin;
       } else {
         h->stats.searches_exact++;
+        all_final = false;
         GLOC_TRY(run_exact(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range,
                            keys_out + q0 * k));
       }
     }
   }
   h->stats.queries_total += nq;
-  {
+  if (!all_final) {
     ProfScope ps(h->prof, "finalize", h->stream);
     const size_t total = nq * k;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -391,6 +434,7 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->exact.release();
   h->keys2.release();
   h->qnorm.release();
+  h->dev_trace.release();
   h->flags.release();
   h->stage_q.release();
   h->stage_idx.release();
@@ -406,6 +450,23 @@ int gloc_knn_set_stream(gloc_knn* h, void* hip_stream) {
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_HIP(hipStreamSynchronize(h->stream));
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return GLOC_OK;
+}
+
+// Developer aid (not part of include/gloc3d.h): phase stamps [nq][16] of the LAST fused select + re-rank launch.
+int gloc_knn_debug_trace(gloc_knn* h, int enable_nq, unsigned long long* out, size_t n_words) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  if (out && h->dev_trace.p) {
+    GLOC_HIP(hipMemcpyAsync(out, h->dev_trace.p, n_words * 8, hipMemcpyDeviceToHost, h->stream));
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (enable_nq > 0) {
+    GLOC_TRY(h->dev_trace.ensure((size_t)enable_nq * 128, h->stream));
+  } else if (enable_nq < 0) {
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+    h->dev_trace.release();
+  }
   return GLOC_OK;
 }
 

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lane_ops.hpp"
+
 namespace gloc {
 namespace knn {
 
@@ -528,6 +530,188 @@ __global__ __launch_bounds__(256) void select_chunk_kernel(
   for (int i = tid; i < K; i += 256) o[i] = (i < c) ? buf[i] : KEY_SENTINEL;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (top-k part), one launch: ONE work-group of 1024 threads per query selects the K <= 64 smallest
+// keys of up to 16 384 rows -- no chunk lists, no merge launch, no sort through LDS barriers:
+//   1  every thread forms its <= 16 keys (registers) and their minimum;
+//   2  each wave sorts its 64 minima across the lanes (bitonic, register exchanges);
+//   3  a 4-round tournament merges the 16 sorted lists pairwise (the 64 smallest of two sorted lists
+//      are min(a[i], b[63 - i]), a bitonic sequence: six exchange steps sort it) -- wave 0 ends with the
+//      64 smallest thread minima; tau = the K-th of them is an upper bound of the K-th smallest key
+//      (K distinct keys are <= it) and exactly K threads hold a key <= tau;
+//   4  keys <= tau (at most 16 K) are appended to an LDS list; 5  one wave sorts them (<= 64 in
+//      registers, more -- rare -- through the LDS sort) and writes the first K.
+// The round-1 form (256 threads, two LDS bitonic sorts with a barrier per step, five chunk lists and a
+// merge launch) took 21.9 + 9.9 us at 64 x 10 000; this one launch replaces both.
+constexpr int SELQ_THREADS = 1024;
+constexpr int SELQ_EPT = 16;                             // keys per thread
+constexpr int SELQ_MAX_ROWS = SELQ_THREADS * SELQ_EPT;   // 16 384
+
+// one compare-exchange step of the bitonic network at lane distance STRIDE inside blocks of SIZE
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ uint64_t bitonic_step(uint64_t x, int lane) {
+  const uint64_t y = xor_lane_u64<STRIDE>(x);
+  const bool up = SIZE == 64 || (lane & SIZE) == 0;
+  const bool lower = (lane & STRIDE) == 0;
+  // the lower lane of an ascending pair keeps the minimum: keep x when (x < y) says what this lane wants
+  // (equal keys are sentinels: either will do)
+  return ((x < y) == (lower == up)) ? x : y;
+}
+template <int SIZE>
+__device__ __forceinline__ uint64_t bitonic_merge(uint64_t x, int lane) {  // the strides SIZE/2 ... 1
+  if constexpr (SIZE >= 64) x = bitonic_step<SIZE, 32>(x, lane);
+  if constexpr (SIZE >= 32) x = bitonic_step<SIZE, 16>(x, lane);
+  if constexpr (SIZE >= 16) x = bitonic_step<SIZE, 8>(x, lane);
+  if constexpr (SIZE >= 8) x = bitonic_step<SIZE, 4>(x, lane);
+  if constexpr (SIZE >= 4) x = bitonic_step<SIZE, 2>(x, lane);
+  return bitonic_step<SIZE, 1>(x, lane);
+}
+// ascending bitonic sort of one key per lane over the wave (lane exchanges through DPP / permlane swaps:
+// lane_ops.hpp); FULL = false: the input is already bitonic (only the last merge stage runs)
+template <bool FULL>
+__device__ __forceinline__ uint64_t wave_sort_u64(uint64_t x, int lane) {
+  if constexpr (FULL) {
+    x = bitonic_merge<2>(x, lane);
+    x = bitonic_merge<4>(x, lane);
+    x = bitonic_merge<8>(x, lane);
+    x = bitonic_merge<16>(x, lane);
+    x = bitonic_merge<32>(x, lane);
+  }
+  return bitonic_merge<64>(x, lane);
+}
+
+// The selection proper, for the calling work-group's query: leaves the K smallest keys, sorted, in
+// buf[0..K) (padded with the sentinel) and returns after a barrier.  MODE 1 also returns the query's norm.
+template <int MODE>
+__device__ __forceinline__ float selq_select(const float* __restrict__ row, size_t strideP, int n_splits,
+                                             const float* __restrict__ qr, int dim, const float* __restrict__ dn,
+                                             size_t first_row, int n_range, int K, uint64_t* buf /* [SEL_LIST] */,
+                                             float* qred /* [16] */, uint64_t* tau_s, int* cnt,
+                                             unsigned long long* st = nullptr /* dev: 4 stamps */) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the loads of the keys' operands go out before the norm's reduction (one memory round trip, not two)
+  // (split by split with every key slot's load issued before the first use: the first form walked the
+  // splits inside the slot loop and waited for ten round trips in turn -- 6.5 us of a 14-us selection)
+  float dot[SELQ_EPT], dnv[SELQ_EPT];
+#pragma unroll
+  for (int e = 0; e < SELQ_EPT; ++e) {
+    const int j = e * SELQ_THREADS + tid;
+    dot[e] = (j < n_range) ? row[j] : 0.f;
+    dnv[e] = (MODE == 1 && j < n_range) ? dn[first_row + (size_t)j] : 0.f;
+  }
+  if (MODE == 1) {
+    if (n_splits > 1) {  // the usual second split rides in the first batch of loads
+      float part[SELQ_EPT];
+#pragma unroll
+      for (int e = 0; e < SELQ_EPT; ++e) {
+        const int j = e * SELQ_THREADS + tid;
+        part[e] = (j < n_range) ? row[strideP + j] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < SELQ_EPT; ++e) dot[e] += part[e];
+    }
+    for (int sp = 2; sp < n_splits; ++sp) {
+      float part[SELQ_EPT];
+#pragma unroll
+      for (int e = 0; e < SELQ_EPT; ++e) {
+        const int j = e * SELQ_THREADS + tid;
+        part[e] = (j < n_range) ? row[(size_t)sp * strideP + j] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < SELQ_EPT; ++e) dot[e] += part[e];
+    }
+  }
+  float qnv = 0.f;
+  if (MODE == 1) {
+    float sq = 0.f;
+    for (int d = tid; d < dim; d += SELQ_THREADS) sq += qr[d] * qr[d];
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) qred[w] = sq;
+    __syncthreads();
+    for (int i = 0; i < SELQ_THREADS / 64; ++i) qnv += qred[i];  // a fixed order, the same in every thread
+  }
+  // 1: keys and the thread minimum
+  uint64_t key[SELQ_EPT], mn = KEY_SENTINEL;
+#pragma unroll
+  for (int e = 0; e < SELQ_EPT; ++e) {
+    const int j = e * SELQ_THREADS + tid;
+    key[e] = KEY_SENTINEL;
+    if (j < n_range) {
+      const float d = (MODE == 1) ? (qnv + dnv[e]) - 2.f * dot[e] : dot[e];  // as select_key<MODE>
+      key[e] = make_key(d, (uint32_t)(first_row + (size_t)j));
+    }
+    mn = key[e] < mn ? key[e] : mn;
+  }
+  if (st && tid == 0) st[0] = __builtin_amdgcn_s_memtime();
+  // 2: the wave's minima, sorted over its lanes
+  uint64_t x = wave_sort_u64<true>(mn, lane);
+  if (st && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+  // 3: tournament
+  if (tid == 0) *cnt = 0;
+#pragma unroll
+  for (int r = 1; r < SELQ_THREADS / 64; r <<= 1) {
+    if ((w & (2 * r - 1)) == r) buf[w * 64 + lane] = x;  // the partner list
+    __syncthreads();
+    if ((w & (2 * r - 1)) == 0) {
+      const uint64_t y = buf[(w + r) * 64 + (63 - lane)];
+      x = wave_sort_u64<false>(x < y ? x : y, lane);
+    }
+    __syncthreads();
+  }
+  if (w == 0 && lane == K - 1) *tau_s = x;
+  __syncthreads();
+  if (st && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+  const uint64_t tau = *tau_s;
+  // 4: everything <= tau (one LDS atomic per wave and key slot)
+#pragma unroll
+  for (int e = 0; e < SELQ_EPT; ++e) {
+    const bool take = key[e] <= tau && key[e] != KEY_SENTINEL;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(cnt, (int)__popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (take && pos < SEL_LIST) buf[pos] = key[e];
+    }
+  }
+  __syncthreads();
+  if (st && tid == 0) st[3] = __builtin_amdgcn_s_memtime();
+  const int c = *cnt < SEL_LIST ? *cnt : SEL_LIST;
+  if (c <= 64) {  // 5: the usual case -- one wave, in registers
+    uint64_t v = KEY_SENTINEL;
+    if (w == 0) v = wave_sort_u64<true>(lane < c ? buf[lane] : KEY_SENTINEL, lane);
+    __syncthreads();
+    if (w == 0) buf[lane] = v;
+  } else {
+    int n2 = 128;
+    while (n2 < c) n2 <<= 1;
+    for (int i = c + tid; i < n2; i += SELQ_THREADS) buf[i] = KEY_SENTINEL;
+    bitonic_sort_lds(buf, n2, tid, SELQ_THREADS);
+  }
+  __syncthreads();
+  return qnv;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SELQ_THREADS) void select_query_kernel(
+    const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits,
+    float* __restrict__ qn, const float* __restrict__ queries, int dim, const float* __restrict__ dn,
+    size_t first_row, int n_range, int K, uint64_t* __restrict__ out_keys /* [nq][K] */,
+    const int* __restrict__ only_flagged) {
+  __shared__ uint64_t buf[SEL_LIST];     // tournament lists (16 x 64), then the candidate list
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;
+  if (only_flagged && !only_flagged[q]) return;  // uniform over the work-group
+  const float qnv = selq_select<MODE>(dist + (size_t)q * ld, strideP, n_splits, queries + (size_t)q * dim, dim, dn,
+                                      first_row, n_range, K, buf, qred, &tau_s, &cnt);
+  if (MODE == 1 && tid == 0) qn[q] = qnv;
+  if (tid < K) out_keys[(size_t)q * K + tid] = buf[tid];
+}
+
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
 __global__ __launch_bounds__(256) void select_merge_kernel(const uint64_t* __restrict__ in_keys,
                                                            int nlists, int per_group, int K,
@@ -673,6 +857,226 @@ __global__ __launch_bounds__(64) void rerank_final_kernel(
   if (lane == 0) {
     flags[q] = complete ? 0 : 1;
     if (!complete && n_incomplete) atomicAdd(n_incomplete, 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 + K1b in ONE launch (MFMA path, <= 16 384 rows, KC <= 32 candidates, dim <= 4096): the query's
+// work-group selects the KC coarse candidates (selq_select), computes the reference-order distances of
+// the prefix that can reach the top k, ranks them and raises the query's flag when the candidate set
+// may be incomplete -- what select_query + rerank_dist + rerank_final did in three launches, each with
+// a ~4.6 us floor at this size.  Arithmetic identical to rerank_dist_kernel: group sums
+// ((e0^2 + e1^2) + e2^2) + e3^2 of 4 dims, then the reference's sequential chain over the groups.
+//   R1  wave w forms the group sums of candidates w and w + 16 (the query's groups loaded once) into LDS;
+//   R2  4 waves x 8 lanes run the chains (one wave per SIMD: a chain is 1024 dependent adds whichever
+//       lanes are active, so the chains of a SIMD should share instructions, not waves);
+//   F   wave 0 ranks the exact keys.
+constexpr int SRR_KC = 32;
+constexpr int SRR_G = 1024;          // groups of 4 dims held per candidate
+static_assert(SEL_LIST * 8 >= 4 * SRR_G * 4, "the selection's key list doubles as the staged query");
+constexpr int SRR_LD = SRR_G + 4;    // floats per candidate row: 16 bytes of shift spread the chains' reads over the banks
+
+// Where a kernel that ends a search leaves its result directly (what finalize_kernel would make of its keys).
+struct FinalOut {
+  uint64_t* idx;   // [nq][k], null: keys only
+  float* d2;
+  uint64_t offset, stride;
+};
+__device__ __forceinline__ void final_store(const FinalOut& fo, size_t i, uint64_t key) {
+  if (!fo.idx) return;
+  if (key == KEY_SENTINEL) {
+    fo.idx[i] = ~0ull;
+    fo.d2[i] = 3.402823466e+38f;
+  } else {
+    fo.idx[i] = (uint64_t)(uint32_t)key * fo.stride + fo.offset;
+    fo.d2[i] = ord2f((uint32_t)(key >> 32));
+  }
+}
+
+// Reference-order distances of the query (staged in LDS: qs, dim floats) to the m <= 32 rows listed in
+// rows_s (LDS), by the whole work-group of 1024 threads; exact_s[c] = distance to rows_s[c].  Ends with a
+// barrier.  The rows are random 16-KB reads from HBM: a wave keeps the NEXT four groups of its two rows in
+// flight while it works on the current four (the first form waited for four round trips in turn: 8 us).
+__device__ __forceinline__ void srr_exact_batch(const float* __restrict__ db, const float* qs, int dim,
+                                                const uint32_t* rows_s, int m, float* S, float* exact_s,
+                                                unsigned long long* stamp = nullptr /* dev: [1] = after R1 */) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int G = dim >> 2;
+  if (w < m) {  // R1: group sums
+    const int c0 = w, c1 = (w + 16 < m) ? w + 16 : w;  // (c1 == c0: the second row is loaded twice, stored once)
+    const float* r0 = db + (size_t)rows_s[c0] * dim;
+    const float* r1 = db + (size_t)rows_s[c1] * dim;
+    f4u a0[4], a1[4], b0[4], b1[4];
+    auto load = [&](f4u(&x0)[4], f4u(&x1)[4], int gb) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // clamped: unconditional
+        const int g = gb + u * 64 + lane, gc = g < G ? g : G - 1;
+        x0[u] = *reinterpret_cast<const f4u*>(r0 + 4 * (size_t)gc);
+        x1[u] = *reinterpret_cast<const f4u*>(r1 + 4 * (size_t)gc);
+      }
+    };
+    auto work = [&](const f4u(&x0)[4], const f4u(&x1)[4], int gb) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = gb + u * 64 + lane;
+        if (g < G) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + 4 * g);
+          {
+            const float e0 = qv.x - x0[u].x, e1 = qv.y - x0[u].y, e2 = qv.z - x0[u].z, e3 = qv.w - x0[u].w;
+            S[c0 * SRR_LD + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA (as exact_pairs_wave)
+          }
+          if (c1 != c0) {
+            const float e0 = qv.x - x1[u].x, e1 = qv.y - x1[u].y, e2 = qv.z - x1[u].z, e3 = qv.w - x1[u].w;
+            S[c1 * SRR_LD + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+          }
+        }
+      }
+    };
+    load(a0, a1, 0);
+    for (int gb = 0; gb < G; gb += 512) {
+      if (gb + 256 < G) load(b0, b1, gb + 256);
+      work(a0, a1, gb);
+      if (gb + 512 < G) load(a0, a1, gb + 512);
+      if (gb + 256 < G) work(b0, b1, gb + 256);
+    }
+  }
+  __syncthreads();
+  if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+  if (w < 4 && lane < 8) {  // R2: the chains
+    const int c = w * 8 + lane;
+    if (c < m) {
+      const float* sp = S + c * SRR_LD;
+      float acc = 0.f;
+      int i = 0;
+#pragma unroll 8
+      for (; i + 4 <= G; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + i);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+      }
+      for (; i < G; ++i) acc += sp[i];
+      exact_s[c] = acc;
+    }
+  }
+  __syncthreads();
+}
+// the query into LDS (dim <= 4 * SRR_G floats), one group of 4 dims per thread; the caller adds the barrier
+__device__ __forceinline__ void srr_stage_query(const float* __restrict__ qp, int dim, float* qs) {
+  const int g = threadIdx.x;
+  if (g < (dim >> 2)) *reinterpret_cast<f32x4*>(qs + 4 * g) = *reinterpret_cast<const f32x4*>(qp + 4 * (size_t)g);
+}
+
+__global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
+    const float* __restrict__ P, size_t ld, size_t strideP, int n_splits, const float* __restrict__ queries,
+    int dim, const float* __restrict__ dn, size_t first_row, int n_range, int KC, int k,
+    const float* __restrict__ db, const uint32_t* __restrict__ dn_max_bits, float eps_rel_d, float eps_rel_n,
+    float* __restrict__ qn_out, uint64_t* __restrict__ out_keys /* [nq][k] */, int* __restrict__ flags,
+    unsigned long long* __restrict__ n_incomplete, FinalOut fo,
+    unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */) {
+  const unsigned long long t_start = dev_trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  __shared__ __attribute__((aligned(16))) float S[SRR_KC * SRR_LD];
+  __shared__ float exact_s[SRR_KC];
+  __shared__ uint32_t rows_s[SRR_KC];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int q = blockIdx.x;
+  const float* qp = queries + (size_t)q * dim;
+  const float qnv = selq_select<1>(P + (size_t)q * ld, strideP, n_splits, qp, dim, dn, first_row, n_range, KC, buf,
+                                   qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
+  if (tid == 0) qn_out[q] = qnv;
+  if (dev_trace && tid == 0) {
+    dev_trace[q * 16 + 0] = t_start;
+    dev_trace[q * 16 + 1] = __builtin_amdgcn_s_memtime();
+  }
+  // the prefix of candidates that gets reference-order distances (every wave computes the same values)
+  const uint64_t ck = (lane < KC) ? buf[lane] : KEY_SENTINEL;
+  const bool valid = ck != KEY_SENTINEL;
+  const float dco = ord2f((uint32_t)(ck >> 32));
+  const int n_valid = __popcll(__builtin_amdgcn_ballot_w64(valid));
+  const int kk = k < n_valid ? k : n_valid;
+  int m = 0;
+  bool complete = true;
+  if (kk > 0) {
+    const float theta = rerank_theta(__shfl(dco, kk - 1), qnv, __uint_as_float(*dn_max_bits), eps_rel_d, eps_rel_n);
+    m = __popcll(__builtin_amdgcn_ballot_w64(valid && dco <= theta));
+    if (n_valid == KC && n_range > KC) complete = __shfl(dco, KC - 1) > theta;
+  }
+  if (w == 0 && lane < SRR_KC) rows_s[lane] = valid ? (uint32_t)ck : 0u;
+  __syncthreads();  // every wave has its candidates in registers: buf is free and takes the query
+  float* qs = reinterpret_cast<float*>(buf);
+  srr_stage_query(qp, dim, qs);
+  __syncthreads();
+  if (dev_trace && tid == 0) dev_trace[q * 16 + 2] = __builtin_amdgcn_s_memtime();
+  srr_exact_batch(db, qs, dim, rows_s, m, S, exact_s, dev_trace ? dev_trace + q * 16 + 3 : nullptr);
+  if (dev_trace && tid == 0) dev_trace[q * 16 + 4] = __builtin_amdgcn_s_memtime();
+  // F: rank the exact keys (distinct: distinct rows)
+  if (w == 0) {
+    const uint64_t ek = (lane < m) ? make_key(exact_s[lane], (uint32_t)ck) : KEY_SENTINEL;
+    int rank = 0;
+    for (int i = 0; i < m; ++i) {
+      const uint64_t o = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ek >> 32), i) << 32) | (uint32_t)__shfl((int)(uint32_t)ek, i);
+      rank += (o < ek) ? 1 : 0;
+    }
+    if (lane < m && rank < k) {
+      out_keys[(size_t)q * k + rank] = ek;
+      final_store(fo, (size_t)q * k + rank, ek);
+    }
+    for (int i = m + lane; i < k; i += 64) {
+      out_keys[(size_t)q * k + i] = KEY_SENTINEL;
+      final_store(fo, (size_t)q * k + i, KEY_SENTINEL);
+    }
+    if (lane == 0) {
+      flags[q] = complete ? 0 : 1;
+      if (!complete && n_incomplete) atomicAdd(n_incomplete, 1ull);
+      if (dev_trace) {
+        dev_trace[q * 16 + 5] = __builtin_amdgcn_s_memtime();
+        dev_trace[q * 16 + 6] = (unsigned long long)m;
+      }
+    }
+  }
+}
+
+// The device-side fallback in ONE launch: a query whose flag is set is searched exactly by its work-group
+// alone -- reference-order distances of every row of the window (32 at a time: srr_exact_batch), then the
+// selection (selq_select<0>).  Slow by design (one CU streams the whole window: ~1.5 ms at 10 000 x 4096)
+// and rare (0 of 13 440 queries at cfg B); every other work-group leaves at once, so the launch costs its
+// floor.  Rounds 1-2 enqueued two full-size launches (dist_exact, select) for the same purpose.
+__global__ __launch_bounds__(SELQ_THREADS) void fallback_exact_kernel(
+    const int* __restrict__ flags, const float* __restrict__ db, const float* __restrict__ queries, int dim,
+    size_t first_row, int n_range, int k, float* __restrict__ dist /* [nq][ld] scratch */, size_t ld,
+    uint64_t* __restrict__ out_keys /* [nq][k] */, FinalOut fo) {
+  const int q = blockIdx.x;
+  if (!flags[q]) return;  // uniform over the work-group
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  __shared__ __attribute__((aligned(16))) float S[SRR_KC * SRR_LD];
+  __shared__ float exact_s[SRR_KC];
+  __shared__ uint32_t rows_s[SRR_KC];
+  const int tid = threadIdx.x;
+  const float* qp = queries + (size_t)q * dim;
+  float* drow = dist + (size_t)q * ld;
+  float* qs = reinterpret_cast<float*>(buf);  // (the selection below takes buf over once the distances are out)
+  srr_stage_query(qp, dim, qs);
+  for (int base = 0; base < n_range; base += SRR_KC) {
+    const int mb = (n_range - base) < SRR_KC ? (n_range - base) : SRR_KC;
+    if (tid < SRR_KC) rows_s[tid] = (uint32_t)(first_row + (size_t)base + (tid < mb ? tid : 0));
+    __syncthreads();
+    srr_exact_batch(db, qs, dim, rows_s, mb, S, exact_s);
+    if (tid < mb) drow[base + tid] = exact_s[tid];
+  }
+  __threadfence_block();
+  __syncthreads();
+  selq_select<0>(drow, 0, 1, qp, dim, nullptr, first_row, n_range, k, buf, qred, &tau_s, &cnt);
+  if (tid < k) {
+    out_keys[(size_t)q * k + tid] = buf[tid];
+    final_store(fo, (size_t)q * k + tid, buf[tid]);
   }
 }
 

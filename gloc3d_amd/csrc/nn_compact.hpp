@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lane_ops.hpp"
 #include "reg_kernels.hpp"
 
 namespace gloc {
@@ -67,24 +68,7 @@ __device__ __forceinline__ float wave_minmax(float x) {
   return op(op(r0, r1), op(r2, r3));
 }
 
-// Lane exchanges of fp64 values without the LDS crossbar (ds_bpermute kept the LDS pipe busy and was
-// worth 6 % of the launch).  xor_lane<O>(x) = x of lane (l ^ O) for O < 16, through DPP:
-template <int O>
-__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t x) {
-  static_assert(O == 1 || O == 2 || O == 4 || O == 8, "inside a row of 16 lanes");
-  if (O == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  if (O == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-  if (O == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);  // row_ror:8
-  // xor 4: row_ror:12 for the banks whose lanes have bit 2 clear (they read lane + 4), row_ror:4 for the others
-  const int a = __builtin_amdgcn_update_dpp(0, (int)x, 0x12C, 0xF, 0x5, false);
-  return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)x, 0x124, 0xF, 0xA, false);
-}
-template <int O>
-__device__ __forceinline__ double xor_lane(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const unsigned long long r = ((unsigned long long)xor_lane_u32<O>((uint32_t)(u >> 32)) << 32) | xor_lane_u32<O>((uint32_t)u);
-  return __builtin_bit_cast(double, r);
-}
+// (xor_lane<O>: lane_ops.hpp -- DPP below 16 lanes; ds_bpermute kept the LDS pipe busy and was worth 6 % of the launch)
 // The reduce-scatter exchange at distance 32 (16): a lane with that bit clear keeps x and hands y to its
 // partner, a lane with it set keeps y and hands x over.  gfx950's v_permlane32_swap (v_permlane16_swap)
 // moves the handed-over halves in place: afterwards EVERY lane holds (kept, received) in some order in
@@ -173,7 +157,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_cand_chunks = 0, n_processed = 0, n_rounds = 0, n_listed = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0;
+  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0;
   unsigned long long n_items = 0;
 
   float px[CS], py[CS], pz[CS], best[CS];
@@ -287,7 +271,6 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       mask &= mask - 1;
       if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
       const uint32_t c = c0 + b;
-      n_cand_chunks++;
       f32x4 lo, hi;
       lo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.x), b));
       lo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.y), b));
@@ -394,7 +377,6 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       n_items += total;
-      n_listed += k;
       if (trace) {
         uint32_t lm = 0;
         for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;

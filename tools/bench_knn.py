@@ -23,3 +23,15 @@ ix.synchronize(); dt = (time.time() - t) / a.reps
 flop = 2.0 * a.q * a.n * a.d; byt = 4.0 * (a.n * a.d + a.q * a.d)
 print(f"kNN {a.q}x{a.n}x{a.d} k={a.k} algo={a.algo}: {dt*1e6:.1f} us/search (wall, device resident) -> {a.q/dt:.0f} queries/s; "
       f"whole-search {flop/dt/1e12:.1f} TFLOP/s, {byt/dt/1e12:.2f} TB/s; stats {ix.stats()}")
+if os.environ.get("GLOC3D_KNN_TRACE"):  # dev: phase stamps of the fused select + re-rank kernel (s_memtime ticks)
+    import ctypes as C
+    L = capi.lib(); f = L.gloc_knn_debug_trace; f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    f(ix._h, a.q, None, 0)
+    ix.search_device(q.data_ptr(), a.q, a.k, idx.data_ptr(), d2.data_ptr()); ix.synchronize()
+    tr = np.zeros((a.q, 16), np.uint64); f(ix._h, 0, tr.ctypes.data_as(C.c_void_p), a.q * 16)
+    t = tr[:, :6].astype(np.int64); d = np.diff(t, axis=1)
+    s4 = tr[:, 8:12].astype(np.int64) - t[:, :1]
+    print("inside select (ticks from kernel start, mean): keys ready %d, minima sorted %d, tournament done %d, collected %d, end %d" % (*s4.mean(0), d[:, 0].mean()))
+    print("phase ticks (mean over queries): select %d, prefix+stage %d, R1 group sums %d, R2 chains %d, rank %d | m mean %.1f | first start -> last end %d"
+          % (*d.mean(0), tr[:, 6].mean(), t[:, 5].max() - t[:, 0].min()))

@@ -117,14 +117,17 @@ constexpr int SELECT_ONE_BLOCK_MAX = 16384;  // rows one work-group per query se
 
 template <int MODE>
 int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
-               int n_splits, uint64_t* d_keys_out, const int* only_flagged = nullptr) {
+               int n_splits, uint64_t* d_keys_out, const int* only_flagged = nullptr,
+               const FinalOut& fo = FinalOut{nullptr, nullptr, 0, 1}, bool* finalized = nullptr) {
+  if (finalized) *finalized = false;
   ProfScope ps(h->prof, "select", h->stream);
   static const bool no_selq = getenv("GLOC3D_KNN_NO_SELECT_QUERY") != nullptr;  // developer switch: the chunked form
   if (n_range <= SELQ_MAX_ROWS && K <= 64 && !no_selq) {  // one launch, one work-group per query
     hipLaunchKernelGGL(select_query_kernel<MODE>, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
                        strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, h->norms.as<float>(), first, n_range,
-                       K, d_keys_out, only_flagged);
+                       K, d_keys_out, only_flagged, fo);
     GLOC_HIP(hipGetLastError());
+    if (finalized) *finalized = fo.idx != nullptr;
     return GLOC_OK;
   }
   const int per_group = SEL_LIST / K;  // lists one merge can take
@@ -165,11 +168,11 @@ int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n
 }
 
 int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
-              uint64_t* d_keys_out) {
+              uint64_t* d_keys_out, const FinalOut& fo = FinalOut{nullptr, nullptr, 0, 1}, bool* finalized = nullptr) {
   const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
   GLOC_TRY(h->dist.ensure((size_t)nq * ld * sizeof(float), h->stream));
   GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld));
-  return run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out);
+  return run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out, nullptr, fo, finalized);
 }
 
 // ---- MFMA path -------------------------------------------------------------------------------
@@ -376,9 +379,10 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
         all_final = all_final && fin;
       } else {
         h->stats.searches_exact++;
-        all_final = false;
-        GLOC_TRY(run_exact(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range,
-                           keys_out + q0 * k));
+        bool fin = false;
+        const FinalOut fo{d_idx + q0 * k, d_d2 + q0 * k, index_offset, index_stride};
+        GLOC_TRY(run_exact(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range, keys_out + q0 * k, fo, &fin));
+        all_final = all_final && fin;
       }
     }
   }

@@ -580,6 +580,23 @@ __device__ __forceinline__ uint64_t wave_sort_u64(uint64_t x, int lane) {
   return bitonic_merge<64>(x, lane);
 }
 
+// Where a kernel that ends a search leaves its result directly (what finalize_kernel would make of its keys).
+struct FinalOut {
+  uint64_t* idx;   // [nq][k], null: keys only
+  float* d2;
+  uint64_t offset, stride;
+};
+__device__ __forceinline__ void final_store(const FinalOut& fo, size_t i, uint64_t key) {
+  if (!fo.idx) return;
+  if (key == KEY_SENTINEL) {
+    fo.idx[i] = ~0ull;
+    fo.d2[i] = 3.402823466e+38f;
+  } else {
+    fo.idx[i] = (uint64_t)(uint32_t)key * fo.stride + fo.offset;
+    fo.d2[i] = ord2f((uint32_t)(key >> 32));
+  }
+}
+
 // The selection proper, for the calling work-group's query: leaves the K smallest keys, sorted, in
 // buf[0..K) (padded with the sentinel) and returns after a barrier.  MODE 1 also returns the query's norm.
 template <int MODE>
@@ -698,7 +715,7 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_query_kernel(
     const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits,
     float* __restrict__ qn, const float* __restrict__ queries, int dim, const float* __restrict__ dn,
     size_t first_row, int n_range, int K, uint64_t* __restrict__ out_keys /* [nq][K] */,
-    const int* __restrict__ only_flagged) {
+    const int* __restrict__ only_flagged, FinalOut fo) {
   __shared__ uint64_t buf[SEL_LIST];     // tournament lists (16 x 64), then the candidate list
   __shared__ float qred[SELQ_THREADS / 64];
   __shared__ uint64_t tau_s;
@@ -709,7 +726,10 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_query_kernel(
   const float qnv = selq_select<MODE>(dist + (size_t)q * ld, strideP, n_splits, queries + (size_t)q * dim, dim, dn,
                                       first_row, n_range, K, buf, qred, &tau_s, &cnt);
   if (MODE == 1 && tid == 0) qn[q] = qnv;
-  if (tid < K) out_keys[(size_t)q * K + tid] = buf[tid];
+  if (tid < K) {
+    out_keys[(size_t)q * K + tid] = buf[tid];
+    final_store(fo, (size_t)q * K + tid, buf[tid]);
+  }
 }
 
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
@@ -876,90 +896,78 @@ constexpr int SRR_G = 1024;          // groups of 4 dims held per candidate
 static_assert(SEL_LIST * 8 >= 4 * SRR_G * 4, "the selection's key list doubles as the staged query");
 constexpr int SRR_LD = SRR_G + 4;    // floats per candidate row: 16 bytes of shift spread the chains' reads over the banks
 
-// Where a kernel that ends a search leaves its result directly (what finalize_kernel would make of its keys).
-struct FinalOut {
-  uint64_t* idx;   // [nq][k], null: keys only
-  float* d2;
-  uint64_t offset, stride;
-};
-__device__ __forceinline__ void final_store(const FinalOut& fo, size_t i, uint64_t key) {
-  if (!fo.idx) return;
-  if (key == KEY_SENTINEL) {
-    fo.idx[i] = ~0ull;
-    fo.d2[i] = 3.402823466e+38f;
-  } else {
-    fo.idx[i] = (uint64_t)(uint32_t)key * fo.stride + fo.offset;
-    fo.d2[i] = ord2f((uint32_t)(key >> 32));
-  }
-}
-
 // Reference-order distances of the query (staged in LDS: qs, dim floats) to the m <= 32 rows listed in
 // rows_s (LDS), by the whole work-group of 1024 threads; exact_s[c] = distance to rows_s[c].  Ends with a
-// barrier.  The rows are random 16-KB reads from HBM: a wave keeps the NEXT four groups of its two rows in
-// flight while it works on the current four (the first form waited for four round trips in turn: 8 us).
+// barrier.  A chain is 1024 DEPENDENT fp32 adds (12 cycles each: 6 us) whatever else the chip does, so the
+// work-group is split: waves 0-3 (8 lanes each, one candidate per lane) run the chains over chunk c of 256
+// groups while waves 4-15 form the group sums of chunk c + 1 (three rows per wave: random 16-KB reads from
+// HBM); a barrier per chunk hands the chunks over.  (Unpipelined: 6.0 + 5.9 us; the sums now hide behind the chains.)
 __device__ __forceinline__ void srr_exact_batch(const float* __restrict__ db, const float* qs, int dim,
                                                 const uint32_t* rows_s, int m, float* S, float* exact_s,
-                                                unsigned long long* stamp = nullptr /* dev: [1] = after R1 */) {
+                                                unsigned long long* stamp = nullptr /* dev: [1] = after the first chunk's sums */) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int G = dim >> 2;
-  if (w < m) {  // R1: group sums
-    const int c0 = w, c1 = (w + 16 < m) ? w + 16 : w;  // (c1 == c0: the second row is loaded twice, stored once)
-    const float* r0 = db + (size_t)rows_s[c0] * dim;
-    const float* r1 = db + (size_t)rows_s[c1] * dim;
-    f4u a0[4], a1[4], b0[4], b1[4];
-    auto load = [&](f4u(&x0)[4], f4u(&x1)[4], int gb) {
+  const int n_chunks = (G + 255) / 256;
+  const bool summing = w >= 4;
+  // summing waves: candidates w - 4, w + 8, w + 20
+  int cs[3];
+  const float* rp[3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {  // clamped: unconditional
-        const int g = gb + u * 64 + lane, gc = g < G ? g : G - 1;
-        x0[u] = *reinterpret_cast<const f4u*>(r0 + 4 * (size_t)gc);
-        x1[u] = *reinterpret_cast<const f4u*>(r1 + 4 * (size_t)gc);
-      }
-    };
-    auto work = [&](const f4u(&x0)[4], const f4u(&x1)[4], int gb) {
+  for (int r = 0; r < 3; ++r) {
+    cs[r] = (w - 4) + 12 * r;
+    rp[r] = db + (size_t)rows_s[(summing && cs[r] < m) ? cs[r] : 0] * dim;
+  }
+  auto sums = [&](int ch) {
+    if (cs[0] >= m) return;  // wave-uniform
+    const int gb = ch * 256;
+    f4u x[3][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int g = gb + u * 64 + lane;
-        if (g < G) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + 4 * g);
-          {
-            const float e0 = qv.x - x0[u].x, e1 = qv.y - x0[u].y, e2 = qv.z - x0[u].z, e3 = qv.w - x0[u].w;
-            S[c0 * SRR_LD + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA (as exact_pairs_wave)
-          }
-          if (c1 != c0) {
-            const float e0 = qv.x - x1[u].x, e1 = qv.y - x1[u].y, e2 = qv.z - x1[u].z, e3 = qv.w - x1[u].w;
-            S[c1 * SRR_LD + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    for (int u = 0; u < 4; ++u) {  // all twelve loads before the first use (clamped: unconditional)
+      const int g = gb + u * 64 + lane, gc = g < G ? g : G - 1;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) x[r][u] = *reinterpret_cast<const f4u*>(rp[r] + 4 * (size_t)gc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = gb + u * 64 + lane;
+      if (g < G) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (cs[r] < m) {
+            const float e0 = qv.x - x[r][u].x, e1 = qv.y - x[r][u].y, e2 = qv.z - x[r][u].z, e3 = qv.w - x[r][u].w;
+            S[cs[r] * SRR_LD + g] = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;  // left-to-right, no FMA (as exact_pairs_wave)
           }
         }
       }
-    };
-    load(a0, a1, 0);
-    for (int gb = 0; gb < G; gb += 512) {
-      if (gb + 256 < G) load(b0, b1, gb + 256);
-      work(a0, a1, gb);
-      if (gb + 512 < G) load(a0, a1, gb + 512);
-      if (gb + 256 < G) work(b0, b1, gb + 256);
     }
-  }
+  };
+  const int cc = w * 8 + lane;  // chain lanes: waves 0-3, lanes 0-7
+  const bool chaining = !summing && lane < 8 && cc < m;
+  float acc = 0.f;
+  if (summing) sums(0);
   __syncthreads();
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
-  if (w < 4 && lane < 8) {  // R2: the chains
-    const int c = w * 8 + lane;
-    if (c < m) {
-      const float* sp = S + c * SRR_LD;
-      float acc = 0.f;
-      int i = 0;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    if (summing) {
+      if (ch + 1 < n_chunks) sums(ch + 1);
+    } else if (chaining) {
+      const float* sp = S + cc * SRR_LD;
+      const int end = (ch * 256 + 256) < G ? (ch * 256 + 256) : G;
+      int i = ch * 256;
 #pragma unroll 8
-      for (; i + 4 <= G; i += 4) {
+      for (; i + 4 <= end; i += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(sp + i);
         acc += v.x;
         acc += v.y;
         acc += v.z;
         acc += v.w;
       }
-      for (; i < G; ++i) acc += sp[i];
-      exact_s[c] = acc;
+      for (; i < end; ++i) acc += sp[i];
     }
+    __syncthreads();
   }
+  if (chaining) exact_s[cc] = acc;
   __syncthreads();
 }
 // the query into LDS (dim <= 4 * SRR_G floats), one group of 4 dims per thread; the caller adds the barrier

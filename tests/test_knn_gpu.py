@@ -302,3 +302,41 @@ def test_save_load_round_trip(capi, oracle_mod, tmp_path):
     assert len(b) == 1800
     b.close()
     c.close()
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("N,D,Q,k", [(16384, 64, 12, 20), (16385, 64, 12, 20), (12000, 100, 20, 52), (40, 4096, 10, 20)])
+def test_one_work_group_per_query_select_limits(capi, oracle_mod, algo, N, D, Q, k):
+    """The one-launch selection (<= 16384 rows, <= 64 keys) at its limits, one row past them (chunked form),
+    dim % 256 != 0 (tail groups of the re-rank), k = 52 (64 candidates: selection only), fewer rows than candidates."""
+    from gloc3d_amd import synth
+    db = synth.descriptors_iid(300 + N, 0, N, D)
+    q = synth.descriptors_iid(400 + N, 0, Q, D)
+    ix = _index(capi, db, algo)
+    idx, d2 = ix.search(q, k)
+    oi, od = oracle_mod.knn_search(db, q, k, threads=4)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_select_with_near_rows_on_few_threads(capi, oracle_mod, algo):
+    """Rows j with j % 1024 < 4 lie near the query: four of the selecting work-group's 1024 threads hold all the
+    small keys, so more than 64 keys pass the threshold of thread minima (the list is sorted through LDS then);
+    with a row window that does not start at 0, and duplicated rows among the near ones (ties by row index)."""
+    from gloc3d_amd import synth
+    N, D, Q = 9000, 128, 11
+    db = synth.descriptors_iid(51, 0, N, D)
+    q = synth.descriptors_iid(52, 0, Q, D)
+    first = 37
+    near = np.array([j for j in range(first, N) if (j - first) % 1024 < 4])
+    noise = synth.descriptors_iid(53, 0, len(near), D)
+    db[near] = (q[0][None, :] + np.float32(0.02) * noise).astype(np.float32)
+    db[near[5]] = db[near[1]]
+    db[near[9]] = db[near[1]]
+    ix = _index(capi, db, algo)
+    for k in (20, 33):
+        idx, d2 = ix.search(q, k, first, N)
+        oi, od = oracle_mod.knn_search(db, q, k, first, N)
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    ix.close()

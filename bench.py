@@ -512,14 +512,17 @@ def main():
         if pj.get("jobs_per_launch") and abs(pj["jobs_per_launch"] - jobs_per_launch) > 1e-6:
             traffic = traffic * jobs_per_launch / pj["jobs_per_launch"]      # PMC passes ran at another batch size
         # instruction-issue model: the committed per-wave instruction counts (PMC) x the waves of a launch over the
-        # live launch time, against the vector pipes' issue rate (157.3 TFLOP/s counts an FMA as two: 78.65 T lane-ops/s)
+        # live launch time, against the vector pipes' issue rate (39.3 T lane-instructions/s)
         pw = pj.get("per_wave", {})
         if pw.get("valu") and avg_launch_s > 0:
             waves = jobs_per_launch * np.ceil(pts_q / 128.0)
             lane_ops = pw["valu"] * 64.0 * waves / avg_launch_s
             issue_model = {"valu_per_wave": pw["valu"], "salu_per_wave": pw.get("salu"), "lds_per_wave": pw.get("lds"),
                            "vmem_per_wave": pw.get("vmem_rd"), "waves_per_launch": waves,
-                           "vector_lane_ops_per_s": lane_ops, "frac_of_vector_issue_peak": lane_ops / (PEAK_FP32_TFLOPS * 1e12 / 2),
+                           "vector_lane_ops_per_s": lane_ops,
+                           # 157.3 TFLOP/s counts an FMA as two flops and a packed instruction as two lanes' worth: one
+                           # instruction per lane and cycle is a quarter of it (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
+                           "frac_of_vector_issue_peak": lane_ops / (PEAK_FP32_TFLOPS * 1e12 / 4),
                            "valu_busy_frac_under_pmc": pj.get("valu_busy_frac"),
                            "source": "profiles/r02_pmc_traffic_nn_compact.json (SQ_INSTS_* / SQ_WAVES; busy = SQ_ACTIVE_INST_VALU "
                                      "over SQ_BUSY_CYCLES): the vector pipes are busy for that fraction of the launch, a wave64 "

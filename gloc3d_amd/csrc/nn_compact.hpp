@@ -40,9 +40,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int NN_WPB = GLOC_NN_WPB;
 constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evaluated statistic
-#ifndef GLOC_NN_TU
-#define GLOC_NN_TU 1  // sub-block test steps unrolled together (4 measured 6 % slower: most chunks list < 16 sources)
-#endif
 #ifndef GLOC_NN_WAVES_PER_EU
 #define GLOC_NN_WAVES_PER_EU 4
 #endif
@@ -332,9 +329,9 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       const f32x2 hix = {bB.z, bB.w}, hiy = {bC.x, bC.y}, hiz = {bC.z, bC.w};
       const uint32_t sb0 = (lane & 3) * 2;
       uint32_t total = 0, sbmask = 0;
-      // four steps of 16 sources at a time: their LDS reads and box tests are independent, so a wave
-      // (latency-bound when few share the SIMD) overlaps them; only the queue positions are serial
-      constexpr int TU = GLOC_NN_TU;
+      // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
+      // 6 % slower -- a processed chunk lists 58 sources on average, many far fewer
+      constexpr int TU = 1;
       for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
         uint32_t si[TU];
         bool act[TU];

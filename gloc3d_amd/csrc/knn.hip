@@ -195,7 +195,11 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
     // split K only when the tiles alone cannot give every CU a work-group (the partial sums cost
     // KS x Q x N x 8 B of extra traffic and a longer rounding chain)
     int KS = 1;
-    while (tiles * KS < 200 && KS < 16 && (dim % (64 * KS * 2)) == 0 && dim / (KS * 2) >= 128) KS *= 2;
+    // (one block of queries over >= 64 row tiles: two work-groups per CU overlap each other's LDS hand-offs;
+    // measured at 64 x 10 000 and 25 x 4541 x 4096: -4 / -3 us; 128 x 16 000 and 32 x 2000: +4 us, so not there)
+    static const long long wgs_env = getenv("GLOC3D_MFMA_WGS") ? atoll(getenv("GLOC3D_MFMA_WGS")) : 0;  // developer override
+    const long long want_wgs = wgs_env ? wgs_env : ((qblocks == 1 && tiles >= 64) ? 400 : 200);
+    while (tiles * KS < want_wgs && KS < 16 && (dim % (64 * KS * 2)) == 0 && dim / (KS * 2) >= 128) KS *= 2;
     const int klen = (dim + KS - 1) / KS;
     const long long wgs = tiles * KS;
     const long long rounds = (wgs + 255) / 256;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
       if (j < ix.n) {
         const f32x4 t = ix.pts[j];
         best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
-        b0 = j / SB;
+        b0 = j / (SB / 2);  // the key's low word: (sub-block << 1) | half of the sub-block
       } else {
         const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
         uint32_t lo = 0, hi = ix.n;  // lower_bound over the sorted keys
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
           const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
           if (dd < best[s]) {
             best[s] = dd;
-            b0 = (uint32_t)jj / SB;
+            b0 = (uint32_t)jj / (SB / 2);
           }
         }
       }
@@ -390,7 +390,9 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
         const f32x4 p = L.src[slot];
         const float* sb = &L.stage[bi * SB_STRIDE];
         const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
-        float m = 3.402823466e+38f;
+        // the minimum of each HALF of the sub-block: the key records which half holds the minimum, so the index
+        // recovery re-reads 8 targets instead of 16 (equal halves -- two targets at the minimum -- take the tie path)
+        float mh[2] = {3.402823466e+38f, 3.402823466e+38f};
 #pragma unroll
         for (int i = 0; i < SB / 2; ++i) {
           const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
@@ -398,13 +400,16 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
           // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
           const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
           const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-          m = fminf(fminf(m, d2.x), d2.y);
+          mh[i / (SB / 4)] = fminf(fminf(mh[i / (SB / 4)], d2.x), d2.y);
         }
+        const float m = fminf(mh[0], mh[1]);
         if (act) {
           const uint32_t blk = c * NSB + bi;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | blk;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 2u + (mh[1] < mh[0] ? 1u : 0u));
           const unsigned long long old = atomicMin(&L.key[slot], key);
-          if ((uint32_t)(old >> 32) == __float_as_uint(m) && (uint32_t)old != blk) L.tie[slot] = 1;
+          // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this one
+          const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
+          if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -435,32 +440,28 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLO
     bpos[s] = 0xFFFFFFFFu;
     if (!valid[s] || !ix.n) continue;
     const int slot = s * 64 + lane;
-    const uint32_t bch = (uint32_t)L.key[slot];
+    const uint32_t bch = (uint32_t)L.key[slot];  // (sub-block << 1) | half: 8 targets
     const bool tie = L.tie[slot] != 0;
     uint32_t bj = 0xFFFFFFFFu;
     if (!tie) {
       // (the store pads the scan to whole chunks, so the loads are unconditional)
-      // eight loads in flight at a time (sixteen would cost the 5th wave per SIMD its registers)
-      GPTR(f32x4) tp = ix.pts + (size_t)bch * SB;
+      GPTR(f32x4) tp = ix.pts + (size_t)bch * (SB / 2);
       const f32x2 pxy = {px[s], py[s]};
+      f32x4 t[SB / 2];
 #pragma unroll
-      for (int u0 = 0; u0 < SB; u0 += 8) {
-        f32x4 t[8];
+      for (int u = 0; u < SB / 2; ++u) t[u] = tp[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = tp[u0 + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          // dist2(): x and y share one packed instruction (a loaded point's x, y are a register pair);
-          // same roundings as the scalar form
-          const f32x2 dxy = pxy - f32x2{t[u].x, t[u].y};
-          const f32x2 sxy = dxy * dxy;
-          const float dz = pz[s] - t[u].z;
-          const float d2 = (sxy.x + sxy.y) + dz * dz;
-          const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
-          if (d2 == best[s] && o < bj) {
-            bj = o;
-            bpos[s] = bch * SB + u0 + u;
-          }
+      for (int u = 0; u < SB / 2; ++u) {
+        // dist2(): x and y share one packed instruction (a loaded point's x, y are a register pair);
+        // same roundings as the scalar form
+        const f32x2 dxy = pxy - f32x2{t[u].x, t[u].y};
+        const f32x2 sxy = dxy * dxy;
+        const float dz = pz[s] - t[u].z;
+        const float d2 = (sxy.x + sxy.y) + dz * dz;
+        const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
+        if (d2 == best[s] && o < bj) {
+          bj = o;
+          bpos[s] = bch * (SB / 2) + u;
         }
       }
     } else {  // rare: every chunk that can hold a point at the minimum distance

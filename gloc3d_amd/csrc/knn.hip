@@ -282,15 +282,11 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
                        strideP, p.KS, d_q, (int)h->dim, h->norms.as<float>(), first, n_range, KC, k,
                        h->rows.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n, h->qnorm.as<float>(),
-                       d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo,
+                       d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo, h->dist.as<float>(),
                        h->dev_trace.as<unsigned long long>());
     GLOC_HIP(hipGetLastError());
-    // incomplete queries (rare) are redone exactly ON THE DEVICE by one more launch whose work-groups leave
-    // at once unless their query's flag is set: no read-back, no host synchronisation.  (The coarse partial
-    // dots in h->dist are dead by now: the exact distances of a flagged query reuse the buffer, row q at q * ld.)
-    hipLaunchKernelGGL(fallback_exact_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->flags.as<int>(),
-                       h->rows.as<float>(), d_q, (int)h->dim, first, n_range, k, h->dist.as<float>(), ld, d_keys_out, fo);
-    GLOC_HIP(hipGetLastError());
+    // (incomplete queries -- rare -- are redone exactly by their own work-group inside the same launch: no
+    // read-back, no host synchronisation, no further launch)
     h->stats.last_n_tile = (uint32_t)p.BN;
     h->stats.last_k_split = (uint32_t)p.KS;
     h->stats.last_candidates = (uint32_t)KC;

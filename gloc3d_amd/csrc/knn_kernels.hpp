@@ -976,12 +976,43 @@ __device__ __forceinline__ void srr_stage_query(const float* __restrict__ qp, in
   if (g < (dim >> 2)) *reinterpret_cast<f32x4*>(qs + 4 * g) = *reinterpret_cast<const f32x4*>(qp + 4 * (size_t)g);
 }
 
+// The device-side fallback: a query whose candidate set cannot be proven complete is searched exactly by its
+// own work-group, in the same launch -- reference-order distances of every row of the window (32 at a time:
+// srr_exact_batch) into the query's own (dead) row of the coarse workspace, then the selection
+// (selq_select<0>).  Slow by design (one CU streams the whole window: ~1.5 ms at 10 000 x 4096) and rare
+// (0 of 13 440 queries at cfg B).  Rounds 1-2 enqueued two full-size launches (dist_exact, select) for the
+// same purpose, the first form of this round one; now none.
+__device__ __forceinline__ void srr_fallback_exact(const float* __restrict__ db, const float* __restrict__ qp, int dim,
+                                                   size_t first_row, int n_range, int k, float* __restrict__ drow,
+                                                   uint64_t* buf, float* qred, uint64_t* tau_s, int* cnt, float* S,
+                                                   float* exact_s, uint32_t* rows_s, uint64_t* __restrict__ out_keys_q,
+                                                   const FinalOut& fo, size_t out_base) {
+  const int tid = threadIdx.x;
+  float* qs = reinterpret_cast<float*>(buf);  // (the selection below takes buf over once the distances are out)
+  __syncthreads();
+  srr_stage_query(qp, dim, qs);
+  for (int base = 0; base < n_range; base += SRR_KC) {
+    const int mb = (n_range - base) < SRR_KC ? (n_range - base) : SRR_KC;
+    if (tid < SRR_KC) rows_s[tid] = (uint32_t)(first_row + (size_t)base + (tid < mb ? tid : 0));
+    __syncthreads();
+    srr_exact_batch(db, qs, dim, rows_s, mb, S, exact_s);
+    if (tid < mb) drow[base + tid] = exact_s[tid];
+  }
+  __threadfence_block();
+  __syncthreads();
+  selq_select<0>(drow, 0, 1, qp, dim, nullptr, first_row, n_range, k, buf, qred, tau_s, cnt);
+  if (tid < k) {
+    out_keys_q[tid] = buf[tid];
+    final_store(fo, out_base + tid, buf[tid]);
+  }
+}
+
 __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     const float* __restrict__ P, size_t ld, size_t strideP, int n_splits, const float* __restrict__ queries,
     int dim, const float* __restrict__ dn, size_t first_row, int n_range, int KC, int k,
     const float* __restrict__ db, const uint32_t* __restrict__ dn_max_bits, float eps_rel_d, float eps_rel_n,
     float* __restrict__ qn_out, uint64_t* __restrict__ out_keys /* [nq][k] */, int* __restrict__ flags,
-    unsigned long long* __restrict__ n_incomplete, FinalOut fo,
+    unsigned long long* __restrict__ n_incomplete, FinalOut fo, float* __restrict__ dist_scratch /* = P: row q of split 0 is this query's */,
     unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */) {
   const unsigned long long t_start = dev_trace ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ uint64_t buf[SEL_LIST];
@@ -1047,45 +1078,9 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
       }
     }
   }
-}
-
-// The device-side fallback in ONE launch: a query whose flag is set is searched exactly by its work-group
-// alone -- reference-order distances of every row of the window (32 at a time: srr_exact_batch), then the
-// selection (selq_select<0>).  Slow by design (one CU streams the whole window: ~1.5 ms at 10 000 x 4096)
-// and rare (0 of 13 440 queries at cfg B); every other work-group leaves at once, so the launch costs its
-// floor.  Rounds 1-2 enqueued two full-size launches (dist_exact, select) for the same purpose.
-__global__ __launch_bounds__(SELQ_THREADS) void fallback_exact_kernel(
-    const int* __restrict__ flags, const float* __restrict__ db, const float* __restrict__ queries, int dim,
-    size_t first_row, int n_range, int k, float* __restrict__ dist /* [nq][ld] scratch */, size_t ld,
-    uint64_t* __restrict__ out_keys /* [nq][k] */, FinalOut fo) {
-  const int q = blockIdx.x;
-  if (!flags[q]) return;  // uniform over the work-group
-  __shared__ uint64_t buf[SEL_LIST];
-  __shared__ float qred[SELQ_THREADS / 64];
-  __shared__ uint64_t tau_s;
-  __shared__ int cnt;
-  __shared__ __attribute__((aligned(16))) float S[SRR_KC * SRR_LD];
-  __shared__ float exact_s[SRR_KC];
-  __shared__ uint32_t rows_s[SRR_KC];
-  const int tid = threadIdx.x;
-  const float* qp = queries + (size_t)q * dim;
-  float* drow = dist + (size_t)q * ld;
-  float* qs = reinterpret_cast<float*>(buf);  // (the selection below takes buf over once the distances are out)
-  srr_stage_query(qp, dim, qs);
-  for (int base = 0; base < n_range; base += SRR_KC) {
-    const int mb = (n_range - base) < SRR_KC ? (n_range - base) : SRR_KC;
-    if (tid < SRR_KC) rows_s[tid] = (uint32_t)(first_row + (size_t)base + (tid < mb ? tid : 0));
-    __syncthreads();
-    srr_exact_batch(db, qs, dim, rows_s, mb, S, exact_s);
-    if (tid < mb) drow[base + tid] = exact_s[tid];
-  }
-  __threadfence_block();
-  __syncthreads();
-  selq_select<0>(drow, 0, 1, qp, dim, nullptr, first_row, n_range, k, buf, qred, &tau_s, &cnt);
-  if (tid < k) {
-    out_keys[(size_t)q * k + tid] = buf[tid];
-    final_store(fo, (size_t)q * k + tid, buf[tid]);
-  }
+  if (!complete)  // uniform over the work-group (every wave computed the same proof)
+    srr_fallback_exact(db, qp, dim, first_row, n_range, k, dist_scratch + (size_t)q * ld, buf, qred, &tau_s, &cnt, S, exact_s,
+                       rows_s, out_keys + (size_t)q * k, fo, (size_t)q * k);
 }
 
 // keys -> (u64 index * stride + offset, f32 d2); sentinel -> (UINT64_MAX, FLT_MAX).  stride / offset place a

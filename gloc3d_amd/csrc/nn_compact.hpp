@@ -40,9 +40,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int NN_WPB = GLOC_NN_WPB;
 constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evaluated statistic
-#ifndef GLOC_NN_WAVES_PER_EU
-#define GLOC_NN_WAVES_PER_EU 4
-#endif
 
 // Wave-wide min / max without the LDS crossbar: four DPP steps inside every row of 16 lanes (quad
 // swaps, then the half-row and row mirrors: after each step the lanes already paired hold one value,
@@ -96,7 +93,7 @@ __device__ __forceinline__ double exchange_add(double x, double y) {
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
 template <int CS, bool PAIRS>
-__global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(GLOC_NN_WAVES_PER_EU))) void nn_compact_kernel(
+__global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,

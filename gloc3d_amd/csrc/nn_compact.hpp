@@ -108,13 +108,20 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // the extra 32 B shift sub-block b's pair i into bank group (i + b) % 8, so lanes that walk
   // different sub-blocks in lock step never collide.
   constexpr int SB_STRIDE = (SB / 2) * 8 + 8;  // floats per sub-block: SB/2 pairs x 8 floats + 8 of shift
+  // queue entries: a chunk queues 55 items on average; a test step adds at most 128, and the queue is evaluated
+  // early when the next step might not fit (a wave's LDS: 6.8 KB; with the 1024-entry queue of the worst case,
+  // 7.8 KB, the same kernel measured 3 % slower; six waves per SIMD -- 80 VGPRs -- spill and gain nothing)
+#ifndef GLOC_NN_QCAP
+#define GLOC_NN_QCAP 512
+#endif
+  constexpr int QCAP = GLOC_NN_QCAP;  // (tests build a 128-entry variant to drive the early evaluation on every step)
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
     f32x4 src[S];                   // moved source points
     unsigned long long key[S];      // (bits(best d2) << 32) | sub-block holding it
     uint8_t tie[S];                 // (sizes are chosen so that CS = 2 stays under 8 KB per wave: 5 work-groups per CU)
     uint16_t list[S];               // source slots that passed the chunk-level test
-    uint16_t queue[S * NSB];        // work items: (source slot << 3) | sub-block within the chunk
+    uint16_t queue[QCAP];           // work items: (source slot << 3) | sub-block within the chunk
 #ifdef GLOC_NN_LDS_PAD
     uint8_t pad_[GLOC_NN_LDS_PAD];  // dev: occupancy experiments
 #endif
@@ -324,12 +331,51 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       // instruction), against the source's CURRENT bound; the passing pairs become the work items
       const f32x2 lox = {bA.x, bA.y}, loy = {bA.z, bA.w}, loz = {bB.x, bB.y};
       const f32x2 hix = {bB.z, bB.w}, hiy = {bC.x, bC.y}, hiz = {bC.z, bC.w};
-      const uint32_t sb0 = (lane & 3) * 2;
       uint32_t total = 0, sbmask = 0;
+      auto run_rounds = [&]() {  // evaluate the queued work items
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        n_items += total;
+        for (uint32_t r = 0; r < total; r += 64) {
+          n_rounds++;
+          const uint32_t it = r + lane;
+          const bool act = it < total;
+          const uint32_t item = L.queue[act ? it : r];
+          const uint32_t slot = item >> 3, bi = item & 7;
+          const f32x4 p = L.src[slot];
+          const float* sb = &L.stage[bi * SB_STRIDE];
+          const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
+          // the minimum of each HALF of the sub-block: the key records which half holds the minimum, so the index
+          // recovery re-reads 8 targets instead of 16 (equal halves -- two targets at the minimum -- take the tie path)
+          float mh[2] = {3.402823466e+38f, 3.402823466e+38f};
+  #pragma unroll
+          for (int i = 0; i < SB / 2; ++i) {
+            const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
+            const f32x2 zz = *reinterpret_cast<const f32x2*>(sb + i * 8 + 4);
+            // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
+            const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
+            const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+            mh[i / (SB / 4)] = fminf(fminf(mh[i / (SB / 4)], d2.x), d2.y);
+          }
+          const float m = fminf(mh[0], mh[1]);
+          if (act) {
+            const uint32_t blk = c * NSB + bi;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 2u + (mh[1] < mh[0] ? 1u : 0u));
+            const unsigned long long old = atomicMin(&L.key[slot], key);
+            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this one
+            const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
+            if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
+          }
+        }
+        total = 0;
+      };
+      const uint32_t sb0 = (lane & 3) * 2;
       // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
       // 6 % slower -- a processed chunk lists 58 sources on average, many far fewer
       constexpr int TU = 1;
       for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
+        if (total + 128 * TU > (uint32_t)QCAP) run_rounds();  // rare: this step's items might not fit
         uint32_t si[TU];
         bool act[TU];
 #pragma unroll
@@ -367,10 +413,6 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           if (trace) sbmask |= (nd0 ? (1u << sb0) : 0u) | (nd1 ? (2u << sb0) : 0u);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      n_items += total;
       if (trace) {
         uint32_t lm = 0;
         for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;
@@ -378,37 +420,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         n_live_pairs += (uint32_t)__popc((lm | (lm >> 1)) & 0x55u);
         n_steps += (k + 15) / 16;
       }
-      for (uint32_t r = 0; r < total; r += 64) {
-        n_rounds++;
-        const uint32_t it = r + lane;
-        const bool act = it < total;
-        const uint32_t item = L.queue[act ? it : r];
-        const uint32_t slot = item >> 3, bi = item & 7;
-        const f32x4 p = L.src[slot];
-        const float* sb = &L.stage[bi * SB_STRIDE];
-        const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
-        // the minimum of each HALF of the sub-block: the key records which half holds the minimum, so the index
-        // recovery re-reads 8 targets instead of 16 (equal halves -- two targets at the minimum -- take the tie path)
-        float mh[2] = {3.402823466e+38f, 3.402823466e+38f};
-#pragma unroll
-        for (int i = 0; i < SB / 2; ++i) {
-          const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
-          const f32x2 zz = *reinterpret_cast<const f32x2*>(sb + i * 8 + 4);
-          // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
-          const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
-          const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-          mh[i / (SB / 4)] = fminf(fminf(mh[i / (SB / 4)], d2.x), d2.y);
-        }
-        const float m = fminf(mh[0], mh[1]);
-        if (act) {
-          const uint32_t blk = c * NSB + bi;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 2u + (mh[1] < mh[0] ? 1u : 0u));
-          const unsigned long long old = atomicMin(&L.key[slot], key);
-          // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this one
-          const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
-          if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
-        }
-      }
+      run_rounds();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

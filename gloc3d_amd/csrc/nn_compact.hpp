@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           v[1 + a] += P[a];
           v[4 + a] += Q[a];
 #pragma unroll
-          for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += P[a] * Q[b];
+          for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = __builtin_fma(P[a], Q[b], v[7 + 3 * a + b]);  // (fp64 sums: fused is fine)
         }
       }
     }

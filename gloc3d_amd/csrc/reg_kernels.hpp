@@ -313,7 +313,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                                                            float thr2,
                                                            const CandState* __restrict__ states,
                                                            uint32_t* __restrict__ inliers) {
-  __shared__ f32x4 sp[2 * SC_STAGE];
+  // staged pairs, two correspondences per entry, structure-of-arrays: (px0 px1 py0 py1)(pz0 pz1 qx0 qx1)(qy0 qy1 qz0 qz1)
+  // so that one packed fp32 instruction moves / measures two correspondences (v_pk_mul / v_pk_add round each
+  // half like the scalar forms: same bits as xform() + dist2())
+  __shared__ f32x4 sp[3 * (SC_STAGE / 2)];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int cand = blockIdx.z;
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
   const uint32_t n = jobs[cand].n_src;
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   const uint32_t i0 = blockIdx.y * SC_CHUNK;
   const uint32_t i1 = (i0 + SC_CHUNK) < n ? (i0 + SC_CHUNK) : n;
   uint32_t cnt = 0;
+  float* spf = reinterpret_cast<float*>(sp);
   for (uint32_t b = i0; b < i1; b += SC_STAGE) {
     const uint32_t i = b + threadIdx.x;
     f32x4 pv = {0.f, 0.f, 0.f, 0.f}, qv = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // padding: never inlier
@@ -337,16 +342,25 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
       qv = pairs[((size_t)cand * ld + i) * 2 + 1];
     }
     __syncthreads();
-    sp[2 * threadIdx.x + 0] = pv;
-    sp[2 * threadIdx.x + 1] = qv;
+    {
+      float* d = spf + (threadIdx.x >> 1) * 12 + (threadIdx.x & 1);
+      d[0] = pv.x; d[2] = pv.y; d[4] = pv.z; d[6] = qv.x; d[8] = qv.y; d[10] = qv.z;
+    }
     __syncthreads();
-    const int t_begin = (int)(sub * (SC_STAGE / nsub)), t_end = (int)((sub + 1) * (SC_STAGE / nsub));
+    const int t_begin = (int)(sub * (SC_STAGE / 2 / nsub)), t_end = (int)((sub + 1) * (SC_STAGE / 2 / nsub));
 #pragma unroll 4
     for (int t = t_begin; t < t_end; ++t) {
-      const f32x4 p = sp[2 * t], q = sp[2 * t + 1];
-      float x, y, z;
-      xform(T, p.x, p.y, p.z, x, y, z);
-      cnt += (dist2(x, y, z, q.x, q.y, q.z) < thr2) ? 1u : 0u;
+      const f32x4 a = sp[3 * t], bq = sp[3 * t + 1], c = sp[3 * t + 2];
+      const f32x2 px = {a.x, a.y}, py = {a.z, a.w}, pz = {bq.x, bq.y}, qx = {bq.z, bq.w}, qy = {c.x, c.y}, qz = {c.z, c.w};
+      // xform(): ((r0 x + r1 y) + r2 z) + t, two points at once
+      const f32x2 x = ((f32x2{T[0], T[0]} * px + f32x2{T[1], T[1]} * py) + f32x2{T[2], T[2]} * pz) + f32x2{T[9], T[9]};
+      const f32x2 y = ((f32x2{T[3], T[3]} * px + f32x2{T[4], T[4]} * py) + f32x2{T[5], T[5]} * pz) + f32x2{T[10], T[10]};
+      const f32x2 z = ((f32x2{T[6], T[6]} * px + f32x2{T[7], T[7]} * py) + f32x2{T[8], T[8]} * pz) + f32x2{T[11], T[11]};
+      // dist2(): (dx dx + dy dy) + dz dz
+      const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+      const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+      cnt += (d2.x < thr2) ? 1u : 0u;
+      cnt += (d2.y < thr2) ? 1u : 0u;
     }
   }
   if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
     const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
     const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
-    return ((ex * ex + ey * ey) + ez * ez) * 0.99999905f;
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * 0.99999905f;  // (a bound, not a distance: fused is fine)
   };
   for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
     float lbs = 3.402823466e+38f;
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
         const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
         const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-        const f32x2 lb = ((ex * ex + ey * ey) + ez * ez) * f32x2{0.99999905f, 0.99999905f};
+        const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * 0.99999905f,
+                          __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
         need[0] = valid[0] && lb.x <= best[0];
         need[1] = valid[1] && lb.y <= best[1];
         any_need = need[0] || need[1];
@@ -399,7 +400,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
           const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
           const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-          const f32x2 lb = ((ex * ex + ey * ey) + ez * ez) * f32x2{0.99999905f, 0.99999905f};
+          // sums of squares with scalar fma (2.7 cycles each; the packed forms are 4.4): a bound, not a distance
+          const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * 0.99999905f,
+                            __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
           const bool nd0 = act[u] && lb.x <= bst[u], nd1 = act[u] && lb.y <= bst[u];
           const unsigned long long m0 = __builtin_amdgcn_ballot_w64(nd0), m1 = __builtin_amdgcn_ballot_w64(nd1);
           const uint32_t c0n = (uint32_t)__popcll(m0);

@@ -9,10 +9,12 @@
 //   * upper bounds come from the previous ICP pass's correspondence (warm start) or from the curve
 //     neighbourhood of the point in the target's key order;
 //   * 64 boxes at a time are tested against the wave's box by the 64 lanes (one ballot), the
-//     survivors against each lane's own points; every (source, sub-block) pair that can still hold a
-//     nearer (or equally near) point becomes a work item in a wave-private LDS queue, consumed 64 items
-//     at a time: a lane walks ITS sub-block's 16 staged targets and folds the minimum into the source's
-//     packed (d2 bits << 32 | sub-block) key with an LDS atomic min.
+//     survivors against each lane's own points; the sources that pass a chunk are listed, and a lane tests
+//     one listed source against TWO of the chunk's sub-block boxes (stored interleaved for packed fp32);
+//     every (source, sub-block) pair that can still hold a nearer (or equally near) point becomes a work
+//     item in a wave-private LDS queue, consumed 64 items at a time: a lane walks ITS sub-block's 16 staged
+//     targets and folds the minimum into the source's packed (d2 bits << 32 | sub-block << 1 | half) key
+//     with an LDS atomic min; the index recovery re-reads the 8 targets of the winning half.
 // A box is skipped only when a conservative lower bound of its distance exceeds the current best
 // of the point (or of every point of the wave), so no candidate for the minimum (or for a tie) is missed.
 //
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
     size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
-    uint32_t* __restrict__ trace /* dev only: [wave][8] = cycles, candidate chunks, chunks, rounds, items, listed sources, job, group */) {
+    uint32_t* __restrict__ trace /* dev only: [wave][8] = cycles, cycles in chunks, chunks, rounds, items, prologue cycles, job, live sub-blocks | pairs | steps */) {
   constexpr int S = 64 * CS;        // sources per wave
   constexpr int NSB = CH / SB;      // sub-blocks per chunk
   // The staged chunk is kept as PAIRS of targets, structure-of-arrays: pair i of a sub-block is
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
     f32x4 src[S];                   // moved source points
-    unsigned long long key[S];      // (bits(best d2) << 32) | sub-block holding it
-    uint8_t tie[S];                 // (sizes are chosen so that CS = 2 stays under 8 KB per wave: 5 work-groups per CU)
+    unsigned long long key[S];      // (bits(best d2) << 32) | (sub-block holding it << 1) | its half
+    uint8_t tie[S];                 // (CS = 2: 6.8 KB per wave; five waves per SIMD -- 88 VGPRs -- need <= 8 KB)
     uint16_t list[S];               // source slots that passed the chunk-level test
     uint16_t queue[QCAP];           // work items: (source slot << 3) | sub-block within the chunk
 #ifdef GLOC_NN_LDS_PAD

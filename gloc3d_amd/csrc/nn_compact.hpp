@@ -119,10 +119,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   constexpr int QCAP = GLOC_NN_QCAP;  // (tests build a 128-entry variant to drive the early evaluation on every step)
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
-    f32x4 src[S];                   // moved source points
-    unsigned long long key[S];      // (bits(best d2) << 32) | (sub-block holding it << 1) | its half
+    f32x4 src[S + 1];               // moved source points; [S]: a dummy the padded tail of the list points at
+    unsigned long long key[S + 1];  // (bits(best d2) << 32) | (sub-block holding it << 1) | its half; [S]: bound -1 (nothing passes)
     uint8_t tie[S];                 // (CS = 2: 6.8 KB per wave; five waves per SIMD -- 88 VGPRs -- need <= 8 KB)
-    uint16_t list[S];               // source slots that passed the chunk-level test
+    uint16_t list[S + 16];          // source slots that passed the chunk-level test, padded to a multiple of 16 with S
     uint16_t queue[QCAP];           // work items: (source slot << 3) | sub-block within the chunk
 #ifdef GLOC_NN_LDS_PAD
     uint8_t pad_[GLOC_NN_LDS_PAD];  // dev: occupancy experiments
@@ -219,6 +219,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     L.src[slot] = f32x4{px[s], py[s], pz[s], 0.f};
     L.key[slot] = ((unsigned long long)__float_as_uint(best[s]) << 32) | b0;
     L.tie[slot] = 0;
+  }
+  if (lane == 0) {  // the dummy slot: a negative bound -- no box lower bound (>= 0) passes it
+    L.src[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+    L.key[S] = (unsigned long long)__float_as_uint(-1.f) << 32;
   }
   auto wave_max_best = [&]() {
     float m = -1.f;
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
               (uint16_t)(s * 64 + lane);
         k += (uint32_t)__popcll(m);
       }
+      if (lane < 16) L.list[k + lane] = (uint16_t)S;  // (the test steps then need no bounds check)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -384,8 +389,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
           const uint32_t t = t0 + u * 64 + lane;
-          act[u] = t < k * (NSB / 2);
-          si[u] = L.list[act[u] ? (t >> 2) : 0];
+          act[u] = true;  // entries past k are the dummy slot: its bound (-1) rejects every box
+          si[u] = L.list[t >> 2];
         }
         f32x4 p[TU];
         float bst[TU];

@@ -371,9 +371,13 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             const uint32_t blk = c * NSB + bi;
             const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 2u + (mh[1] < mh[0] ? 1u : 0u));
             const unsigned long long old = atomicMin(&L.key[slot], key);
-            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this one
+            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this
+            // one.  Both need an exact equality first: the rest is looked at only when some lane has one (rare).
             const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
-            if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
+            const bool maybe = od == md || mh[0] == mh[1];
+            if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+              if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
+            }
           }
         }
         total = 0;

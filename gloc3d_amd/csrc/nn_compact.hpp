@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         total = 0;
       };
       const uint32_t sb0 = (lane & 3) * 2;
+      const uint16_t* list_lane = &L.list[lane >> 2];
       // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
       // 6 % slower -- a processed chunk lists 58 sources on average, many far fewer
       constexpr int TU = 1;
@@ -392,9 +393,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         bool act[TU];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-          const uint32_t t = t0 + u * 64 + lane;
           act[u] = true;  // entries past k are the dummy slot: its bound (-1) rejects every box
-          si[u] = L.list[t >> 2];
+          si[u] = list_lane[(t0 + u * 64) >> 2];  // = L.list[(t0 + u * 64 + lane) >> 2]: one add per step
         }
         f32x4 p[TU];
         float bst[TU];

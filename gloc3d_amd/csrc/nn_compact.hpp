@@ -94,7 +94,7 @@ __device__ __forceinline__ double exchange_add(double x, double y) {
 // so with job_group a multiple of 8 all work-groups of a job run on ONE XCD and its candidate scan (2 MB of
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
-template <int CS, bool PAIRS>
+template <int CS, bool PAIRS, bool TRACE = false>
 __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
     const CandState* __restrict__ states,
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
-  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0;
   unsigned long long n_items = 0;
 
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         }
       }
     }
+    if (!valid[s]) best[s] = -1.f;  // a lane without a point: a bound no box lower bound (>= 0) passes
     const int slot = s * 64 + lane;
     L.src[slot] = f32x4{px[s], py[s], pz[s], 0.f};
     L.key[slot] = ((unsigned long long)__float_as_uint(best[s]) << 32) | b0;
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   auto wave_max_best = [&]() {
     float m = -1.f;
 #pragma unroll
-    for (int s = 0; s < CS; ++s) m = fmaxf(m, valid[s] ? best[s] : -1.f);
+    for (int s = 0; s < CS; ++s) m = fmaxf(m, best[s]);  // (-1 where there is no point)
     return wave_minmax<true>(m);
   };
   float wmax = wave_max_best();
-  const unsigned long long t_pro = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_pro = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_chunks = 0;
 
   // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
@@ -296,19 +297,19 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
         const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * 0.99999905f,
                           __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
-        need[0] = valid[0] && lb.x <= best[0];
-        need[1] = valid[1] && lb.y <= best[1];
+        need[0] = lb.x <= best[0];  // (a lane without a point carries the bound -1: nothing passes)
+        need[1] = lb.y <= best[1];
         any_need = need[0] || need[1];
       } else {
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
-          need[s] = valid[s] && (box_lb(px[s], py[s], pz[s], lo, hi) <= best[s]);
+          need[s] = box_lb(px[s], py[s], pz[s], lo, hi) <= best[s];
           any_need |= need[s];
         }
       }
       if (__builtin_amdgcn_ballot_w64(any_need) == 0ull) continue;
       n_processed++;
-      const unsigned long long t_c0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+      const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
 #pragma unroll
       for (int u = 0; u < CH / 64; ++u) {
@@ -424,10 +425,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             L.queue[total + c0n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] =
                 (uint16_t)((si[u] << 3) | (sb0 + 1));
           total += c0n + (uint32_t)__popcll(m1);
-          if (trace) sbmask |= (nd0 ? (1u << sb0) : 0u) | (nd1 ? (2u << sb0) : 0u);
+          if constexpr (TRACE) sbmask |= (nd0 ? (1u << sb0) : 0u) | (nd1 ? (2u << sb0) : 0u);
         }
       }
-      if (trace) {
+      if constexpr (TRACE) {
         uint32_t lm = 0;
         for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;
         n_live_sb += (uint32_t)__popc(lm);
@@ -446,14 +447,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         best[s] = nb;
       }
       if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax = wave_max_best();
-      if (trace) t_chunks += __builtin_amdgcn_s_memtime() - t_c0;
+      if constexpr (TRACE) t_chunks += __builtin_amdgcn_s_memtime() - t_c0;
     }
     }  // batches of this super-chunk group
   }
   // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
   // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
-  const unsigned long long t_sweep = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     if ((lane & 3) == 0) out[(lane >> 2) & 15] = x;
     if (lane == 0) out[16] = y;
   }
-  if (trace && lane == 0) {
+  if (TRACE && trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
     trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
     trace[8 * wid + 1] = (uint32_t)t_chunks;  // cycles inside chunk processing

@@ -93,7 +93,12 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 32, h->stream));
     }
 #define LAUNCH_COMPACT(CS_, P_)                                                                          \
-  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
+  do {                                                                                                  \
+    if (h->trace_on) LAUNCH_COMPACT_T(CS_, P_, true);                                                   \
+    else LAUNCH_COMPACT_T(CS_, P_, false);                                                              \
+  } while (0)
+#define LAUNCH_COMPACT_T(CS_, P_, T_)                                                                    \
+  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, (uint32_t)h->nn_job_group, n_wg, h->states.as<CandState>(),              \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), h->partials.as<double>(), bd.n_part, bd.ld, \
@@ -112,6 +117,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       }
     }
 #undef LAUNCH_COMPACT
+#undef LAUNCH_COMPACT_T
   }
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;

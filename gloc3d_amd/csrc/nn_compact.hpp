@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       hi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.x), b));
       hi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.y), b));
       hi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.z), b));
-      bool need[CS], any_need = false;
+      bool need[CS];
+      unsigned long long nm[CS], nm_any = 0ull;  // the ballots, taken where the comparisons are made
       if constexpr (CS == 2) {  // box_lb() of the lane's two points per packed instruction
         const f32x2 qx = {px[0], px[1]}, qy = {py[0], py[1]}, qz = {pz[0], pz[1]};
         const f32x2 ax = f32x2{lo.x, lo.x} - qx, bx = qx - f32x2{hi.x, hi.x};
@@ -299,15 +300,18 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
                           __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
         need[0] = lb.x <= best[0];  // (a lane without a point carries the bound -1: nothing passes)
         need[1] = lb.y <= best[1];
-        any_need = need[0] || need[1];
+        nm[0] = __builtin_amdgcn_ballot_w64(need[0]);
+        nm[1] = __builtin_amdgcn_ballot_w64(need[1]);
+        nm_any = nm[0] | nm[1];
       } else {
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
           need[s] = box_lb(px[s], py[s], pz[s], lo, hi) <= best[s];
-          any_need |= need[s];
+          nm[s] = __builtin_amdgcn_ballot_w64(need[s]);
+          nm_any |= nm[s];
         }
       }
-      if (__builtin_amdgcn_ballot_w64(any_need) == 0ull) continue;
+      if (nm_any == 0ull) continue;
       n_processed++;
       const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       uint32_t k = 0;
 #pragma unroll
       for (int s = 0; s < CS; ++s) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(need[s]);
+        const unsigned long long m = nm[s];
         if (need[s])
           L.list[k + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
               (uint16_t)(s * 64 + lane);

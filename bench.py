@@ -507,7 +507,10 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_nn_compact.json")
     issue_model = None
     if args.nn_mode == "culled" and world == 1 and os.path.exists(pmc):
-        pj = json.load(open(pmc))
+        try:
+            pj = json.load(open(pmc))
+        except ValueError:      # an empty or damaged file: the line is still printed, without the PMC-derived fields
+            pj = {}
         traffic = pj.get("hbm_bytes_per_launch")
         if pj.get("jobs_per_launch") and abs(pj["jobs_per_launch"] - jobs_per_launch) > 1e-6:
             traffic = traffic * jobs_per_launch / pj["jobs_per_launch"]      # PMC passes ran at another batch size

@@ -10,6 +10,7 @@ base = [store.add(np.ascontiguousarray(synth.lidar_scan(w, bench.pool_pose(s), s
 cands = [store.add_variant(base[g % 4], bench.place_perturbation(g), 0.01, 7000 + g) for g in range(40)]
 qs = [store.add_variant(base[g % 4], bench.place_perturbation(100 + g), 0.01, 8000 + g) for g in range(25)]
 reg = capi.Registrar(store=store)
+reg.set_option(capi.REG_OPT_PROFILE, 1)
 cl = [[cands[(q + c) % 40] for c in range(20)] for q in range(25)]
 for name, prm in (("no work (ransac 0, icp 0)", capi.default_reg_params(ransac_iters=0, icp_iters=0)),
                   ("1 ICP pass", capi.default_reg_params(ransac_iters=0, icp_iters=1)),

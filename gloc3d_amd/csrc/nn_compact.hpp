@@ -57,11 +57,12 @@ __device__ __forceinline__ float wave_minmax(float x) {
   x = op(x, dpp_f32<0x4E>(x));   // quad_perm [2,3,0,1]
   x = op(x, dpp_f32<0x141>(x));  // row_half_mirror
   x = op(x, dpp_f32<0x140>(x));  // row_mirror
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
-  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
-  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
-  return op(op(r0, r1), op(r2, r3));
+  // across the four rows: row_bcast:15 hands a row's value (all its lanes hold it) to the next row -- rows 1 and 3
+  // take it -- then row_bcast:31 hands rows 0-1's to rows 2 and 3; lanes left out keep x (old = x: op(x, x) = x).
+  // Lane 63 ends with the wave's value: one v_readlane instead of four plus three combines.
+  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x142, 0xA, 0xF, false)));
+  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x143, 0xC, 0xF, false)));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
 // (xor_lane<O>: lane_ops.hpp -- DPP below 16 lanes; ds_bpermute kept the LDS pipe busy and was worth 6 % of the launch)

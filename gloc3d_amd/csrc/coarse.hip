@@ -22,6 +22,8 @@ struct gloc_coarse {
   std::vector<void*> blocks;      // one allocation per grid (null: released)
   std::vector<GridDev> grids;     // host copies of the device views
   std::vector<uint32_t> counts;   // occupied cells per grid
+  std::vector<uint32_t> cell_px;  // the geometry each grid was built with: a match with other parameters
+  std::vector<float> res;         // would silently return a wrong (x, y, yaw), so it is rejected
   std::vector<uint32_t> free_ids;
   DevBuf scratch_bits, scratch_cnt, stage_img, tiny_img;
   DevBuf d_grids, d_pq, d_pd, d_trig, d_yaw, d_yawout, d_cand, d_verify, d_out;
@@ -45,7 +47,7 @@ int check_params(const gloc_coarse_params* p) {
 }
 
 // bits in h->scratch_bits -> a new grid
-int finish_grid(gloc_coarse* h, uint32_t* grid_id) {
+int finish_grid(gloc_coarse* h, const gloc_coarse_params* prm, uint32_t* grid_id) {
   hipStream_t s = h->stream;
   // count first (host needs it to size the cell list)
   std::vector<uint32_t> hb(G * GW);
@@ -64,16 +66,20 @@ int finish_grid(gloc_coarse* h, uint32_t* grid_id) {
   g.hy = g.hx + G;
   g.cells = g.hy + G;
   g.count = g.cells + std::max<uint32_t>(n, 1);
-  if (hipMemcpyAsync(g.bits, h->scratch_bits.p, sizeof(uint32_t) * G * GW, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemsetAsync(g.count, 0, sizeof(uint32_t), s) != hipSuccess) {
+  hipError_t e = hipMemcpyAsync(g.bits, h->scratch_bits.p, sizeof(uint32_t) * G * GW, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(g.count, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
     (void)hipFree(blk);
-    set_err("coarse grid setup failed: %s", hipGetErrorString(hipGetLastError()));
+    set_err("coarse grid setup failed: %s", hipGetErrorString(e));
     return GLOC_ERR_HIP;
   }
   hipLaunchKernelGGL(finish_grid_kernel, dim3(1), dim3(G), 0, s, g, std::max<uint32_t>(n, 1));
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+  e = hipGetLastError();  // (read once: the call clears the error)
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
     (void)hipFree(blk);
-    set_err("coarse grid kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    set_err("coarse grid kernel failed: %s", hipGetErrorString(e));
     return GLOC_ERR_HIP;
   }
   uint32_t id;
@@ -83,11 +89,15 @@ int finish_grid(gloc_coarse* h, uint32_t* grid_id) {
     h->blocks[id] = blk;
     h->grids[id] = g;
     h->counts[id] = n;
+    h->cell_px[id] = prm->cell_px;
+    h->res[id] = prm->resolution;
   } else {
     id = (uint32_t)h->grids.size();
     h->blocks.push_back(blk);
     h->grids.push_back(g);
     h->counts.push_back(n);
+    h->cell_px.push_back(prm->cell_px);
+    h->res.push_back(prm->resolution);
   }
   h->grids_dirty = true;
   *grid_id = id;
@@ -166,7 +176,7 @@ int gloc_coarse_add_image(gloc_coarse* h, const uint8_t* occupancy, uint32_t wid
                        h->scratch_bits.as<uint32_t>());
     GLOC_HIP(hipGetLastError());
   }
-  return finish_grid(h, grid_id);
+  return finish_grid(h, params, grid_id);
 }
 
 int gloc_coarse_add_scan(gloc_coarse* h, const float* xyz, size_t n, size_t stride_floats,
@@ -198,7 +208,7 @@ int gloc_coarse_add_scan(gloc_coarse* h, const float* xyz, size_t n, size_t stri
                        (int)params->cell_px, h->scratch_bits.as<uint32_t>());
     GLOC_HIP(hipGetLastError());
   }
-  return finish_grid(h, grid_id);
+  return finish_grid(h, params, grid_id);
 }
 
 int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id) {
@@ -239,7 +249,7 @@ int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t 
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   DevScan sc;
-  GLOC_TRY(gloc::reg::store_get(store, scan_id, 2, &sc));
+  GLOC_TRY(gloc::reg::store_get(store, scan_id, 0, &sc));  // only the points are read
   if (!h->bev) {
     GLOC_TRY(gloc_bev_create(h->device, &h->bev));
     GLOC_TRY(gloc_bev_set_stream(h->bev, (void*)s));
@@ -264,7 +274,7 @@ int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t 
                        (int)params->cell_px, h->scratch_bits.as<uint32_t>());
     GLOC_HIP(hipGetLastError());
   }
-  return finish_grid(h, grid_id);
+  return finish_grid(h, params, grid_id);
 }
 
 int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
@@ -285,6 +295,10 @@ int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint3
                  q_grids[i]);
     GLOC_REQUIRE(db_grids[i] < h->blocks.size() && h->blocks[db_grids[i]], GLOC_ERR_INVALID, "unknown grid id %u",
                  db_grids[i]);
+    for (uint32_t g : {q_grids[i], db_grids[i]})
+      GLOC_REQUIRE(h->cell_px[g] == params->cell_px && h->res[g] == params->resolution, GLOC_ERR_INVALID,
+                   "grid %u was built with cell_px %u / resolution %g, the match asks for %u / %g", g, h->cell_px[g],
+                   (double)h->res[g], params->cell_px, (double)params->resolution);
   }
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;

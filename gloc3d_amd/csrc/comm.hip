@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "comm.hpp"
@@ -33,9 +34,8 @@ struct Rccl {
 
 Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;  // two host threads may make their first gloc_comm_* / sharded call together
+  std::call_once(once, [] {
     // a copy already in the process first (PyTorch's), then GLOC3D_RCCL, then the system's
     const char* env = getenv("GLOC3D_RCCL");
     const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -52,7 +52,7 @@ Rccl* rccl() {
       r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
       if (!r.get_id || !r.init_rank || !r.destroy || !r.allgather || !r.group_start || !r.group_end) r.lib = nullptr;
     }
-  }
+  });
   return r.lib ? &r : nullptr;
 }
 
@@ -132,6 +132,9 @@ int gloc_comm_create(int device, int rank, int world, const uint8_t* id128, gloc
 int gloc_comm_destroy(gloc_comm* c) {
   if (!c) return GLOC_OK;
   Rccl* r = rccl();
+  // collectives of this communicator may still be in flight on streams this library does not own
+  // (gloc_knn_search_sharded's handle stream, the caller's stream of all_gather_device): drain the device first
+  if (hipSetDevice(c->device) == hipSuccess) (void)hipDeviceSynchronize();
   if (r && c->nccl) (void)r->destroy(c->nccl);
   delete c;
   return GLOC_OK;
@@ -160,12 +163,19 @@ int gloc_comm_all_gather_host(gloc_comm* c, const void* send, void* recv, size_t
   char* ds = static_cast<char*>(d);
   char* dr = ds + bytes_per_rank;
   int rc = GLOC_OK;
-  if (hipMemcpy(ds, send, bytes_per_rank, hipMemcpyHostToDevice) != hipSuccess) rc = GLOC_ERR_HIP;
-  if (rc == GLOC_OK) rc = comm::all_gather(c, ds, dr, bytes_per_rank, nullptr);
-  if (rc == GLOC_OK && (hipStreamSynchronize(nullptr) != hipSuccess ||
-                        hipMemcpy(recv, dr, bytes_per_rank * (size_t)c->world, hipMemcpyDeviceToHost) != hipSuccess))
+  hipError_t e = hipMemcpy(ds, send, bytes_per_rank, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = comm::all_gather(c, ds, dr, bytes_per_rank, nullptr);  // (on failure its own message stays in place)
+    if (rc == GLOC_OK) {
+      e = hipStreamSynchronize(nullptr);
+      if (e == hipSuccess) e = hipMemcpy(recv, dr, bytes_per_rank * (size_t)c->world, hipMemcpyDeviceToHost);
+    }
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_err("gloc_comm_all_gather_host: %s", hipGetErrorString(e));
     rc = GLOC_ERR_HIP;
-  if (rc == GLOC_ERR_HIP) set_err("gloc_comm_all_gather_host: %s", hipGetErrorString(hipGetLastError()));
+  }
   (void)hipFree(d);
   return rc;
 }

@@ -301,7 +301,7 @@ struct TempScans {
     std::lock_guard<std::mutex> lk(st->mu);
     DevScan s;
     GLOC_TRY(store_make_scan(st, pts, n, 3, false, &s));
-    if (cs != 2) GLOC_TRY(store_build_order(st, s, cs));
+    GLOC_TRY(store_build_order(st, s, cs));  // (cs = 0: a target, no order)
     scans.push_back(s);
     return GLOC_OK;
   }
@@ -462,7 +462,7 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   GLOC_TRY(ensure_store(h));
   TempScans tmp(h->store);  // released on return
   GLOC_TRY(tmp.add(q_xyz, nq_pts, h->nn_src_per_lane));
-  for (size_t c = 0; c < n_cand; ++c) GLOC_TRY(tmp.add(cand_xyz[c], cand_npts[c], 2));
+  for (size_t c = 0; c < n_cand; ++c) GLOC_TRY(tmp.add(cand_xyz[c], cand_npts[c], 0));
   std::vector<JobHost> jh(n_cand);
   for (size_t c = 0; c < n_cand; ++c)
     jh[c] = JobHost{tmp.scans[0], tmp.scans[c + 1], cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c,
@@ -494,7 +494,7 @@ int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_i
       if (cand_scan_ids[o] == 0xFFFFFFFFu) continue;  // "no candidate" (a retrieval list shorter than k)
       JobHost j;
       j.src = src;
-      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 2, &j.tgt));
+      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 0, &j.tgt));  // a target's launch order is never read
       j.stream_id = cand_stream_ids ? cand_stream_ids[o] : (uint32_t)c;
       j.init_T = init_T ? init_T + 16 * o : nullptr;
       jh.push_back(j);
@@ -561,7 +561,7 @@ int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* 
       if (cand_scan_ids[o] == 0xFFFFFFFFu) continue;
       JobHost j;
       j.src = src[q];
-      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 2, &j.tgt));
+      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 0, &j.tgt));  // a target's launch order is never read
       j.stream_id = (uint32_t)r;  // the RANSAC stream of retrieval rank r: the same job as in gloc_reg_batch_multi
       j.init_T = init_T ? init_T + 16 * o : nullptr;
       jh.push_back(j);
@@ -628,7 +628,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   hipStream_t s = h->stream;
   TempScans tmp(h->store);
   GLOC_TRY(tmp.add(src_xyz, n_src, h->nn_src_per_lane));
-  GLOC_TRY(tmp.add(tgt_xyz, n_tgt, 2));
+  GLOC_TRY(tmp.add(tgt_xyz, n_tgt, 0));
   const int cs = h->nn_src_per_lane;
   const uint32_t ng = (uint32_t)((n_src + 64 * cs - 1) / (64 * cs));
   BatchDims bd{1, (uint32_t)n_src, ng, std::max<uint32_t>(ng, 1), ((size_t)n_src + 127) & ~(size_t)127};

@@ -272,9 +272,9 @@ Layout layout_for(size_t n) {
   L.b1 = L.c1 * (CH / SB / 2) * 3;  // float4 per scan of the paired sub-block boxes
   L.u1 = std::max<size_t>(nsup, 1);
   L.g1 = (L.n1 + 63) / 64;
-  // header | pts4 | box_lo | box_hi | sb2 | sup_lo | sup_hi | xyz | keys | inv | order
+  // header | pts4 | box_lo | box_hi | sb2 | sup_lo | sup_hi | xyz | keys | inv | order (cs = 1 | 2 | 4)
   L.bytes = sizeof(ScanHeader) + sizeof(f32x4) * (L.np + 2 * L.c1 + L.b1 + 2 * L.u1) +
-            sizeof(float) * 3 * L.n1 + sizeof(uint32_t) * (2 * L.n1 + L.g1);
+            sizeof(float) * 3 * L.n1 + sizeof(uint32_t) * (2 * L.n1 + 2 * L.g1 + 2);
   return L;
 }
 
@@ -289,7 +289,21 @@ int take_block(gloc_scan_store* st, size_t bytes, void** out, size_t* cap) {
     return GLOC_OK;
   }
   const size_t want = (bytes + (256u << 10) - 1) & ~(size_t)((256u << 10) - 1);  // 256 KiB granules: reuse
-  GLOC_HIP(hipMalloc(out, want));
+  hipError_t e = hipMalloc(out, want);
+  if (e == hipErrorOutOfMemory && !st->free_blocks.empty()) {
+    // a store near HBM capacity: give the parked allocations back before reporting failure
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(st->stream);
+    for (auto& kv : st->free_blocks) (void)hipFree(kv.second);
+    st->free_blocks.clear();
+    st->cached_bytes = 0;
+    e = hipMalloc(out, want);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_err("hipMalloc of %zu bytes for a scan failed: %s", want, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? GLOC_ERR_NOMEM : GLOC_ERR_HIP;
+  }
   *cap = want;
   return GLOC_OK;
 }
@@ -309,10 +323,16 @@ void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block) {
 }
 
 int store_build_order(gloc_scan_store* st, DevScan& s, int cs) {
-  if (s.order_cs == cs || s.n == 0) {
-    s.order_cs = cs;
+  if (cs == 0) {
+    s.order = nullptr;
     return GLOC_OK;
   }
+  if (cs != 1 && cs != 2 && cs != 4) {
+    set_err("sources per lane must be 1, 2 or 4 (got %d)", cs);
+    return GLOC_ERR_INVALID;
+  }
+  s.order = s.order_of(cs);
+  if ((s.order_built & (1u << cs)) || s.n == 0) return GLOC_OK;
   hipStream_t q = st->stream;
   const uint32_t group = 64u * (uint32_t)cs;
   const uint32_t ng = (uint32_t)((s.n + group - 1) / group);
@@ -331,7 +351,7 @@ int store_build_order(gloc_scan_store* st, DevScan& s, int cs) {
                                                         s.order, (int)ng, 0, 32, q));
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipStreamSynchronize(q));
-  s.order_cs = cs;
+  s.order_built |= 1u << cs;
   return GLOC_OK;
 }
 
@@ -352,7 +372,9 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
   s.xyz = reinterpret_cast<float*>(uhi + L.u1);
   uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * L.n1);
   uint32_t* inv = keys + L.n1;
-  s.order = inv + L.n1;
+  s.order_base = inv + L.n1;
+  s.order_g1 = L.g1;
+  s.order = nullptr;
   s.idx = ScanIndexDev{p4, lo, hi, sb2, nullptr, keys, inv, hdr, ulo, uhi, (uint32_t)n, (uint32_t)nch,
                        (uint32_t)nsup, 0u};
   hipStream_t q = st->stream;
@@ -367,16 +389,19 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
     if (!device_src) {
       // host points travel as they are (stride included) into a staging buffer; the pack kernel
       // drops the extra channels on the device
-      if (st->stage.ensure(sizeof(float) * stride * n, q)) return fail(GLOC_ERR_NOMEM);
-      if (hipMemcpyAsync(st->stage.p, pts, sizeof(float) * stride * n, hipMemcpyHostToDevice, q) != hipSuccess) {
-        set_err("scan upload failed: %s", hipGetErrorString(hipGetLastError()));
+      if (int rc = st->stage.ensure(sizeof(float) * stride * n, q)) return fail(rc);
+      const hipError_t eu = hipMemcpyAsync(st->stage.p, pts, sizeof(float) * stride * n, hipMemcpyHostToDevice, q);
+      if (eu != hipSuccess) {
+        (void)hipGetLastError();
+        set_err("scan upload failed: %s", hipGetErrorString(eu));
         return fail(GLOC_ERR_HIP);
       }
       d_in = st->stage.as<float>();
     }
-    if (st->sort_keys.ensure(sizeof(uint32_t) * n, q) || st->sort_vals.ensure(sizeof(uint32_t) * n, q) ||
-        st->sort_perm.ensure(sizeof(uint32_t) * n, q) || st->sort_tmp.ensure(sizeof(uint32_t) * 6 * PACK_BLOCKS, q))
-      return fail(GLOC_ERR_NOMEM);
+    for (auto need : {std::make_pair(&st->sort_keys, sizeof(uint32_t) * n), std::make_pair(&st->sort_vals, sizeof(uint32_t) * n),
+                      std::make_pair(&st->sort_perm, sizeof(uint32_t) * n),
+                      std::make_pair(&st->sort_tmp, sizeof(uint32_t) * 6 * PACK_BLOCKS)})
+      if (int rc = need.first->ensure(need.second, q)) return fail(rc);  // (the actual code: NOMEM or a HIP error)
     const unsigned nb = (unsigned)((n + 255) / 256);
     const unsigned npk = std::min<unsigned>(nb, PACK_BLOCKS);
     uint32_t* part = st->sort_tmp.as<uint32_t>();  // free until the radix sort below
@@ -389,7 +414,7 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
                                            st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
                                            (int)n, 0, 30, q) != hipSuccess)
       return fail(GLOC_ERR_HIP);
-    if (st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q)) return fail(GLOC_ERR_NOMEM);
+    if (int rc = st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q)) return fail(rc);
     if (hipcub::DeviceRadixSort::SortPairs(st->sort_tmp.p, tmp_bytes, st->sort_keys.as<uint32_t>(), keys,
                                            st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
                                            (int)n, 0, 30, q) != hipSuccess)
@@ -400,8 +425,9 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
     hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((L.b1 / 3 + 255) / 256)), dim3(256), 0, q, p4,
                        (uint32_t)n, (uint32_t)(L.b1 / 3), sb2);
     hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, q, lo, hi, (uint32_t)nch, ulo, uhi);
-    if (hipGetLastError() != hipSuccess) {
-      set_err("scan indexing failed: %s", hipGetErrorString(hipGetLastError()));
+    const hipError_t ei = hipGetLastError();  // (read once: the call clears the error)
+    if (ei != hipSuccess) {
+      set_err("scan indexing failed: %s", hipGetErrorString(ei));
       return fail(GLOC_ERR_HIP);
     }
     int rc = store_build_order(st, s, 2);  // the default sources-per-lane; synchronises the stream
@@ -421,8 +447,9 @@ int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out) {
     return GLOC_ERR_INVALID;
   }
   DevScan& s = st->scans[id];
-  if (s.order_cs != cs && s.n) GLOC_TRY(store_build_order(st, s, cs));
+  GLOC_TRY(store_build_order(st, s, cs));  // builds that cs's own array on first use; never rewrites another
   *out = s;
+  out->order = cs ? s.order_of(cs) : nullptr;
   return GLOC_OK;
 }
 

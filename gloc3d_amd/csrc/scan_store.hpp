@@ -17,8 +17,18 @@ struct DevScan {
   float* xyz = nullptr;  // original order, packed
   size_t n = 0;
   gloc::reg::ScanIndexDev idx{};
-  uint32_t* order = nullptr;  // source groups of 64 * order_cs sorted points, widest first
-  int order_cs = 0;           // 0: not built
+  // Launch order of the source groups (groups of 64 * cs sorted points, widest first), ONE ARRAY PER cs in
+  // {1, 2, 4}, each built once (cs = 2 at upload, the others on first request) and never rewritten: a
+  // DevScan copy handed out by store_get() keeps pointing at valid, unchanging data whatever other
+  // handles or later calls ask for.  `order` of a copy returned by store_get(cs) is the array of that cs
+  // (null for cs = 0: a target's order is never read).
+  uint32_t* order_base = nullptr;
+  uint32_t* order = nullptr;
+  unsigned order_built = 0;  // bit (cs) set: order_of(cs) is valid
+  size_t order_g1 = 0;       // groups at cs = 1
+  uint32_t* order_of(int cs) const {
+    return order_base + (cs == 1 ? 0 : cs == 2 ? order_g1 : order_g1 + (order_g1 + 1) / 2);
+  }
   bool live = false;
 };
 
@@ -42,9 +52,11 @@ namespace reg {
 int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
                     DevScan* out);
 void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block);
-// (Re)build the launch order of a scan for `cs` source points per lane.  Caller holds store->mu.
+// Build (once) the launch order of a scan for `cs` source points per lane into its own array and point
+// s.order at it.  Caller holds store->mu.
 int store_build_order(gloc_scan_store* st, DevScan& s, int cs);
-// Copy of scan `id` (by value: the table may grow under another thread).  GLOC_ERR_INVALID if unknown.
+// Copy of scan `id` (by value: the table may grow under another thread) with `order` = the launch order
+// for `cs` sources per lane (cs = 0: the scan is used as a target only, no order).  GLOC_ERR_INVALID if unknown.
 int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out);
 
 }  // namespace reg

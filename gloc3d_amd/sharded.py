@@ -94,8 +94,14 @@ class CapiShardedKnn:
         """tables: this rank's [K, n, RESULT_COLS] float32 device tensor -> [world * K, n, RESULT_COLS]."""
         t = tables.contiguous()
         out = torch.empty((self.comm.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        # ONE stream carries every collective of the communicator (the side stream the sharded search runs on):
+        # RCCL orders a communicator's operations by issue order only if they share a stream
         cur = torch.cuda.current_stream()
-        self.comm.all_gather_device(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), cur.cuda_stream)
+        self.side.wait_stream(cur)
+        self.comm.all_gather_device(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), self.side.cuda_stream)
+        cur.wait_stream(self.side)
+        t.record_stream(self.side)
+        out.record_stream(self.side)
         return out.view((self.comm.world * t.shape[0],) + tuple(t.shape[1:]))
 
 

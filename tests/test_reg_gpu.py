@@ -315,6 +315,40 @@ def test_batch_multi_equals_one_query_at_a_time(capi, scans):
     store.close()
 
 
+def test_scan_as_query_and_candidate_with_other_sources_per_lane(capi, scans):
+    """One store scan is the QUERY of one row and a CANDIDATE of another in a single batch_multi call, at
+    sources-per-lane 4 and 1 (the launch order of a scan is one array per setting, built once and never
+    rewritten: round 2 rebuilt it in place and a job could read an order that no longer matched its
+    group count), and two handles with different settings share the store: every row equals the
+    single-query call and the default setting's result."""
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    sa, sb, sc = (store.add(np.ascontiguousarray(x)) for x in (A[::3], B[::3], Cc[::4]))
+    qs = [sa, sb]
+    cand = np.array([[sb, sc], [sa, sc]], np.uint32)      # sa / sb: query of one row, candidate of the other
+    prm = capi.default_reg_params(ransac_iters=200, icp_iters=5)
+    ref = None
+    regs = []
+    for cs in (2, 4, 1, 4):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_SRC_PER_LANE, cs)
+        regs.append(r)
+        m = r.batch_multi(qs, cand, params=prm)
+        for qi in range(2):
+            one = r.batch_ids(qs[qi], cand[qi], params=prm)
+            assert (bits(m["T"][qi]) == bits(one["T"])).all() and (m["inliers"][qi] == one["inliers"]).all()
+        if ref is None:
+            ref = m
+        # the 1-NN results do not depend on the setting; the fp64 moments are summed per wave of 64 * cs sources
+        assert (m["inliers"] == ref["inliers"]).all() and (m["ok"] == ref["ok"]).all()
+        assert np.abs(m["T"] - ref["T"]).max() < 2e-6
+    again = regs[0].batch_multi(qs, cand, params=prm)     # the first handle's order (cs = 2) is still intact
+    assert (bits(again["T"]) == bits(ref["T"])).all()
+    for r in regs:
+        r.close()
+    store.close()
+
+
 def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
     """After EVERY number of ICP passes the correspondences and distances of the last (warm-started) pass of
     the culled search equal those of the exhaustive kernel, bit for bit -- full-size scans, a positive and a

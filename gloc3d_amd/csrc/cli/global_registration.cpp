@@ -1,13 +1,16 @@
 // global_registration -- drop-in for the reference's pairwise registration evaluator
 // (registration/global_registration.cpp:1198-1444; no CMake target upstream):
 //
-//   global_registration VALSET POSES
+//   global_registration VALSET POSES [kitti|nclt|auto]
 //
 // For every query scan and every ground-truth positive database scan: register the pair, print
 // "err_pos, err_rot" (:1417), then the success rate (<1 m and <5 deg) and mean/std (:1432-1442).
 // The reference composes a 2-D SURF match with ground alignment and optionally refines with PCL ICP
 // (:1342-1398, use_icp=false :1222); here the pair goes through the 3-D RANSAC-SVD + ICP hot path.
-// No GUI windows are opened.  Scans: KITTI float32 x,y,z,i, or NCLT raw if the size says so.
+// No GUI windows are opened.  Scans: the reference reads NCLT raw records unconditionally (:1239,1304) although
+// its comments say KITTI (:1224-1226); here the optional third argument (or GLOC_SCAN_FORMAT) names the format,
+// and "auto" (default) decides by CONTENT -- never by file size: an NCLT file with an even number of 8-byte
+// records is a multiple of 16 bytes as well (host/gloc_io.hpp: looks_like_kitti).
 #include <cstdio>
 #include <fstream>
 #include <memory>
@@ -16,18 +19,15 @@
 
 using namespace gloc_host;
 
-static std::vector<float> read_scan(const std::string& path) {
-  std::ifstream f(path, std::ios::binary | std::ios::ate);
-  if (!f.is_open()) return {};
-  const size_t bytes = (size_t)f.tellg();
-  return (bytes % 16 == 0) ? read_lidar_kitti(path) : read_lidar_nclt(path);
-}
+static ScanFormat g_format = ScanFormat::Auto;
+static std::vector<float> read_scan(const std::string& path) { return read_lidar_any(path, g_format); }
 
 int main(int argc, char* argv[]) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s VALSET POSES\n", argv[0]);
+    std::fprintf(stderr, "usage: %s VALSET POSES [kitti|nclt|auto]\n", argv[0]);
     return 2;
   }
+  g_format = scan_format_from_string(argc > 3 ? argv[3] : getenv("GLOC_SCAN_FORMAT"));
   Valset vs;
   std::vector<Mat4> poses;
   if (!read_valset(argv[1], vs) || !read_valset_pose(argv[2], poses)) return 1;

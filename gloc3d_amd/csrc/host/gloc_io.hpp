@@ -6,6 +6,7 @@
 // plus the descriptor file that stands in for the TorchScript model (the CNN is out of scope).
 #pragma once
 #include <array>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -141,19 +142,79 @@ inline std::vector<float> read_lidar_kitti(const std::string& path) {
   return buf;
 }
 
-// NCLT velodyne_sync: u16 x,y,z; u8 intensity, label; metres = v * 0.005 - 100.
+// NCLT velodyne_sync: u16 x,y,z; u8 intensity, label; metres = v * 0.005 - 100
+// (read_lidar_data_nclt, registration/global_registration.cpp:181-209).  The reference's loop tests eof()
+// BEFORE it reads (:191-192), so after the last whole record it goes round once more: the reads fail, the
+// fields keep their values and the last point is pushed a second time -- a file of n records gives n + 1
+// points (and the bytes of a truncated trailing record overwrite the leading fields of that extra point).
+// Reproduced here, so that clouds -- and everything computed from them -- equal the reference's.  An empty
+// file yields an empty cloud (upstream pushes one point of uninitialised fields).
 inline std::vector<float> read_lidar_nclt(const std::string& path) {
   std::ifstream f(path, std::ifstream::in | std::ifstream::binary);
   std::vector<float> out;
   if (!f.is_open()) return out;
-  struct __attribute__((packed)) Rec { uint16_t x, y, z; uint8_t i, l; } r;
-  while (f.read(reinterpret_cast<char*>(&r), sizeof(r))) {
-    out.push_back(r.x * 0.005f - 100.f);
-    out.push_back(r.y * 0.005f - 100.f);
-    out.push_back(r.z * 0.005f - 100.f);
-    out.push_back((float)r.i);
+  f.seekg(0, std::ios::end);
+  const size_t bytes = (size_t)f.tellg();
+  f.seekg(0, std::ios::beg);
+  if (bytes == 0) return out;
+  std::vector<unsigned char> raw(bytes);
+  f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)bytes);
+  unsigned char rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  out.reserve(4 * (bytes / 8 + 1));
+  for (size_t off = 0;; off += 8) {
+    const size_t avail = off < bytes ? (bytes - off < 8 ? bytes - off : 8) : 0;
+    std::memcpy(rec, raw.data() + (off < bytes ? off : 0), avail);  // a failed read leaves the rest untouched
+    uint16_t v[3];
+    std::memcpy(v, rec, 6);
+    out.push_back((float)v[0] * 0.005f + -100.0f);
+    out.push_back((float)v[1] * 0.005f + -100.0f);
+    out.push_back((float)v[2] * 0.005f + -100.0f);
+    out.push_back((float)rec[6]);
+    if (avail < 8) break;  // that read hit the end of the file: eof() is set, the loop ends
   }
   return out;
+}
+
+enum class ScanFormat { Auto, Kitti, Nclt };
+
+// "kitti" / "nclt" / "auto" (anything else: Auto)
+inline ScanFormat scan_format_from_string(const char* s) {
+  if (!s) return ScanFormat::Auto;
+  const std::string t(s);
+  if (t == "kitti" || t == "KITTI") return ScanFormat::Kitti;
+  if (t == "nclt" || t == "NCLT") return ScanFormat::Nclt;
+  return ScanFormat::Auto;
+}
+
+// Tell a KITTI float file from an NCLT raw file by CONTENT (the file size says nothing: an NCLT file with an
+// even number of records is a multiple of 16 bytes too).  KITTI: whole x y z i float quadruples, every coordinate
+// finite and within a kilometre, none of them a denormal / vanishing non-zero.  NCLT records read as floats pair
+// two u16 fields: (x | y << 16) has the exponent of y's top bits -- 5e8 for a point at y = 0 -- and
+// (z | (i | l << 8) << 16) is a denormal for label 0.  The first 256 points decide.
+inline bool looks_like_kitti(const std::string& path) {
+  std::ifstream f(path, std::ifstream::in | std::ifstream::binary);
+  if (!f.is_open()) return false;
+  f.seekg(0, std::ios::end);
+  const size_t bytes = (size_t)f.tellg();
+  f.seekg(0, std::ios::beg);
+  if (bytes == 0 || bytes % 16 != 0) return bytes == 0;
+  const size_t n = std::min<size_t>(bytes / 16, 256);
+  std::vector<float> v(4 * n);
+  f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(16 * n));
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float c = v[4 * i + a];
+      if (!std::isfinite(c) || std::fabs(c) > 1000.f || (c != 0.f && std::fabs(c) < 1e-20f)) return false;
+    }
+  return true;
+}
+
+// The reference's global_registration reads every scan with the NCLT reader (:1239,1304), its
+// global_localization with the KITTI one (global_localization.cpp:160-182); a drop-in for both takes the format
+// from the caller (trailing argument / GLOC_SCAN_FORMAT) and otherwise from the content.
+inline std::vector<float> read_lidar_any(const std::string& path, ScanFormat fmt = ScanFormat::Auto) {
+  if (fmt == ScanFormat::Auto) fmt = looks_like_kitti(path) ? ScanFormat::Kitti : ScanFormat::Nclt;
+  return fmt == ScanFormat::Kitti ? read_lidar_kitti(path) : read_lidar_nclt(path);
 }
 
 // Descriptor file standing in for MODEL: "GLOCDESC" u32 n u32 dim, then n*dim float32

@@ -2,7 +2,8 @@
 
 valset  registration/global_localization.cpp:64-122; writers dataset/kitti_i2i.py:82-104
 poses   registration/global_localization.cpp:124-156; writer dataset/kitti_i2i.py:108-120
-scans   KITTI .bin float32 x y z i (global_localization.cpp:160-182)
+scans   KITTI .bin float32 x y z i (global_localization.cpp:160-182);
+        NCLT raw u16 x y z, u8 intensity, label (global_registration.cpp:181-209)
 """
 import struct
 
@@ -92,3 +93,63 @@ def read_descriptors(path):
         assert f.read(8) == b"GLOCDESC"
         n, dim = struct.unpack("<II", f.read(8))
         return np.fromfile(f, np.float32, n * dim).reshape(n, dim)
+
+
+# ---- scans ------------------------------------------------------------------------------------
+
+def write_lidar_nclt(path, xyz, intensity=None, label=None):
+    """NCLT velodyne_sync records: u16 x, y, z = round((metres + 100) / 0.005), u8 intensity, u8 label."""
+    p = np.asarray(xyz, np.float64)[:, :3]
+    rec = np.zeros(p.shape[0], dtype=[("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("i", "u1"), ("l", "u1")])
+    q = np.clip(np.rint((p + 100.0) / 0.005), 0, 65535).astype(np.uint16)
+    rec["x"], rec["y"], rec["z"] = q[:, 0], q[:, 1], q[:, 2]
+    if intensity is not None:
+        rec["i"] = np.asarray(intensity, np.uint8)
+    if label is not None:
+        rec["l"] = np.asarray(label, np.uint8)
+    rec.tofile(path)
+
+
+def read_lidar_nclt(path):
+    """float32 [n + 1, 4] (x, y, z, intensity) of an n-record NCLT file -- n + 1: the reference's reader tests
+    eof() before it reads (global_registration.cpp:191-192), so the last record is pushed twice; the bytes of a
+    truncated trailing record overwrite the leading fields of that extra point.  Empty file: empty cloud."""
+    raw = np.fromfile(path, np.uint8)
+    if raw.size == 0:
+        return np.zeros((0, 4), np.float32)
+    n = raw.size // 8
+    recs = raw[:8 * n].reshape(n, 8)
+    last = recs[-1].copy() if n else np.zeros(8, np.uint8)
+    last[:raw.size - 8 * n] = raw[8 * n:]
+    recs = np.concatenate([recs, last[None]])
+    v = np.ascontiguousarray(recs[:, :6]).view("<u2").astype(np.float32)
+    out = np.empty((recs.shape[0], 4), np.float32)
+    out[:, :3] = v * np.float32(0.005) + np.float32(-100.0)
+    out[:, 3] = recs[:, 6].astype(np.float32)
+    return out
+
+
+def read_lidar_kitti(path):
+    raw = np.fromfile(path, np.float32)
+    return raw[:raw.size - raw.size % 4].reshape(-1, 4)
+
+
+def looks_like_kitti(path):
+    """Content sniff (never the file size: an NCLT file with an even record count is a multiple of 16 bytes
+    too): the first 256 float quadruples are finite, within a kilometre and not denormal -- NCLT records read as
+    floats are ~5e8 (x | y << 16) or denormals (z | intensity << 16)."""
+    import os
+    size = os.path.getsize(path)
+    if size == 0 or size % 16:
+        return size == 0
+    v = np.fromfile(path, np.float32, 4 * min(size // 16, 256)).reshape(-1, 4)[:, :3]
+    with np.errstate(invalid="ignore"):
+        bad = ~np.isfinite(v) | (np.abs(v) > 1000.0) | ((v != 0) & (np.abs(v) < 1e-20))
+    return not bool(bad.any())
+
+
+def read_lidar_any(path, fmt="auto"):
+    """fmt: 'kitti', 'nclt' or 'auto' (by content)."""
+    if fmt == "auto":
+        fmt = "kitti" if looks_like_kitti(path) else "nclt"
+    return read_lidar_kitti(path) if fmt == "kitti" else read_lidar_nclt(path)

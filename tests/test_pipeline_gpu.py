@@ -104,6 +104,28 @@ def test_command_lines(dataset):
     errs = re.findall(r"err_pos, err_rot: ([\d.eE+-]+), ([\d.eE+-]+)", out)
     assert len(errs) == 3 * N_Q
     assert float(re.search(r"Success rate: ([\d.eE+-]+)", out).group(1)) > 0.9
+    # the same drive as NCLT raw records (what the reference's global_registration reads, :1239,1304), every file
+    # with an EVEN record count (a multiple of 16 bytes, which round 2 mistook for KITTI floats): format by content,
+    # and named explicitly
+    from gloc3d_amd import gloc_io, synth
+    nd = d / "nclt"
+    nd.mkdir(exist_ok=True)
+    def as_nclt(path):
+        s_ = synth.read_kitti_bin(path)
+        s_ = s_[:len(s_) - len(s_) % 2]
+        out_ = str(nd / os.path.basename(path))
+        gloc_io.write_lidar_nclt(out_, s_[:, :3], intensity=(s_[:, 3] * 255).astype(np.uint8))
+        assert os.path.getsize(out_) % 16 == 0
+        return out_
+    gloc_io.write_valset(nd / "valset.txt", [as_nclt(f) for f in dataset["files"]], [as_nclt(f) for f in dataset["qfiles"]],
+                         dataset["positives"])
+    for extra in ([], ["nclt"]):
+        out_n = _run([os.path.join(bindir, "global_registration"), str(nd / "valset.txt"), str(d / "poses.txt")] + extra, cwd=d)
+        errs_n = re.findall(r"err_pos, err_rot: ([\d.eE+-]+), ([\d.eE+-]+)", out_n)
+        assert len(errs_n) == 3 * N_Q
+        assert float(re.search(r"Success rate: ([\d.eE+-]+)", out_n).group(1)) > 0.9
+        # 5 mm quantisation + one repeated point per scan: the same poses to a few millimetres
+        assert max(abs(float(a[0]) - float(b[0])) for a, b in zip(errs, errs_n)) < 0.05
     # sharded mode below the C ABI (gloc_comm_* + gloc_knn_search_sharded), on the one GPU of this box: a
     # communicator of one rank, the collective path end to end, the same report
     env = dict(os.environ, GLOC_WORLD="1", GLOC_RANK="0", GLOC_COMM_ID_FILE=str(d / "comm.id"))

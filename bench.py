@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- localization queries/sec (kNN + top-20 registration) on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launches its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One STEP = one batch of `--batch` (default 25) localization queries per GPU through the hot path, as
@@ -21,15 +21,29 @@ N > 1  the same database, interleave-sharded over the N ranks; a step handles N 
        and merged on every rank; rank r then registers its B queries against its replica of the scan
        store, and the result tables are all-gathered.  Per-GPU work is fixed as N grows ("weak").
        --places 1000000 gives BASELINE.json configs[4]'s sharded database; --mode latency shards ONE
-       query's candidates over the ranks instead.
+       query's candidates over the ranks instead.  Without torchrun's environment `--gpus N` starts the N
+       ranks itself (a child `python -m torch.distributed.run`, before anything here touches the GPU).
 
-Prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel (K4 point-NN, HIP-event
-timed inside the timed region on the one stream it runs on) and the `cpu_baseline` object (the CPU
-checker timed on this box's host cores, rank 0, N = 1 only, bounded sample).
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   the metric;
+  accuracy              recall@1/5/10/20, registration success rate, position / rotation error of the stream
+                        against its constructed ground truth, exactly as the reference's evaluator defines
+                        them (registration/global_localization.cpp:221-268, 270-335); the run FAILS (exit 3)
+                        when the success rate falls below --min-success;
+  roofline              the dominant kernel (K4 point-NN), HIP-event timed inside the timed region;
+  legs                  (N = 1) the same pipeline with each work-reducing choice switched off, and on harder
+                        data: all 3000 RANSAC hypotheses scored; the brute-force 1-NN kernel; candidate poses
+                        drawn as SURVEY cfg C writes them; candidates 5-20 m away;
+  sub_records           (N = 1) BASELINE configs[1] (kNN 64 x 10k x 4096), configs[2] (one query alone incl.
+                        its preparation), one shard of configs[4] (kNN over 125k x 4096);
+  cpu_baseline          the CPU checker on this box's host cores: ONE WHOLE query (kNN + its 20 candidates),
+                        not an extrapolation; its 20 results also check the timed 500-job launch's rows.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -45,6 +59,7 @@ N_PLACES_1GPU = 4541          # KITTI odometry 00 (dataset/kitti_i2i.py:46 of th
 POOL_A = 24                   # ray-cast views of world A along a short drive (0.2 m / 0.5 deg apart)
 POOL_B = 6                    # ray-cast views of a different world (the negatives)
 QUERY_VIEWS = 8               # ray-cast query views of world A, each next to pool view 3 * v + 1
+FAR_VIEWS = 10                # world-A views 5-20 m from the query views (the "far" data-sensitivity leg)
 NEG_EVERY = 4                 # place g carries a world-B scan iff g % 4 == 1 -> 5 of 20 consecutive places
 RANSAC_ITERS = 3000           # registration/loop_detector.cpp:257 (cap; adaptive stop at the
                               # reference's OpenCV default confidence 0.99, see gloc_reg_params)
@@ -53,11 +68,15 @@ MIN_INLIER_RATIO = 0.3        # the library default (ok iff RANSAC inliers >= ra
 MAX_RMSE = 1.0                # ... and the final RMS nearest-neighbour distance <= 1 m: both worlds share a
                               # ground plane, so a different-world candidate still has ~0.83 inliers at 0.6 m
                               # (positives 0.86-0.92) but ends at an rmse of 2.1-2.5 m (positives 0.17-0.7)
+POSITIVE_RADIUS_M = 5.0       # SURVEY 8d cfg D: ground-truth positives = places within 5 m (dataset/kitti_i2i.py:94-95)
 DB_SEED = 4001
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 PEAK_FP32_TFLOPS = 157.3
 FLOP_PER_PAIR = 8             # 3 sub + 3 mul + 2 add per (source, target) pair
 BYTES_PER_POINT_INDEXED = 16  # sorted float4 (x, y, z, original index)
+KNN_CFGB = (64, 10000)        # BASELINE.json configs[1]
+KNN_SHARD_ROWS = 125000       # one of the 8 shards of configs[4]
+PMC_FILES = ("r03_pmc_traffic_nn_compact.json", "r02_pmc_traffic_nn_compact.json")
 
 
 def log(msg):
@@ -65,9 +84,34 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+# ---- the synthetic world: poses are known, so every query has a ground truth ----------------------------
+
 def pool_pose(s):
     from gloc3d_amd import synth
     return synth.se3(0.5 * (s - POOL_A / 2), (0.2 * s, 0.04 * s, 0.0))
+
+
+def query_view_pose(v):
+    from gloc3d_amd import synth
+    return pool_pose(3 * v + 1) @ synth.se3(1.5, (0.3, -0.2, 0.02))
+
+
+def far_view_poses(world):
+    """World-A sensor poses 5-20 m from every query view (which sit at x = 0.2 .. 4.4 m), some turned by up to
+    25 degrees: low-overlap candidates.  Positions inside (or within 1.5 m of) a box of the scene are skipped."""
+    from gloc3d_amd import synth
+    out = []
+    cands = [(-5.5, 0), (10.0, 0), (-8.0, 12), (12.5, -10), (-11.0, 0), (15.0, 20), (-14.0, -25), (18.0, 0),
+             (-6.5, 8), (11.0, 5), (-9.5, -15), (14.0, 0), (-12.5, 10), (16.5, -5), (-16.0, 0), (20.0, 12)]
+    lo, hi = world["lo"], world["hi"]
+    for x, yaw in cands:
+        p = np.array([x, 0.2 * x, 0.0])
+        inside = ((p[:2] > lo[:, :2] - 1.5) & (p[:2] < hi[:, :2] + 1.5)).all(axis=1).any()
+        if not inside:
+            out.append(synth.se3(yaw, tuple(p)))
+        if len(out) == FAR_VIEWS:
+            break
+    return out
 
 
 def _cast_view(job):
@@ -78,22 +122,48 @@ def _cast_view(job):
 
 def build_views(cache=None):
     """Ray-cast the few base views on the host (numpy, a process per view; called BEFORE anything
-    touches the GPU): world A pool, world B pool, query views.  `cache`: an .npz to load them from /
-    save them to (profiling runs: rocprofv3 and forked workers do not mix)."""
+    touches the GPU): world A pool, world B pool, query views, far views.  `cache`: an .npz to load them
+    from / save them to (profiling runs: rocprofv3 and forked workers do not mix)."""
     from concurrent.futures import ProcessPoolExecutor
     from gloc3d_amd import synth
+    far_poses = far_view_poses(synth.make_world(1001))
+    n_all = POOL_A + POOL_B + QUERY_VIEWS + len(far_poses)
+
+    def split(views):
+        a, b = POOL_A, POOL_A + POOL_B
+        return views[:a], views[a:b], views[b:b + QUERY_VIEWS], views[b + QUERY_VIEWS:], far_poses
+
     if cache and os.path.exists(cache):
         z = np.load(cache)
-        views = [z[f"v{i}"] for i in range(POOL_A + POOL_B + QUERY_VIEWS)]
-        return views[:POOL_A], views[POOL_A:POOL_A + POOL_B], views[POOL_A + POOL_B:]
+        if len(z.files) == n_all:
+            return split([z[f"v{i}"] for i in range(n_all)])
     jobs = [(1001, pool_pose(s), 3000 + s) for s in range(POOL_A)]
     jobs += [(2002, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), 5000 + s) for s in range(POOL_B)]
-    jobs += [(1001, pool_pose(3 * v + 1) @ synth.se3(1.5, (0.3, -0.2, 0.02)), 9000 + v) for v in range(QUERY_VIEWS)]
+    jobs += [(1001, query_view_pose(v), 9000 + v) for v in range(QUERY_VIEWS)]
+    jobs += [(1001, T, 9500 + i) for i, T in enumerate(far_poses)]
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         views = list(ex.map(_cast_view, jobs))
     if cache:
-        np.savez(cache, **{f"v{i}": v for i, v in enumerate(views)})
-    return views[:POOL_A], views[POOL_A:POOL_A + POOL_B], views[POOL_A + POOL_B:]
+        tmp = f"{cache}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            np.savez(f, **{f"v{i}": v for i, v in enumerate(views)})
+        os.replace(tmp, cache)      # atomic: a rank waiting for the file never sees half of it
+    return split(views)
+
+
+def build_views_ranked(args):
+    """Under torchrun every rank needs the same base views: local rank 0 casts them once and the others load
+    its file (N ranks x 16 forked workers would only fight for the host cores)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.views_cache or world == 1:
+        return build_views(args.views_cache), None
+    shared = os.path.join("/tmp", f"gloc3d_bench_views_{os.getppid()}.npz")
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        return build_views(shared), shared
+    t0 = time.time()
+    while not os.path.exists(shared) and time.time() - t0 < 600:
+        time.sleep(0.2)
+    return build_views(shared if os.path.exists(shared) else None), None
 
 
 def place_perturbation(g):
@@ -105,47 +175,138 @@ def place_perturbation(g):
     return synth.se3(2.0 * u[0], (0.3 * u[1], 0.3 * u[2], 0.03 * u[3]))
 
 
-def cpu_baseline(sample, n_places, min_inlier_ratio, gpu_check=None):
-    """The CPU checker on this host: kNN of one query + full registration of candidates of that query
-    (one positive, one negative), extrapolated to the 15 + 5 of a query; 1 thread (the reference's kNN
-    and registration are single-threaded) and all cores (candidates over threads)."""
+def cfgc_perturbation(g):
+    """SURVEY 8d cfg C: candidate re-cast from yaw U(-10, 10) deg, t U(-2, 2)^2 x U(-0.2, 0.2)."""
+    from gloc3d_amd import synth
+    key = synth.rng_key(DB_SEED ^ 0xCF6C, np.uint64(g))
+    u = synth.rng_uniform(key, np.arange(4, dtype=np.uint64)).astype(np.float64) * 2 - 1
+    return synth.se3(10.0 * u[0], (2.0 * u[1], 2.0 * u[2], 0.2 * u[3]))
+
+
+def query_perturbation(j):
+    from gloc3d_amd import synth
+    key = synth.rng_key(DB_SEED ^ 0x9E77, np.uint64(j))
+    u = synth.rng_uniform(key, np.arange(4, dtype=np.uint64)).astype(np.float64) * 2 - 1
+    return synth.se3(1.0 * u[0], (0.2 * u[1], 0.2 * u[2], 0.02 * u[3]))
+
+
+FAR_AWAY = None
+
+
+def far_away_pose():
+    """The 'pose' of a different-world place in world A's frame: nowhere near -- selecting it is a failure."""
+    global FAR_AWAY
+    if FAR_AWAY is None:
+        from gloc3d_amd import synth
+        FAR_AWAY = synth.se3(0.0, (1.0e4, 1.0e4, 0.0))
+    return FAR_AWAY
+
+
+def accuracy_of(cands, sels, tables, q_ids, place_pose, query_pose, is_positive_place, recall_defined=True):
+    """The reference evaluator's report for a stream (host mirror gloc3d_amd/loop_detector.py of
+    GlocEvaluator::recognition_recalls / registration_recalls, global_localization.cpp:221-268, 270-335):
+    cands [Q, k] retrieved place ids, sels [Q] selected retrieval rank (-1: none), tables [Q, k, 19]."""
+    from gloc3d_amd import loop_detector as ld
+    Q = len(q_ids)
+    qpos = [query_pose(j)[:3, 3] for j in q_ids]
+    gt_pos = []
+    for qi in range(Q):     # ground-truth positives: the retrieved or not, every same-world place within 5 m
+        gt_pos.append([int(g) for g in cands[qi] if g >= 0 and is_positive_place(int(g)) and
+                       np.linalg.norm(place_pose(int(g))[:3, 3] - qpos[qi]) < POSITIVE_RADIUS_M])
+    # (positives outside the retrieved list cannot change a first-hit recall: a hit needs a retrieved place)
+    # a query whose retrieved list holds no positive is still a VALID query (the database has ~3400 places within
+    # 5 m of it): it counts as a miss, not as "no ground truth" (which the reference skips, :226)
+    rec, failed_detect = ld.recognition_recalls(cands, [p if p else [-2] for p in gt_pos])
+    if not recall_defined:
+        rec, failed_detect = [None] * 4, []
+    er_all, ep_all, located = [], [], 0
+    ok_rot, ok_pos = [], []
+    for qi in range(Q):
+        r = int(sels[qi])
+        if r < 0:
+            continue
+        located += 1
+        g = int(cands[qi][r])
+        T = np.asarray(tables[qi][r][:16], np.float32).reshape(4, 4)
+        q2db = np.linalg.inv(place_pose(g)) @ query_pose(q_ids[qi])
+        er, ep = ld.pose_error(q2db, T)
+        er_all.append(er)
+        ep_all.append(ep)
+        if ep < 1.0 and er < 5.0:
+            ok_rot.append(er)
+            ok_pos.append(ep)
+
+    def mean_std(v):    # caculate_mean_std: n - 1 in the denominator (global_localization.cpp:185-196)
+        if len(v) < 2:
+            return (float(v[0]) if v else 0.0), 0.0
+        return float(np.mean(v)), float(np.std(v, ddof=1))
+    pm, ps = mean_std(ok_pos)
+    rm, rs = mean_std(ok_rot)
+    f_ = lambda v: None if v is None else float(v)
+    return {"queries": Q, "recall_at_1": f_(rec[0]), "recall_at_5": f_(rec[1]), "recall_at_10": f_(rec[2]),
+            "recall_at_20": f_(rec[3]), "failed_detect": len(failed_detect),
+            "success_rate": len(ok_pos) / Q if Q else 0.0, "succeeded": len(ok_pos), "located": located,
+            "not_located": Q - located, "pos_err_mean_m": pm, "pos_err_std_m": ps, "rot_err_mean_deg": rm,
+            "rot_err_std_deg": rs, "pos_err_max_m_located": float(max(ep_all)) if ep_all else 0.0,
+            "definition": "recall@N: first hit among the top N (global_localization.cpp:221-268), positives = same-world "
+                          f"places within {POSITIVE_RADIUS_M:g} m; success: err_pos < 1 m and err_rot < 5 deg against "
+                          "pose_db^-1 pose_q, mean / std (n - 1) over the successes (:270-335)"}
+
+
+# ---- the CPU checker: one whole query ---------------------------------------------------------------------
+
+def cpu_baseline(q_scan, cand_scans, n_places, min_inlier_ratio, gpu_rows=None):
+    """The CPU checker on this host, ONE WHOLE QUERY of the stream (no extrapolation): top-20 over the
+    descriptor database + full registration of its 20 retrieved candidates (15 same-world, 5 different-world),
+    on one thread (the reference's kNN and registration are single-threaded) and on all cores (candidates over
+    threads).  With oracle/_ref present both searches are the reference's own vendored nanoflann kd-trees.
+    gpu_rows: the 20 result rows the TIMED 500-job launch produced for this query -- checked against it."""
     import oracle
     from gloc3d_amd import synth
     oracle.build(ref=False)
+    use_ref = oracle.have_ref()
     db = synth.descriptors_traj(DB_SEED, 0, n_places, DIM)
     q = synth.queries_near(DB_SEED, [1234], DIM)
-    t0 = time.time()
-    oracle.knn_search(db, q, TOP_K)
-    t_knn = time.time() - t0
-    qscan, pos, neg = sample["query"], sample["positive"], sample["negative"]
+    t_build = 0.0
+    if use_ref:
+        R = oracle.ref()
+        t0 = time.time()
+        tree = R.ref_knn_build(db, db.shape[0], db.shape[1])          # once per database, not per query
+        t_build = time.time() - t0
+        idx, d2 = np.empty((1, TOP_K), np.uint64), np.empty((1, TOP_K), np.float32)
+        t0 = time.time()
+        R.ref_knn_query(tree, q, 1, TOP_K, idx, d2)
+        t_knn = time.time() - t0
+        R.ref_knn_free(tree)
+    else:
+        t0 = time.time()
+        oracle.knn_search(db, q, TOP_K)
+        t_knn = time.time() - t0
     kw = dict(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS, min_inlier_ratio=min_inlier_ratio, max_rmse=MAX_RMSE)
-    use_ref = oracle.have_ref()
     t0 = time.time()
-    o_pos = oracle.reg_one(qscan, pos, cand_id=0, ref_nn=use_ref, **kw)
-    t_pos = time.time() - t0
-    t0 = time.time()
-    o_neg = oracle.reg_one(qscan, neg, cand_id=1, ref_nn=use_ref, **kw)
-    t_neg = time.time() - t0
-    n_neg = TOP_K // NEG_EVERY
-    per_query = t_knn + (TOP_K - n_neg) * t_pos + n_neg * t_neg
+    res = [oracle.reg_one(q_scan, c, cand_id=i, ref_nn=use_ref, **kw) for i, c in enumerate(cand_scans)]
+    t_reg = time.time() - t0
+    per_query = t_knn + t_reg
     extra = {}
-    if gpu_check is not None:
-        # the oracle as the checker: the same two full-size registrations through the HIP path
-        g = gpu_check(qscan, [pos, neg])
-        extra["full_size_parity"] = {
-            "pose_max_abs_diff": float(max(np.abs(g["T"][0] - o_pos["T"]).max(), np.abs(g["T"][1] - o_neg["T"]).max())),
-            "inliers_equal": bool(g["inliers"][0] == o_pos["inliers"] and g["inliers"][1] == o_neg["inliers"]),
-            "ok_equal": bool(g["ok"][0] == o_pos["ok"] and g["ok"][1] == o_neg["ok"]),
-            "ok_positive_negative": [bool(o_pos["ok"]), bool(o_neg["ok"])],
-            "inlier_ratio_positive_negative": [float(o_pos["inliers"]) / len(qscan), float(o_neg["inliers"]) / len(qscan)]}
-    # all cores: the candidates of a query over threads (the per-candidate work is independent)
+    if gpu_rows is not None:
+        T = np.stack([r["T"] for r in res])
+        g_T = np.asarray(gpu_rows[:, :16], np.float32).reshape(-1, 4, 4)
+        extra["timed_launch_parity"] = {
+            "what": f"rows of query 0 in the LAST timed repetition's first {len(cand_scans)}-candidate batch "
+                    "(one gloc_reg_batch_multi of all queries in flight) against the CPU checker, candidate by candidate",
+            "candidates": len(cand_scans),
+            "pose_max_abs_diff": float(np.abs(g_T - T).max()),
+            "inliers_equal": bool(all(int(gpu_rows[c, 17]) == int(res[c]["inliers"]) for c in range(len(res)))),
+            "ok_equal": bool(all(bool(gpu_rows[c, 18] > 0.5) == bool(res[c]["ok"]) for c in range(len(res)))),
+            "rmse_max_abs_diff": float(max(abs(float(gpu_rows[c, 16]) - res[c]["rmse"]) for c in range(len(res)))),
+            "ok": [bool(r["ok"]) for r in res],
+            "inlier_ratio": [round(float(r["inliers"]) / len(q_scan), 4) for r in res]}
     cores = os.cpu_count() or 1
-    nthr = min(cores, TOP_K)
+    nthr = min(cores, len(cand_scans))
     t0 = time.time()
-    oracle.reg_many_mt(qscan, [pos] * (nthr - nthr // NEG_EVERY) + [neg] * (nthr // NEG_EVERY), nthr,
-                       ref_nn=use_ref, **kw)
-    t_mt = time.time() - t0           # nthr candidates in parallel
-    per_query_mt = t_knn + t_mt * (TOP_K / nthr)
+    oracle.reg_many_mt(q_scan, cand_scans, nthr, ref_nn=use_ref, cand_ids=np.arange(len(cand_scans), dtype=np.uint32), **kw)
+    t_mt = time.time() - t0
+    per_query_mt = t_knn + t_mt
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -155,16 +316,33 @@ def cpu_baseline(sample, n_places, min_inlier_ratio, gpu_check=None):
     except OSError:
         pass
     return {**extra, "value": 1.0 / per_query, "unit": "queries/s", "cores": 1,
-            "kind": "reference" if use_ref else "port",
-            "nn_search": ("the reference's vendored nanoflann kd-tree (oracle/_ref), built once per candidate, "
-                          "queried every pass -- as PCL's ICP does") if use_ref else "the port's uniform grid",
-            "sample": f"1 query: kNN over {n_places}x{DIM} ({t_knn*1e3:.0f} ms) + RANSAC{RANSAC_ITERS}+ICP{ICP_ITERS} "
-                      f"registration of 1 positive ({t_pos:.1f} s) and 1 negative ({t_neg:.1f} s) candidate, "
-                      f"~123k-pt scans, extrapolated to {TOP_K - n_neg} + {n_neg} candidates",
+            "kind": "reference" if use_ref else "port", "extrapolated": False,
+            "nn_search": ("the reference's vendored nanoflann kd-trees (oracle/_ref): descriptors -- InvKeyTree, built once "
+                          f"({t_build*1e3:.0f} ms, not counted), queried per query; 3-D points -- built once per candidate, "
+                          "queried every pass, as PCL's ICP does") if use_ref else "the port's brute force / uniform grid",
+            "sample": f"1 whole query: kNN over {n_places}x{DIM} ({t_knn*1e3:.1f} ms) + RANSAC{RANSAC_ITERS}+ICP{ICP_ITERS} "
+                      f"registration of its {len(cand_scans)} retrieved candidates ({t_reg:.1f} s), ~123k-pt scans, measured, "
+                      "not extrapolated",
             "all_cores": {"value": 1.0 / per_query_mt, "threads": nthr,
-                          "sample": f"{nthr} candidates registered concurrently ({t_mt:.1f} s), scaled to {TOP_K}"},
+                          "sample": f"the same query, its {len(cand_scans)} candidates on {nthr} threads ({t_mt:.1f} s)"},
             "host_cpus": cores, "cpu_model": cpu_model,
             "compiler_flags": "gcc -O2 -ffp-contract=off (port), g++ -O3 -DNDEBUG -std=c++14 -ffp-contract=off (reference nanoflann)"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks as a CHILD process tree
+    (nothing here has touched the GPU, torch is not imported: no exec of a GPU-initialised process), pass its
+    output through and leave with its return code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -182,7 +360,7 @@ def main():
                          "with its candidates sharded over the ranks (strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--collectives", choices=["capi", "torch"], default="capi",
-                    help="N > 1: the two all-gathers through the C ABI's own RCCL communicator "
+                    help="N > 1: the all-gathers through the C ABI's own RCCL communicator "
                          "(gloc_knn_search_sharded, gloc_comm_all_gather_device) or through torch.distributed")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
@@ -194,22 +372,29 @@ def main():
                          "default configuration")
     ap.add_argument("--scan-store", type=int, default=0,
                     help="distinct resident scans (0 = one per place up to 4541; places beyond alias modulo)")
-    ap.add_argument("--no-lone-query", action="store_true", help="skip the one-query-alone launches after the timed region (profiling runs)")
+    ap.add_argument("--no-legs", "--no-lone-query", dest="no_legs", action="store_true",
+                    help="skip everything after the timed region but the CPU baseline: legs and sub-records (profiling runs)")
+    ap.add_argument("--leg-steps", type=int, default=4, help="steps of each leg (x --batch queries)")
     ap.add_argument("--views-cache", default=None, help="npz cache of the ray-cast base views (profiling runs)")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-job-group", type=int, default=0, help="culled 1-NN tuning: jobs interleaved in the launch order")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
                     help="1-NN search of the registration (identical results)")
+    ap.add_argument("--ransac-confidence", type=float, default=None,
+                    help="override gloc_reg_params.ransac_confidence (0: score all 3000 hypotheses)")
+    ap.add_argument("--min-success", type=float, default=0.95,
+                    help="the run fails (exit code 3) when the stream's registration success rate is below this")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        log(f"note: WORLD_SIZE = {world} but --gpus {args.gpus}: running with the {world} ranks that exist")
     t_setup = time.time()
-    pool_a, pool_b, qviews = build_views(args.views_cache)   # forks worker processes: before the GPU is initialised
+    (pool_a, pool_b, qviews, far_views, far_poses), shared_views = build_views_ranked(args)   # forks: before the GPU is initialised
     import torch
     import torch.distributed as dist
     from gloc3d_amd import capi, sharded, synth
@@ -260,6 +445,22 @@ def main():
         f"{live_b / 2**30:.1f} GiB, ~{mean_pts:.0f} pts each; negatives: places g % {NEG_EVERY} == 1"
         if neg_on else f"scan store: {n_store} distinct resident scans, {live_b / 2**30:.1f} GiB, no negatives")
 
+    # ground truth: the sensor pose of a place's scan.  A variant moves the POINTS by P in the sensor frame
+    # (p' = P p), i.e. it is the view of a sensor at W_view P^-1
+    scan_override = {}          # place -> (scan id, pose) while a data-sensitivity leg runs
+    pose_cache = {}
+
+    def place_pose(g):
+        g = int(g) % n_store
+        if g in scan_override:
+            return scan_override[g][1]
+        if g not in pose_cache:
+            pose_cache[g] = far_away_pose() if is_negative(g) else pool_pose(g % POOL_A) @ np.linalg.inv(place_perturbation(g))
+        return pose_cache[g]
+
+    def query_pose(j):
+        return query_view_pose(int(j) % QUERY_VIEWS) @ np.linalg.inv(query_perturbation(int(j)))
+
     # ---- the query stream: distinct host-side scans + descriptors -------------------------------
     n_stream = n_steps * per_step                       # distinct queries of one repetition
     total = (n_steps + n_warm) * per_step
@@ -274,10 +475,7 @@ def main():
     qbase = [store.add(v) for v in qviews]
     q_scan_host = []
     for j in range(total):
-        key = synth.rng_key(DB_SEED ^ 0x9E77, np.uint64(j))
-        u = synth.rng_uniform(key, np.arange(4, dtype=np.uint64)).astype(np.float64) * 2 - 1
-        sid = store.add_variant(qbase[int(q_view[j])], synth.se3(1.0 * u[0], (0.2 * u[1], 0.2 * u[2], 0.02 * u[3])),
-                                0.01, seed=880000 + j)
+        sid = store.add_variant(qbase[int(q_view[j])], query_perturbation(j), 0.01, seed=880000 + j)
         h = torch.from_numpy(store.download(sid)).pin_memory()
         store.release(sid)
         q_scan_host.append(h)
@@ -294,8 +492,11 @@ def main():
         reg.set_option(capi.REG_OPT_NN_JOB_GROUP, args.nn_job_group)
     params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS,
                                      min_inlier_ratio=MIN_INLIER_RATIO, max_rmse=MAX_RMSE)
+    if args.ransac_confidence is not None:
+        params.ransac_confidence = args.ransac_confidence
+    cur = {"params": params}       # (legs swap the parameters / the mode)
 
-    capi_knn, collectives = None, "none"
+    capi_knn, collectives, rccl_ranks_seen = None, "none", None
     if world > 1 and args.collectives == "capi" and args.backend == "nccl" and not args.same_device:
         try:
             comm = capi.Comm(local_rank, rank, world, sharded.torch_exchange(dev))
@@ -305,6 +506,7 @@ def main():
             torch.cuda.synchronize()
             if not (got[:, 0, 0].cpu() == torch.arange(world, dtype=torch.float32)).all():
                 raise RuntimeError("all-gather self-test returned the wrong rows")
+            rccl_ranks_seen = comm.rank_world()[1]      # gloc_comm_rank: what the communicator itself reports
             collectives = "capi (gloc_knn_search_sharded + gloc_comm_all_gather_device, RCCL)"
         except Exception as e:   # loud, and recorded in the JSON line: never a silent change of path
             capi_knn = None
@@ -314,6 +516,7 @@ def main():
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)     # all ranks take the same path
         if int(ok_all.item()) == 0:
             capi_knn = None
+            rccl_ranks_seen = None
     if capi_knn is not None:
         knn = capi_knn
     else:
@@ -348,6 +551,12 @@ def main():
         """global place ids [.., n] (-1 = none) -> resident scan ids (every rank holds all scans)."""
         p = np.asarray(places, np.int64)
         out = place_scan[np.clip(p, 0, None) % n_store].astype(np.uint32)
+        if scan_override:
+            flat, pf = out.reshape(-1), (np.clip(p, 0, None) % n_store).reshape(-1)
+            for i_, g_ in enumerate(pf):
+                o = scan_override.get(int(g_))
+                if o is not None:
+                    flat[i_] = o[0]
         out[p < 0] = capi.NO_SCAN
         return out
 
@@ -357,7 +566,7 @@ def main():
         init = coarse_init(q_ids, places) if cm is not None else None
         if fs_state["on"]:
             # the reference's loop as written: stop at the first success (gloc_reg_first_success_multi)
-            f = reg.first_success_multi(q_ids, scans_of(places), params=params, init_T=init)
+            f = reg.first_success_multi(q_ids, scans_of(places), params=cur["params"], init_T=init)
             shape = np.asarray(places).shape
             out = np.zeros(shape + (sharded.RESULT_COLS,), np.float32)
             for k_, rk in enumerate(f["rank"]):
@@ -367,46 +576,49 @@ def main():
             fs_state["jobs"] += f["jobs_run"]
             fs_state["queries"] += len(q_ids)
             return out
-        r = reg.batch_multi(q_ids, scans_of(places), params=params, init_T=init)
+        r = reg.batch_multi(q_ids, scans_of(places), params=cur["params"], init_T=init)
         return sharded.pack_results(r, np.asarray(places).shape)
 
     def local_register(q_id, local_rows, ranks):   # latency mode: this rank's share of one query's candidates
         g = np.asarray(local_rows, np.int64) * world + rank
-        r = reg.batch_ids(q_id, scans_of(g), params=params, stream_ids=ranks)
+        r = reg.batch_ids(q_id, scans_of(g), params=cur["params"], stream_ids=ranks)
         return sharded.pack_results(r, (len(g),))
 
-    sreg = sharded.ShardedRegistrar(rank, world, local_register, comm_device=comm_dev)
+    sreg = sharded.ShardedRegistrar(rank, world, local_register, comm_device=comm_dev,
+                                    gather=capi_knn.all_gather_tables if capi_knn is not None else None)
     qreg = sharded.QueryParallelRegistrar(rank, world, None, comm_device=comm_dev)
     stage = {"prep_wait": 0.0, "h2d_index": 0.0, "knn": 0.0, "register": 0.0}
     work_pairs = []
 
     # ---- one step -----------------------------------------------------------------------------
-    def my_slice(i):
+    def my_slice(i, Bq=None):
+        Bq = B if Bq is None else Bq
         q0 = i * per_step
-        return (q0 + rank * B, q0 + rank * B + B) if args.mode == "throughput" else (q0, q0 + 1)
+        return (q0 + rank * Bq, q0 + rank * Bq + Bq) if args.mode == "throughput" else (q0, q0 + 1)
 
-    def prepare(i):
+    def prepare(i, Bq=None):
         """Query preparation of step i: this rank's fresh query scans go H2D and are indexed
         (gloc_scan_store_add, on the store's stream); the step's descriptors go H2D."""
         t0 = time.time()
-        a, b = my_slice(i)
+        a, b = my_slice(i, Bq)
         ids = [store.add(q_scan_host[j].numpy()) for j in range(a, b)]
         if cm is not None:
             with cm_lock:
                 for sid in ids:
                     cur_qgrids[sid] = cm.add_store_scan(store, sid)
         q0 = i * per_step
-        qd = q_desc_host[q0:q0 + per_step].to(dev, non_blocking=True)
+        n_q = per_step if Bq is None else Bq * (world if args.mode == "throughput" else 1)
+        qd = q_desc_host[q0:q0 + n_q].to(dev, non_blocking=True)
         return ids, qd, time.time() - t0
 
     class Prefetcher:
         def __init__(self):
             self.slot, self.th = None, None
 
-        def start(self, i):
+        def start(self, i, Bq=None):
             def run():
                 torch.cuda.set_device(local_rank)
-                self.slot = prepare(i)
+                self.slot = prepare(i, Bq)
             self.th = threading.Thread(target=run)
             self.th.start()
 
@@ -417,25 +629,27 @@ def main():
 
     pre = Prefetcher()
 
-    def step(i, last, record):
+    def step(i, last, record, Bq=None, prefetch=True):
+        """One step.  Bq: queries of this rank (legs use smaller batches); returns (cand, sel, tables)."""
         t0 = time.time()
-        if args.no_prefetch:
-            ids, qd, t_prep = prepare(i)
+        if args.no_prefetch or not prefetch:
+            ids, qd, t_prep = prepare(i, Bq)
         else:
             ids, qd, t_prep = pre.take()
             if not last:
-                pre.start(i + 1)          # the next step's uploads + indexing overlap this step's registration
+                pre.start(i + 1, Bq)      # the next step's uploads + indexing overlap this step's registration
         t1 = time.time()
         torch.cuda.current_stream().synchronize()   # the descriptors' H2D
         idx, d2 = knn.search(qd, TOP_K)
-        cand = idx.cpu().numpy()                          # [per_step, 20] global place ids, retrieval order
+        cand = idx.cpu().numpy()                          # [queries of the step, 20] global place ids, retrieval order
         t2 = time.time()
-        a, b = my_slice(i)
+        a, b = my_slice(i, Bq)
         if args.mode == "throughput":
             tables = qreg.register_many(ids, cand, dev, register_multi, capi_knn=capi_knn)   # [world*B, 20, 19]
             sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
         else:
             table = sreg.register(ids[0], cand[0], dev)
+            tables = table[None]
             sel = [sreg.select_first_ok(table)]
         for sid in ids:
             reg.scan_release(sid)
@@ -448,11 +662,12 @@ def main():
             stage["h2d_index"] += t_prep
             stage["knn"] += t2 - t1
             stage["register"] += t3 - t2
-            mine = cand[rank * B:(rank + 1) * B] if args.mode == "throughput" else cand[:1]
+            nb = b - a
+            mine = cand[rank * nb:(rank + 1) * nb] if args.mode == "throughput" else cand[:1]
             for k in range(mine.shape[0]):
                 nq = q_scan_host[a + k].shape[0] if args.mode == "throughput" else q_scan_host[a].shape[0]
                 work_pairs.append((nq, int(np.count_nonzero(mine[k] >= 0))))
-        return cand, sel
+        return cand, sel, tables
 
     def fence():
         torch.cuda.synchronize()
@@ -460,33 +675,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_stream(first, count, record=False, Bq=None, keep=False):
+        """`count` steps starting at `first`, fenced on both sides.  Returns (seconds, selections, [cand], [tables])."""
+        fence()
+        t0 = time.time()
+        if not args.no_prefetch:
+            pre.start(first, Bq)       # the first step's preparation has no earlier step to hide behind: paid in full
+        sels_, cands_, tabs_ = [], [], []
+        for i in range(first, first + count):
+            cand, sel, tables = step(i, i == first + count - 1, record, Bq)
+            sels_.extend(sel)
+            if keep:
+                cands_.append(cand)
+                tabs_.append(tables.detach().cpu().numpy())
+        fence()
+        return time.time() - t0, sels_, cands_, tabs_
+
     log(f"setup {time.time() - t_setup:.1f} s; warmup {n_warm}, timing {n_reps} x {n_steps} steps of {per_step} queries")
     if n_warm and not args.no_prefetch:
         pre.start(n_steps)
     for i in range(n_steps, n_steps + n_warm):     # warm-up queries: the tail of the stream
-        cand, sel = step(i, i == n_steps + n_warm - 1, False)
+        cand, sel, _ = step(i, i == n_steps + n_warm - 1, False)
         assert (cand[:, 0] == q_place[i * per_step:(i + 1) * per_step]).all(), "retrieval sanity: top-1 != query place"
-    rep_s, sels = [], []
+    rep_s, sels, cands_last, tabs_last = [], [], [], []
     for rep in range(n_reps):
-        fence()
         if rep == n_reps - 1:
+            fence()
             reg.profile_reset()
-        t0 = time.time()
-        if not args.no_prefetch:
-            pre.start(0)            # step 0's preparation has no earlier step to hide behind: it is paid in full
-        rsel = []
-        for i in range(n_steps):
-            cand, sel = step(i, i == n_steps - 1, rep == n_reps - 1)
-            rsel.extend(sel)
-        fence()
-        elapsed = time.time() - t0
+        elapsed, rsel, rc_, rt_ = run_stream(0, n_steps, record=rep == n_reps - 1, keep=rep == n_reps - 1)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev or dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         rep_s.append(elapsed)
-        sels = rsel
+        sels, cands_last, tabs_last = rsel, rc_, rt_
     elapsed = float(np.median(rep_s))
+
+    # ---- accuracy of the timed stream (the last repetition's results; every repetition computes the same) ----
+    all_cand = np.concatenate(cands_last) if cands_last else np.zeros((0, TOP_K), np.int64)
+    all_tabs = np.concatenate(tabs_last) if tabs_last else np.zeros((0, TOP_K, sharded.RESULT_COLS), np.float32)
+    stream_q = list(range(all_cand.shape[0]))
+    accuracy = accuracy_of(all_cand, sels, all_tabs, stream_q, place_pose, query_pose, lambda g: not is_negative(g % n_store))
 
     # ---- roofline of the dominant kernel (K4 point-NN), from the HIP events of the last repetition --
     nn_ms, nn_launches = reg.profile("nn")
@@ -504,15 +733,15 @@ def main():
     eval_pairs = all_pairs if args.nn_mode == "exhaustive" else float(pairs_eval) / max(nn_launches, 1)
     kname = "gloc::reg::nn_kernel" if args.nn_mode == "exhaustive" else "gloc::reg::nn_compact_kernel"
     traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), same workload
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_nn_compact.json")
+    pmc = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
     issue_model = None
-    if args.nn_mode == "culled" and world == 1 and os.path.exists(pmc):
+    if args.nn_mode == "culled" and world == 1 and pmc:
         try:
             pj = json.load(open(pmc))
         except ValueError:      # an empty or damaged file: the line is still printed, without the PMC-derived fields
             pj = {}
         traffic = pj.get("hbm_bytes_per_launch")
-        if pj.get("jobs_per_launch") and abs(pj["jobs_per_launch"] - jobs_per_launch) > 1e-6:
+        if traffic and pj.get("jobs_per_launch") and abs(pj["jobs_per_launch"] - jobs_per_launch) > 1e-6:
             traffic = traffic * jobs_per_launch / pj["jobs_per_launch"]      # PMC passes ran at another batch size
         # instruction-issue model: the committed per-wave instruction counts (PMC) x the waves of a launch over the
         # live launch time, against the vector pipes' issue rate (39.3 T lane-instructions/s)
@@ -527,7 +756,7 @@ def main():
                            # instruction per lane and cycle is a quarter of it (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
                            "frac_of_vector_issue_peak": lane_ops / (PEAK_FP32_TFLOPS * 1e12 / 4),
                            "valu_busy_frac_under_pmc": pj.get("valu_busy_frac"),
-                           "source": "profiles/r02_pmc_traffic_nn_compact.json (SQ_INSTS_* / SQ_WAVES; busy = SQ_ACTIVE_INST_VALU "
+                           "source": f"profiles/{os.path.basename(pmc)} (SQ_INSTS_* / SQ_WAVES; busy = SQ_ACTIVE_INST_VALU "
                                      "over SQ_BUSY_CYCLES): the vector pipes are busy for that fraction of the launch, a wave64 "
                                      "instruction holding its SIMD for 4 cycles (8 for fp64 and the packed-fp32 forms)"}
     if args.nn_mode == "exhaustive":
@@ -543,39 +772,66 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes, "jobs_per_launch": jobs_per_launch,
                     "launch_ms": avg_launch_s * 1e3, "launches": nn_launches,
                     "pairs_evaluated_per_launch": eval_pairs, "pairs_exhaustive_per_launch": all_pairs,
+                    "pairs_evaluated_per_source": eval_pairs / max(jobs_per_launch * pts_q, 1.0),
                     "issue_model": issue_model,
                     "note": "the culled search evaluates ~1e-3 of the pairs SURVEY 8d's flop count assumes, so its "
                             "floor is reading each scan once: (16 B x (query + candidate points) + 8 B x query "
                             "points) x jobs per launch over the HIP-event duration of the launch (one stream, "
                             "launches do not overlap); the kernel itself is vector-issue bound, see DESIGN.md; the "
-                            "brute-force nn_kernel north_star names runs at 35.7 % of the fp32 peak "
-                            "(--nn-mode exhaustive)"}
+                            "brute-force nn_kernel north_star names: legs.nn_exhaustive_sample"}
 
-    # one query alone (20 jobs per launch): the latency-bound end of the same kernel
-    if world == 1 and args.mode == "throughput" and not args.no_lone_query:
+    run_legs = world == 1 and args.mode == "throughput" and not args.no_legs
+    L = max(1, min(args.leg_steps, n_steps))
+
+    def leg_run(n_leg_steps, Bq=None, acc=True, recall_defined=True):
+        """A leg = the same pipeline steps 0 .. n-1 under changed settings: q/s, stage times, pairs per source, accuracy."""
+        Bq_ = B if Bq is None else Bq
+        run_stream(n_steps if n_warm else 0, 1, Bq=Bq)      # one untimed step under the new settings
         reg.profile_reset()
-        for j in range(3):
+        t, s_, c_, tb_ = run_stream(0, n_leg_steps, Bq=Bq, keep=True)
+        ms, nl = reg.profile("nn")
+        pe, _ = reg.nn_stats()
+        st = {n: reg.profile(n)[0] / n_leg_steps for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve")}
+        nq = n_leg_steps * Bq_
+        cc = np.concatenate(c_)
+        # queries of step i are stream ids i * per_step .. + Bq
+        qids = [i * per_step + k for i in range(n_leg_steps) for k in range(Bq_)]
+        out = {"value": nq / t, "unit": "queries/s", "queries": nq, "queries_per_batch": Bq_, "ms_per_step": t / n_leg_steps * 1e3,
+               "stage_ms_per_step": st, "nn_launch_ms": ms / max(nl, 1),
+               "pairs_evaluated_per_source": float(pe) / max(nl, 1) / max(Bq_ * TOP_K * pts_q, 1.0)}
+        if acc:
+            out["accuracy"] = accuracy_of(cc, s_, np.concatenate(tb_), qids, place_pose, query_pose,
+                                          lambda g: not is_negative(g % n_store), recall_defined=recall_defined)
+            out["accuracy"].pop("definition", None)
+        return out, s_
+
+    legs = {}
+    first_success = None
+    lone = None
+    if run_legs:
+        # one query alone (20 jobs per launch), its preparation included and NOT hidden: BASELINE configs[2]
+        reg.profile_reset()
+        t_lone = []
+        for j in range(8):
+            t0 = time.time()
             sid = store.add(q_scan_host[j].numpy())
+            t_prep = time.time() - t0
             ci, _ = knn.search(q_desc_host[j:j + 1].to(dev), TOP_K)
             reg.batch_multi([sid], scans_of(ci.cpu().numpy()), params=params)
             reg.scan_release(sid)
+            t_lone.append((time.time() - t0, t_prep))
         ms1, n1 = reg.profile("nn")
         roofline["launch_ms_one_query_20_jobs"] = ms1 / max(n1, 1)
+        t_med = float(np.median([a for a, _ in t_lone[2:]]))
+        lone = {"ms_per_query": t_med * 1e3, "queries_per_s": 1.0 / t_med,
+                "prep_ms": float(np.median([b for _, b in t_lone[2:]])) * 1e3,
+                "nn_launch_ms": ms1 / max(n1, 1), "nn_ms_per_query": ms1 / 8,
+                "what": "BASELINE configs[2]: 1 query x 20 full-size candidates, RANSAC 3000 adaptive + ICP 20, batch of ONE: "
+                        "scan H2D + index, descriptor H2D, top-20, registration, release -- wall clock, nothing overlapped"}
 
-    # the same stream with the reference's early exit (registration stops at a query's first successful candidate)
-    first_success = None
-    if world == 1 and args.mode == "throughput" and not args.no_lone_query:
+        # the same stream with the reference's early exit (registration stops at a query's first successful candidate)
         fs_state["on"] = True
-        fence()
-        t0 = time.time()
-        if not args.no_prefetch:
-            pre.start(0)
-        fsel = []
-        for i in range(n_steps):
-            cand, sel = step(i, i == n_steps - 1, False)
-            fsel.extend(sel)
-        fence()
-        t_fs = time.time() - t0
+        t_fs, fsel, _, _ = run_stream(0, n_steps)
         fs_state["on"] = False
         first_success = {"value": n_steps * per_step / t_fs, "unit": "queries/s",
                          "registrations_per_query": fs_state["jobs"] / max(fs_state["queries"], 1),
@@ -583,6 +839,125 @@ def main():
                          "note": "gloc_reg_first_success_multi: rank by rank, only queries still without a success go on "
                                  "(registration/global_localization.cpp:519-572 stops at the first match()==true); not the "
                                  "metric's configuration, which registers all 20 candidates"}
+
+        # leg 1: no adaptive RANSAC stop -- all 3000 hypotheses generated and scored (SURVEY App. B's wording of S2)
+        log("leg: RANSAC without the adaptive stop (3000 hypotheses scored)")
+        cur["params"] = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS, min_inlier_ratio=MIN_INLIER_RATIO,
+                                                max_rmse=MAX_RMSE, ransac_confidence=0.0)
+        legs["ransac_all_3000"], s3k = leg_run(L)
+        legs["ransac_all_3000"]["same_selection_as_adaptive"] = bool(s3k == sels[:len(s3k)])
+        legs["ransac_all_3000"]["what"] = ("ransac_confidence = 0: every one of the 3000 hypotheses is generated and scored, best = max "
+                                           "inliers, tie -> smallest h (SURVEY App. B); the headline follows the reference's call, "
+                                           "cv::estimateAffinePartial2D at its default confidence 0.99 (loop_detector.cpp:256-257), "
+                                           "which stops after the adaptive count")
+        cur["params"] = params
+
+        # leg 2: the brute-force 1-NN kernel north_star names (every (source, target) pair), a few whole queries
+        log("leg: exhaustive 1-NN kernel")
+        reg.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_EXHAUSTIVE)
+        n_ex = min(3, n_steps)
+        legs["nn_exhaustive_sample"], sx = leg_run(n_ex, Bq=1, acc=False)
+        lx = legs["nn_exhaustive_sample"]
+        pairs_x = TOP_K * pts_q * mean_pts
+        tf = FLOP_PER_PAIR * pairs_x / (lx["nn_launch_ms"] * 1e-3) / 1e12
+        lx.update({"roofline": {"kernel": "gloc::reg::nn_kernel", "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                                "note": f"{FLOP_PER_PAIR} flop x {pairs_x:.3e} pairs per launch (20 jobs) / {lx['nn_launch_ms']:.2f} ms; "
+                                        "the un-fused reference arithmetic cannot use FMA, which the peak counts as 2 flop"},
+                   "same_selection_as_culled": bool(sx == [sels[i * per_step] for i in range(n_ex)]),
+                   "what": "GLOC_REG_NN_EXHAUSTIVE, one query (20 candidates) per batch; identical results to the culled search"})
+        lx.pop("pairs_evaluated_per_source", None)
+        reg.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
+
+        # legs 3, 4: harder data.  The places the leg's queries retrieve get other scans for the duration of the leg.
+        leg_q = q_desc_host[:L * per_step].to(dev)
+        leg_c, _ = knn.search(leg_q, TOP_K)
+        leg_places = sorted(set(int(g) % n_store for g in leg_c.cpu().numpy().reshape(-1) if g >= 0))
+        far_base = [store.add(v) for v in far_views]
+
+        def with_override(make):
+            for g in leg_places:
+                scan_override[g] = make(g)
+
+        def drop_override():
+            for g, (sid, _) in list(scan_override.items()):
+                store.release(sid)
+            scan_override.clear()
+
+        log(f"leg: candidate poses as SURVEY cfg C ({len(leg_places)} places re-made)")
+        with_override(lambda g: (store.add_variant(base_b[(g // NEG_EVERY) % POOL_B] if is_negative(g) else base_a[g % POOL_A],
+                                                   cfgc_perturbation(g), 0.01, seed=170000 + g),
+                                 far_away_pose() if is_negative(g) else pool_pose(g % POOL_A) @ np.linalg.inv(cfgc_perturbation(g))))
+        legs["data_cfgC_perturbation"], _ = leg_run(L)
+        legs["data_cfgC_perturbation"]["what"] = ("every candidate scan re-made with yaw U(-10, 10) deg, t U(-2, 2)^2 x U(-0.2, 0.2) m "
+                                                  "(SURVEY 8d cfg C) instead of +-2 deg / +-0.3 m; identity prior (no coarse match)")
+        drop_override()
+
+        if far_base:
+            log("leg: candidates 5-20 m away")
+            with_override(lambda g: (store.add_variant(base_b[(g // NEG_EVERY) % POOL_B] if is_negative(g) else far_base[g % len(far_base)],
+                                                       place_perturbation(g), 0.01, seed=190000 + g),
+                                     far_away_pose() if is_negative(g) else far_poses[g % len(far_base)] @ np.linalg.inv(place_perturbation(g))))
+            # nothing within 5 m is retrieved: recall is not defined for this leg, success means a pose within 1 m / 5 deg
+            legs["data_far_5_20m"], _ = leg_run(L, recall_defined=False)
+            legs["data_far_5_20m"]["what"] = (f"every same-world candidate is one of {len(far_base)} views ray-cast 5-20 m from the query "
+                                              "(some turned by up to 25 deg): low overlap, loose culling bounds; identity prior, so "
+                                              "registration is not expected to succeed -- the leg prices the 1-NN search on such data")
+            drop_override()
+        for sid in far_base:
+            store.release(sid)
+
+    sub_records = None
+    if run_legs:
+        log("sub-records: kNN cfg B, one shard of cfg E")
+        sub_records = {"cfgC_lone_query": lone}
+
+        def knn_record(n_rows, nq, reps_):
+            ix = capi.KnnIndex(DIM, device=local_rank)
+            ix.reserve(n_rows)
+            ix.add_synthetic(1, 2003, 0, n_rows)
+            qh = synth.queries_near(2003, (np.arange(nq) * 131 + 7) % n_rows, DIM)
+            qd_ = torch.from_numpy(qh).to(dev)
+            oi = torch.empty((nq, TOP_K), dtype=torch.int64, device=dev)
+            od = torch.empty((nq, TOP_K), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                ix.search_device(qd_.data_ptr(), nq, TOP_K, oi.data_ptr(), od.data_ptr())
+            ix.synchronize()
+            t0 = time.time()
+            for _ in range(reps_):
+                ix.search_device(qd_.data_ptr(), nq, TOP_K, oi.data_ptr(), od.data_ptr())
+            ix.synchronize()
+            us = (time.time() - t0) / reps_ * 1e6
+            ix.set_option(capi.KNN_OPT_PROFILE, 1)
+            ix.profile_reset()
+            for _ in range(10):
+                ix.search_device(qd_.data_ptr(), nq, TOP_K, oi.data_ptr(), od.data_ptr())
+            kern = {n: ix.profile(n)[0] / 10 * 1e3 for n in ("dist_mfma", "dist_exact", "select", "rerank")}
+            st_ = ix.stats()
+            ix.close()
+            return us, kern, st_
+
+        us, kern, st_ = knn_record(KNN_CFGB[1], KNN_CFGB[0], 50)
+        flop = 2.0 * KNN_CFGB[0] * KNN_CFGB[1] * DIM
+        sub_records["knn_cfgB"] = {
+            "us_per_search": us, "queries": KNN_CFGB[0], "rows": KNN_CFGB[1], "dim": DIM, "kernel_us": kern,
+            "roofline_us": flop / (PEAK_FP32_TFLOPS * 1e12) * 1e6, "frac_of_roofline": flop / (PEAK_FP32_TFLOPS * 1e12) * 1e6 / us,
+            "mfma_kernel_tflops": flop / (kern["dist_mfma"] * 1e-6) / 1e12 if kern["dist_mfma"] > 0 else None,
+            "mfma_kernel_frac_of_peak": flop / (kern["dist_mfma"] * 1e-6) / 1e12 / PEAK_FP32_TFLOPS if kern["dist_mfma"] > 0 else None,
+            "queries_fallback": st_["queries_fallback"],
+            "what": "BASELINE configs[1]: 64 queries x 10 000 x 4096 fp32, device resident, wall clock over 50 back-to-back searches"}
+        sh = {}
+        for nq in (1, 64):
+            us, kern, st_ = knn_record(KNN_SHARD_ROWS, nq, 20)
+            byts = 4.0 * KNN_SHARD_ROWS * DIM
+            flop = 2.0 * nq * KNN_SHARD_ROWS * DIM
+            sh[f"q{nq}"] = {"us_per_search": us, "kernel_us": kern,
+                            "hbm_gbs": byts / (us * 1e-6) / 1e9, "tflops": flop / (us * 1e-6) / 1e12,
+                            "frac_of_roofline": max(byts / (PEAK_HBM_GBS * 1e9), flop / (PEAK_FP32_TFLOPS * 1e12)) / (us * 1e-6)}
+        sub_records["knn_shard_125k"] = {**sh, "rows": KNN_SHARD_ROWS, "dim": DIM,
+                                         "what": "one of the 8 shards of BASELINE configs[4] (1M x 4096): the per-rank search before the "
+                                                 "all-gather of the top-k lists; roofline = max(HBM time of the shard, fp32 MFMA time)"}
 
     q_per_rep = n_steps * per_step
     out = {
@@ -605,34 +980,45 @@ def main():
                                  + ("inline" if args.no_prefetch else "prefetched one step ahead on a second host thread + stream"),
                    "ransac_iters_cap": RANSAC_ITERS, "ransac_confidence": float(params.ransac_confidence),
                    "min_inlier_ratio": MIN_INLIER_RATIO, "max_rmse": MAX_RMSE, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
-                   "nn_mode": args.nn_mode, "collectives": collectives, "coarse_2d_match": bool(args.coarse),
+                   "nn_mode": args.nn_mode, "collectives": collectives, "rccl_ranks_seen": rccl_ranks_seen,
+                   "coarse_2d_match": bool(args.coarse),
                    "parallelism": (f"1 gpu, {B} queries registered per batch on one stream") if world == 1 else (
                        f"{B} queries per gpu per step; "
                        f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "
                        + ("each rank registers its queries locally, result tables all-gathered"
                           if args.mode == "throughput" else
-                          "one query, candidates sharded over the ranks, all-reduce of poses"))},
+                          "one query, candidates sharded over the ranks, result rows gathered"))},
+        "accuracy": accuracy,
         "roofline": roofline,
         "stage_ms_per_step_rank0": {**{k_: v / n_steps for k_, v in stage_ms.items()},
                                     **{"host_" + k_: v / n_steps * 1e3 for k_, v in stage.items()}},
         "selected_candidate_rank_histogram": {str(k_): int(v) for k_, v in
                                               zip(*np.unique(np.asarray(sels), return_counts=True))},
         "first_success_mode": first_success,
+        "legs": legs or None,
+        "sub_records": sub_records,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        log("timing the CPU checker (bounded sample) ...")
-        g_pos = int(q_place[0]) + (1 if is_negative(int(q_place[0])) else 0)     # a same-world neighbour of query 0
-        g_neg = int(q_place[0]) - (int(q_place[0]) % NEG_EVERY) + 1               # the different-world place next to it
-        sample = {"query": q_scan_host[0].numpy(), "positive": store.download(int(place_scan[g_pos])),
-                  "negative": store.download(int(place_scan[g_neg]))}
-        out["cpu_baseline"] = cpu_baseline(sample, n_places, MIN_INLIER_RATIO,
-                                           gpu_check=lambda q_, c_: reg.batch(q_, c_, params=params))
+        log("timing the CPU checker (one whole query) ...")
+        # query 0 of the stream and the 20 places it retrieved in the timed repetition (rank order)
+        c0 = all_cand[0]
+        cand_scans = [store.download(int(place_scan[int(g) % n_store])) for g in c0 if g >= 0]
+        rows0 = all_tabs[0][:len(cand_scans)] if args.mode == "throughput" else None
+        out["cpu_baseline"] = cpu_baseline(q_scan_host[0].numpy(), cand_scans, n_places, MIN_INLIER_RATIO, gpu_rows=rows0)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if shared_views and os.path.exists(shared_views):
+        try:
+            os.remove(shared_views)
+        except OSError:
+            pass
+    if accuracy["success_rate"] < args.min_success:
+        log(f"FAILED: registration success rate {accuracy['success_rate']:.3f} < {args.min_success} on the timed stream")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -377,6 +377,12 @@ class Comm:
         except Exception:
             pass
 
+    def rank_world(self):
+        """(rank, world) as the communicator itself reports them (gloc_comm_rank)."""
+        r, w = C.c_int(), C.c_int()
+        check(lib().gloc_comm_rank(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def all_gather_device(self, send_ptr, recv_ptr, bytes_per_rank, stream=0):
         check(lib().gloc_comm_all_gather_device(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), bytes_per_rank,
                                                 C.c_void_p(stream or 0)))

@@ -119,11 +119,14 @@ def torch_exchange(device):
 class ShardedRegistrar:
     """Candidate-sharded registration: each rank registers the candidates whose scans it owns."""
 
-    def __init__(self, rank, world, local_register, group=None, comm_device=None):
+    def __init__(self, rank, world, local_register, group=None, comm_device=None, gather=None):
         self.rank, self.world, self.group = rank, world, group
         self.comm_device = comm_device
         # (query handle, local scan ids [m], retrieval ranks [m]) -> float32 [m, RESULT_COLS]
         self.local_register = local_register
+        # [1, n, RESULT_COLS] device tensor -> [world, n, RESULT_COLS]: the exchange below the C ABI
+        # (CapiShardedKnn.all_gather_tables = gloc_comm_all_gather_device); None: torch.distributed
+        self.gather = gather
 
     def register(self, query, cand_global, device):
         cand_global = np.asarray(cand_global, dtype=np.int64)
@@ -133,7 +136,10 @@ class ShardedRegistrar:
         if mine.size:
             res = self.local_register(query, cand_global[mine] // self.world, mine.astype(np.uint32))
             table[torch.as_tensor(mine, device=device)] = torch.as_tensor(res, device=device)
-        if self.world > 1:
+        if self.world > 1 and self.gather is not None:
+            # every rank's table holds its own rows and zeros elsewhere: the sum over ranks is exact
+            table = self.gather(table[None]).sum(dim=0)
+        elif self.world > 1:
             t = table.to(self.comm_device) if self.comm_device else table
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # disjoint rows: exact
             table = t.to(device)

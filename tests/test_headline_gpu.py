@@ -1,0 +1,141 @@
+"""GPU: the launch that makes bench.py's headline, under the oracle ("configs_untested").
+
+BASELINE configs[3] / configs[2] at their real shape: the 4541 x 4096 descriptor database, 25 queries in flight,
+each with its 20 retrieved FULL-SIZE candidate scans (~123k points; 5 of 20 from a different world), registered by
+ONE gloc_reg_batch_multi call -- 500 jobs per kernel launch, the culled 1-NN search at its default job_group, RANSAC
+3000 (adaptive) + ICP 20, max_rmse 1 m: bench.py's parameters and bench.py's way of making the places (its own
+functions are imported).  Checked:
+  * retrieval: top-20 indices and d2 bits of all 25 queries against the CPU checker over the same database;
+  * registration: TWO whole queries (all 20 candidates each, positives and negatives) against
+    oracle.reg_one with the reference's kd-tree as the 1-NN search where oracle/_ref is present -- pose within
+    1e-4 m / 1e-4 rad, inliers / ok exact;
+  * every row of the 25 x 20 batch equals the one-query call (configs[2]: 1 query x 20 candidates) bit for bit;
+  * the reference's evaluation of the result (recall, success < 1 m / 5 deg) on the constructed ground truth.
+"""
+import numpy as np
+import pytest
+
+from util import bits
+
+pytestmark = pytest.mark.gpu
+N_Q, TOP_K = 25, 20
+N_A, N_B, N_QV = 6, 2, 2          # ray-cast base views (bench.py uses 24 / 6 / 8; one process here, so fewer)
+CHECKED_QUERIES = (0, 13)         # compared with the CPU checker, all 20 candidates each
+
+
+def _rot_angle(Ra, Rb):
+    E = Ra.astype(np.float64).T @ Rb.astype(np.float64)
+    v = 0.5 * np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])
+    return float(np.arctan2(np.linalg.norm(v), (np.trace(E) - 1) / 2))
+
+
+@pytest.fixture(scope="module")
+def headline(capi):
+    import bench
+    from gloc3d_amd import synth
+    wa, wb = synth.make_world(1001), synth.make_world(2002)
+    a_pose = [bench.pool_pose(4 * i + 1) for i in range(N_A)]           # pool views 1, 5, .. 21
+    views_a = [np.ascontiguousarray(synth.lidar_scan(wa, T, seed=3000 + i)[:, :3]) for i, T in enumerate(a_pose)]
+    views_b = [np.ascontiguousarray(synth.lidar_scan(wb, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), seed=5000 + s)[:, :3])
+               for s in range(N_B)]
+    q_pose = [a_pose[2 * v + 1] @ synth.se3(1.5, (0.3, -0.2, 0.02)) for v in range(N_QV)]
+    views_q = [np.ascontiguousarray(synth.lidar_scan(wa, T, seed=9000 + v)[:, :3]) for v, T in enumerate(q_pose)]
+
+    index = capi.KnnIndex(bench.DIM)
+    index.add_synthetic(1, bench.DB_SEED, 0, bench.N_PLACES_1GPU)
+    # as in bench.py: query j is taken next to a place whose base view is the pool view beside its query view
+    rows = ((np.arange(N_Q, dtype=np.int64) * 977 + 211) % (bench.N_PLACES_1GPU - 40)) + 20
+    q_place = rows - rows % N_A + (2 * (np.arange(N_Q) % N_QV) + 1)
+    q_desc = synth.queries_near(bench.DB_SEED, q_place, bench.DIM)
+    idx, d2 = index.search(q_desc, TOP_K)
+    index.close()
+
+    store = capi.ScanStore()
+    base_a = [store.add(v) for v in views_a]
+    base_b = [store.add(v) for v in views_b]
+    base_q = [store.add(v) for v in views_q]
+    neg = lambda g: g % bench.NEG_EVERY == 1
+    place_sid, place_pose = {}, {}
+    for g in sorted(set(int(x) for x in idx.reshape(-1))):
+        P = bench.place_perturbation(g)
+        base = base_b[(g // bench.NEG_EVERY) % N_B] if neg(g) else base_a[g % N_A]
+        place_sid[g] = store.add_variant(base, P, 0.01, seed=7000 + g)
+        place_pose[g] = bench.far_away_pose() if neg(g) else a_pose[g % N_A] @ np.linalg.inv(P)
+    q_sid, q_poses = [], []
+    for j in range(N_Q):
+        Pq = bench.query_perturbation(j)
+        q_sid.append(store.add_variant(base_q[j % N_QV], Pq, 0.01, seed=880000 + j))
+        q_poses.append(q_pose[j % N_QV] @ np.linalg.inv(Pq))
+    cand_sid = np.array([[place_sid[int(g)] for g in row] for row in idx], np.uint32)
+    reg = capi.Registrar(store=store)
+    prm = capi.default_reg_params(ransac_iters=bench.RANSAC_ITERS, icp_iters=bench.ICP_ITERS,
+                                  min_inlier_ratio=bench.MIN_INLIER_RATIO, max_rmse=bench.MAX_RMSE)
+    out = reg.batch_multi(q_sid, cand_sid, params=prm)          # THE launch sequence: 25 x 20 = 500 jobs per launch
+    yield dict(bench=bench, store=store, reg=reg, prm=prm, idx=idx, d2=d2, q_desc=q_desc, q_place=q_place, q_sid=q_sid,
+               cand_sid=cand_sid, out=out, place_pose=place_pose, q_poses=q_poses, neg=neg)
+    reg.close()
+    store.close()
+
+
+def test_retrieval_of_the_batch_is_the_checkers(headline, oracle_mod):
+    from gloc3d_amd import synth
+    b = headline["bench"]
+    db = synth.descriptors_traj(b.DB_SEED, 0, b.N_PLACES_1GPU, b.DIM)
+    oi, od = oracle_mod.knn_search(db, headline["q_desc"], TOP_K, threads=8)
+    assert (headline["idx"] == oi).all() and (bits(headline["d2"]) == bits(od)).all()
+    assert (headline["idx"][:, 0] == headline["q_place"].astype(np.uint64)).all()
+
+
+def test_two_whole_queries_of_the_500_job_launch_match_the_checker(headline, oracle_mod):
+    h = headline
+    store, out, b = h["store"], h["out"], h["bench"]
+    use_ref = oracle_mod.have_ref()          # the reference's own nanoflann kd-tree as the 1-NN search
+    kw = dict(ransac_iters=b.RANSAC_ITERS, icp_iters=b.ICP_ITERS, min_inlier_ratio=b.MIN_INLIER_RATIO, max_rmse=b.MAX_RMSE)
+    for qi in CHECKED_QUERIES:
+        q = store.download(h["q_sid"][qi])
+        assert q.shape[0] > 120000
+        cands = [store.download(int(s)) for s in h["cand_sid"][qi]]
+        o = oracle_mod.reg_many_mt(q, cands, 10, ref_nn=use_ref, cand_ids=np.arange(TOP_K, dtype=np.uint32), **kw)
+        n_neg = 0
+        for c in range(TOP_K):
+            assert np.abs(out["T"][qi, c][:3, 3] - o["T"][c][:3, 3]).max() < 1e-4, (qi, c)
+            assert _rot_angle(out["T"][qi, c][:3, :3], o["T"][c][:3, :3]) < 1e-4, (qi, c)
+            assert out["inliers"][qi, c] == o["inliers"][c] and bool(out["ok"][qi, c]) == bool(o["ok"][c]), (qi, c)
+            assert abs(out["rmse"][qi, c] - o["rmse"][c]) < 1e-5
+            is_neg = h["neg"](int(h["idx"][qi, c]))
+            n_neg += is_neg
+            assert not (is_neg and out["ok"][qi, c]), (qi, c)         # no different-world candidate is accepted
+        assert n_neg == TOP_K // b.NEG_EVERY and out["ok"][qi].any()
+
+
+def test_every_row_of_the_batch_equals_the_one_query_call(headline):
+    """BASELINE configs[2] (1 query x its 20 full-size candidates as one batch) for each of the 25 queries: the
+    rows of the 500-job launch, bit for bit -- and through the first-success loop, the same rank and pose."""
+    h = headline
+    out = h["out"]
+    for qi in range(N_Q):
+        one = h["reg"].batch_ids(h["q_sid"][qi], h["cand_sid"][qi], params=h["prm"])
+        assert (bits(out["T"][qi]) == bits(one["T"])).all(), qi
+        assert (bits(out["rmse"][qi]) == bits(one["rmse"])).all() and (out["inliers"][qi] == one["inliers"]).all()
+        assert (out["ok"][qi] == one["ok"]).all()
+    fs = h["reg"].first_success_multi(h["q_sid"], h["cand_sid"], params=h["prm"])
+    for qi in range(N_Q):
+        r = int(np.argmax(out["ok"][qi])) if out["ok"][qi].any() else -1
+        assert fs["rank"][qi] == r and (bits(fs["T"][qi]) == bits(out["T"][qi, r])).all()
+
+
+def test_the_reference_evaluators_report_on_the_batch(headline):
+    """recall@N and the registration success criterion (global_localization.cpp:221-268, 270-335) on the
+    constructed ground truth: what bench.py prints as `accuracy`."""
+    h = headline
+    out, b = h["out"], h["bench"]
+    sels = [int(np.argmax(ok)) if ok.any() else -1 for ok in out["ok"]]
+    tables = np.zeros((N_Q, TOP_K, 19), np.float32)
+    tables[..., :16] = out["T"].reshape(N_Q, TOP_K, 16)
+    acc = b.accuracy_of(h["idx"].astype(np.int64), sels, tables, list(range(N_Q)), lambda g: h["place_pose"][int(g)],
+                        lambda j: h["q_poses"][int(j)], lambda g: not h["neg"](int(g)))
+    assert acc["success_rate"] == 1.0 and acc["not_located"] == 0, acc
+    assert acc["pos_err_mean_m"] < 0.5 and acc["rot_err_mean_deg"] < 2.0, acc
+    n_rank0_neg = sum(1 for qi in range(N_Q) if h["neg"](int(h["idx"][qi, 0])))
+    assert abs(acc["recall_at_1"] - (N_Q - n_rank0_neg) / N_Q) < 1e-9 and acc["recall_at_5"] == 1.0
+    assert all(s == (1 if h["neg"](int(h["idx"][qi, 0])) else 0) for qi, s in enumerate(sels))

@@ -70,6 +70,15 @@ def _worker(rank, world, port, n_places, dim, out_dir):
     sreg = sharded.ShardedRegistrar(rank, world, local_register)
     table = sreg.register(0, gi[0].numpy(), torch.device("cpu"))
     sel = sreg.select_first_ok(table)
+    # the same exchange as an all-gather of the per-rank tables (the form below the C ABI,
+    # gloc_comm_all_gather_device; here a gloo stand-in with the same [1, n, C] -> [world, n, C] contract)
+    def gather(t):
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t.contiguous())
+        return out
+    sreg_g = sharded.ShardedRegistrar(rank, world, local_register, gather=gather)
+    table_g = sreg_g.register(0, gi[0].numpy(), torch.device("cpu"))
+    assert (table_g == table).all() and sreg_g.select_first_ok(table_g) == sel
     # throughput mode: query r registered entirely by rank r, tables all-gathered
     def register_all(query, places, ranks):
         out = np.zeros((len(places), sharded.RESULT_COLS), np.float32)

@@ -220,7 +220,7 @@ def accuracy_of(cands, sels, tables, q_ids, place_pose, query_pose, is_positive_
     if not recall_defined:
         rec, failed_detect = [None] * 4, []
     er_all, ep_all, located = [], [], 0
-    ok_rot, ok_pos = [], []
+    ok_rot, ok_pos, wrong = [], [], []
     for qi in range(Q):
         r = int(sels[qi])
         if r < 0:
@@ -235,6 +235,11 @@ def accuracy_of(cands, sels, tables, q_ids, place_pose, query_pose, is_positive_
         if ep < 1.0 and er < 5.0:
             ok_rot.append(er)
             ok_pos.append(ep)
+        elif len(wrong) < 16:
+            d_place = float(np.linalg.norm(place_pose(g)[:3, 3] - qpos[qi]))
+            wrong.append({"query": int(q_ids[qi]), "rank": r, "place": g, "place_to_query_m": round(d_place, 2),
+                          "err_pos_m": round(ep, 3), "err_rot_deg": round(er, 3), "rmse_m": round(float(tables[qi][r][16]), 3),
+                          "inliers": int(tables[qi][r][17])})
 
     def mean_std(v):    # caculate_mean_std: n - 1 in the denominator (global_localization.cpp:185-196)
         if len(v) < 2:
@@ -248,6 +253,7 @@ def accuracy_of(cands, sels, tables, q_ids, place_pose, query_pose, is_positive_
             "success_rate": len(ok_pos) / Q if Q else 0.0, "succeeded": len(ok_pos), "located": located,
             "not_located": Q - located, "pos_err_mean_m": pm, "pos_err_std_m": ps, "rot_err_mean_deg": rm,
             "rot_err_std_deg": rs, "pos_err_max_m_located": float(max(ep_all)) if ep_all else 0.0,
+            "located_but_wrong": wrong,
             "definition": "recall@N: first hit among the top N (global_localization.cpp:221-268), positives = same-world "
                           f"places within {POSITIVE_RADIUS_M:g} m; success: err_pos < 1 m and err_rot < 5 deg against "
                           "pose_db^-1 pose_q, mean / std (n - 1) over the successes (:270-335)"}
@@ -382,6 +388,8 @@ def main():
                     help="1-NN search of the registration (identical results)")
     ap.add_argument("--ransac-confidence", type=float, default=None,
                     help="override gloc_reg_params.ransac_confidence (0: score all 3000 hypotheses)")
+    ap.add_argument("--no-target-index", action="store_true",
+                    help="leave the database scans in curve order (A/B of gloc_scan_store_build_target_index)")
     ap.add_argument("--min-success", type=float, default=0.95,
                     help="the run fails (exit code 3) when the stream's registration success rate is below this")
     args = ap.parse_args()
@@ -439,6 +447,8 @@ def main():
     for g in range(n_store):
         base = base_b[(g // NEG_EVERY) % POOL_B] if is_negative(g) else base_a[g % POOL_A]
         place_scan[g] = store.add_variant(base, place_perturbation(g), 0.01, seed=7000 + g)
+        if not args.no_target_index:
+            store.build_target_index(int(place_scan[g]))   # a database place: the kd-ordered target index, once
     live_b, _ = store.bytes()
     mean_pts = float(np.mean([p.shape[0] for p in pool_a]))
     log(f"scan store: {n_store} distinct resident scans (+{POOL_A + POOL_B} base views), "
@@ -878,6 +888,8 @@ def main():
         def with_override(make):
             for g in leg_places:
                 scan_override[g] = make(g)
+                if not args.no_target_index:
+                    store.build_target_index(scan_override[g][0])
 
         def drop_override():
             for g, (sid, _) in list(scan_override.items()):
@@ -973,7 +985,7 @@ def main():
                    "repetitions": n_reps, "repetition_seconds": rep_s, "value_is": "median repetition",
                    "places": n_places, "dim": DIM, "top_k": TOP_K, "points_per_scan": int(mean_pts),
                    "scan_store_scans": int(store_scans_resident), "scan_store_distinct_places": int(n_store),
-                   "scan_store_gib": live_b / 2**30,
+                   "scan_store_gib": live_b / 2**30, "database_scans_target_index": "kd order" if not args.no_target_index else "curve order",
                    "negatives_per_query": (TOP_K // NEG_EVERY) if neg_on else 0,
                    "query_prep_in_timed_region": True,
                    "query_prep": "per query: scan H2D from pinned host memory + device indexing + descriptor H2D, "

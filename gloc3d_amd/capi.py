@@ -16,7 +16,7 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
              5: "GLOC_ERR_STATE"}
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA = 0, 1, 2
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
-REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_JOB_GROUP = 1, 2, 3, 4
+REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_JOB_GROUP, REG_OPT_TEMP_TARGET_INDEX = 1, 2, 3, 4, 5
 REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
 NO_SCAN = 0xFFFFFFFF
 SIZE_MAX = C.c_size_t(-1).value
@@ -130,6 +130,7 @@ _PROTOS = [
     ("gloc_scan_store_add", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_scan_store_add_device", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_scan_store_add_variant", _i, [_vp, _u32, _vp, C.c_float, _u64, C.POINTER(_u32)]),
+    ("gloc_scan_store_build_target_index", _i, [_vp, _u32]),
     ("gloc_scan_store_release", _i, [_vp, _u32]),
     ("gloc_scan_store_clear", _i, [_vp]),
     ("gloc_scan_store_count", _i, [_vp, C.POINTER(_sz)]),
@@ -138,6 +139,7 @@ _PROTOS = [
     ("gloc_scan_store_download", _i, [_vp, _u32, _vp, _sz]),
     ("gloc_reg_attach_store", _i, [_vp, _vp]),
     ("gloc_reg_scan_upload", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
+    ("gloc_reg_scan_build_target_index", _i, [_vp, _u32]),
     ("gloc_reg_scan_release", _i, [_vp, _u32]),
     ("gloc_reg_scan_count", _i, [_vp, C.POINTER(_sz)]),
     ("gloc_reg_scan_clear", _i, [_vp]),
@@ -446,6 +448,11 @@ class ScanStore:
                                                 float(noise_sigma), int(seed), C.byref(sid)))
         return sid.value
 
+    def build_target_index(self, scan_id):
+        """Re-sort the scan's index into kd order: for scans that serve as registration targets (database places)."""
+        check(lib().gloc_scan_store_build_target_index(self._h, int(scan_id)))
+        return scan_id
+
     def release(self, scan_id):
         check(lib().gloc_scan_store_release(self._h, int(scan_id)))
 
@@ -537,6 +544,10 @@ class Registrar:
         check(lib().gloc_reg_scan_upload(self._h, _np_ptr(pts), pts.shape[0], pts.shape[1],
                                          C.byref(sid)))
         return sid.value
+
+    def scan_build_target_index(self, scan_id):
+        check(lib().gloc_reg_scan_build_target_index(self._h, int(scan_id)))
+        return scan_id
 
     def scan_count(self):
         n = C.c_size_t()

@@ -68,6 +68,7 @@ class RpyPCLoopDetector {
     if (!comm_ || (int)(db_size_ % (size_t)world_) == rank_) check(gloc_knn_add(knn_, descriptor.data(), 1));
     uint32_t sid = 0;
     check(gloc_reg_scan_upload(reg_, scan_xyzi, n_pts, 4, &sid));
+    check(gloc_reg_scan_build_target_index(reg_, sid));  // a database place is a registration target from now on
     db_scan_ids_.push_back(sid);
     uint32_t gid = 0;  // db_grids_.push_back(grid), loop_detector.cpp:16-19
     check(gloc_coarse_add_scan(coarse_, scan_xyzi, n_pts, 4, &coarse_params_, &gid));

@@ -4,7 +4,9 @@
 // evaluated pair is the un-fused fp32 ((dx dx + dy dy) + dz dz), ties go to the smallest ORIGINAL
 // target index.  What changes is which pairs are evaluated:
 //   * every scan is Hilbert-sorted once (scan_store.hip) and cut into chunks of 128 points, sub-blocks
-//     of 16 and super-chunks of 64 chunks, each with an axis-aligned bounding box;
+//     of 16 and super-chunks of 64 chunks, each with an axis-aligned bounding box; a scan that serves as a
+//     target (a database place) is re-sorted into kd order, whose chunks and sub-blocks are disjoint cells
+//     (scan_index.hpp) -- nothing below depends on which order it is;
 //   * a wave owns 64*CS consecutive (hence spatially compact) sorted source points, CS per lane;
 //   * upper bounds come from the previous ICP pass's correspondence (warm start) or from the curve
 //     neighbourhood of the point in the target's key order;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
   struct IndexView {
     GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb2;
-    GPTR(uint32_t) keys; GPTR(ScanHeader) hdr;
+    GPTR(uint32_t) keys; GPTR(uint32_t) kpos; GPTR(ScanHeader) hdr;
     uint32_t n, nchunks;
     GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
     uint32_t nsup;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // treat as generic (flat_load): view them in the global address space explicitly.
   const ScanIndexDev ixg = J.tgt;
   const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
-                     (GPTR(f32x4))ixg.sb2, (GPTR(uint32_t))ixg.keys,
+                     (GPTR(f32x4))ixg.sb2, (GPTR(uint32_t))ixg.keys, (GPTR(uint32_t))ixg.kpos,
                      (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
                      (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup};
   GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
@@ -207,11 +209,13 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         for (int d = -2; d <= 2; ++d) {
           long long jj = (long long)lo + d;
           jj = jj < 0 ? 0 : (jj >= (long long)ix.n ? (long long)ix.n - 1 : jj);
-          const f32x4 t = ix.pts[jj];
+          // (a target index is in kd order: the curve neighbour's place among the points comes from kpos)
+          const uint32_t pj = ix.kpos ? ix.kpos[jj] : (uint32_t)jj;
+          const f32x4 t = ix.pts[pj];
           const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
           if (dd < best[s]) {
             best[s] = dd;
-            b0 = (uint32_t)jj / (SB / 2);
+            b0 = pj / (SB / 2);
           }
         }
       }

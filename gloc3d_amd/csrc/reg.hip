@@ -34,6 +34,7 @@ struct gloc_reg {
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
   int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
+  bool temp_target_index = false;  // kd-ordered target index for the temporary scans of the host-buffer calls
   uint64_t nn_launches = 0;
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
@@ -297,12 +298,13 @@ struct TempScans {
   gloc_scan_store* st;
   std::vector<DevScan> scans;
   explicit TempScans(gloc_scan_store* s) : st(s) {}
-  int add(const float* pts, size_t n, int cs) {
+  int add(const float* pts, size_t n, int cs, bool target_index = false) {
     std::lock_guard<std::mutex> lk(st->mu);
     DevScan s;
     GLOC_TRY(store_make_scan(st, pts, n, 3, false, &s));
-    GLOC_TRY(store_build_order(st, s, cs));  // (cs = 0: a target, no order)
-    scans.push_back(s);
+    scans.push_back(s);  // (owned from here on: freed by the destructor whatever happens below)
+    if (target_index) GLOC_TRY(store_build_target_index(st, scans.back()));
+    GLOC_TRY(store_build_order(st, scans.back(), cs));  // (cs = 0: a target, no order)
     return GLOC_OK;
   }
   ~TempScans() {
@@ -413,6 +415,10 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
     h->nn_job_group = (int)value;
     return GLOC_OK;
   }
+  if (option == GLOC_REG_OPT_TEMP_TARGET_INDEX) {
+    h->temp_target_index = value != 0;
+    return GLOC_OK;
+  }
   if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {
     GLOC_REQUIRE(value == 1 || value == 2 || value == 4, GLOC_ERR_INVALID, "must be 1, 2 or 4");
     h->nn_src_per_lane = (int)value;
@@ -428,6 +434,14 @@ int gloc_reg_scan_upload(gloc_reg* h, const float* pts, size_t n, size_t stride_
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_TRY(ensure_store(h));
   return gloc_scan_store_add(h->store, pts, n, stride_floats, scan_id);
+}
+
+int gloc_reg_scan_build_target_index(gloc_reg* h, uint32_t scan_id) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_REQUIRE(h->store, GLOC_ERR_INVALID, "unknown scan id %u", scan_id);
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_HIP(hipStreamSynchronize(h->stream));  // no launch of this handle may still read the scan
+  return gloc_scan_store_build_target_index(h->store, scan_id);
 }
 
 int gloc_reg_scan_release(gloc_reg* h, uint32_t scan_id) {
@@ -462,7 +476,7 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   GLOC_TRY(ensure_store(h));
   TempScans tmp(h->store);  // released on return
   GLOC_TRY(tmp.add(q_xyz, nq_pts, h->nn_src_per_lane));
-  for (size_t c = 0; c < n_cand; ++c) GLOC_TRY(tmp.add(cand_xyz[c], cand_npts[c], 0));
+  for (size_t c = 0; c < n_cand; ++c) GLOC_TRY(tmp.add(cand_xyz[c], cand_npts[c], 0, h->temp_target_index));
   std::vector<JobHost> jh(n_cand);
   for (size_t c = 0; c < n_cand; ++c)
     jh[c] = JobHost{tmp.scans[0], tmp.scans[c + 1], cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c,
@@ -628,7 +642,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   hipStream_t s = h->stream;
   TempScans tmp(h->store);
   GLOC_TRY(tmp.add(src_xyz, n_src, h->nn_src_per_lane));
-  GLOC_TRY(tmp.add(tgt_xyz, n_tgt, 0));
+  GLOC_TRY(tmp.add(tgt_xyz, n_tgt, 0, h->temp_target_index));
   const int cs = h->nn_src_per_lane;
   const uint32_t ng = (uint32_t)((n_src + 64 * cs - 1) / (64 * cs));
   BatchDims bd{1, (uint32_t)n_src, ng, std::max<uint32_t>(ng, 1), ((size_t)n_src + 127) & ~(size_t)127};

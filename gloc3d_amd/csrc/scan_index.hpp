@@ -3,6 +3,14 @@
 //   bounding box -> Hilbert keys on a 1024^3 grid -> radix sort -> sorted float4 copy with the
 //   original indices, inverse permutation -> boxes per 128-point chunk, per 16-point sub-block and
 //   per 64-chunk super-chunk -> launch order of the source groups (widest first).
+// A scan that serves as a registration TARGET (a database place) is re-sorted once more, into KD ORDER
+// (gloc_scan_store_build_target_index): a complete binary tree over the sorted positions, every aligned
+// block of 16 * 2^j positions one kd cell -- at every level the points of a cell are split at the middle
+// position along the widest axis of their bounding box.  Cells of one level are disjoint and fit the
+// point density, where runs of a space-filling curve have irregular, overlapping bounding boxes: on
+// lidar scans a moved query point is within its nearest-neighbour distance of 1.7 chunk boxes and 2.5
+// sub-block boxes instead of 2.6 and 3.5, and the culled search evaluates 30 % fewer pairs and tests 35 %
+// fewer boxes.  The order of a scan never changes a result: the search is exact either way.
 // The structures live here; the kernels that fill them are in scan_store.hip; the 1-NN kernels
 // (nn_compact.hpp) read them.
 #pragma once
@@ -34,7 +42,10 @@ struct ScanIndexDev {
   // (lo0.x lo1.x lo0.y lo1.y) (lo0.z lo1.z hi0.x hi1.x) (hi0.y hi1.y hi0.z hi1.z) -- a lane tests one
   // point against both with packed fp32 instructions, the pairs being register pairs as loaded
   const f32x4* sb2;
-  const void* reserved_;
+  // Target index only (null for a scan in plain Hilbert order): position in `pts` of the point with the
+  // i-th smallest curve key.  A target index is sorted in kd order (see below), the curve keys stay the
+  // cold-start lookup: binary search in `keys`, then through kpos to the points.
+  const uint32_t* kpos;
   const uint32_t* keys;  // sorted curve keys
   const uint32_t* inv;   // original index -> sorted position
   const ScanHeader* hdr;

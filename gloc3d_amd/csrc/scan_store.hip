@@ -256,6 +256,111 @@ __global__ void scan_variant_kernel(const float* __restrict__ xyz, uint32_t n, c
   out[3 * (size_t)i + 2] = z + nz;
 }
 
+
+// ---- kd order (target index): see scan_index.hpp -------------------------------------------------------
+// The scan is already in curve order.  P = 16 * 2^L >= n positions form a complete binary tree; at level
+// l a node is the aligned block of (P >> l) positions.  Level by level (top down) every node's points are
+// sorted along the widest axis of their bounding box, so that its lower half -- the left child -- holds the
+// smaller coordinates: one device-wide radix sort per level by (node, coordinate), stable, so that equal
+// coordinates keep their current (deterministic) order.  Positions >= n are never materialised: they stand
+// for points at +infinity, which stay at the end of their node under every sort.
+__global__ void kd_box_init_kernel(uint32_t* __restrict__ box, uint32_t nodes) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nodes) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    box[6 * k + a] = 0xFFFFFFFFu;
+    box[6 * k + 3 + a] = 0u;
+  }
+}
+
+// one thread per block of 16 points; a wave's 64 blocks lie in ONE node when the node holds >= 1024 positions
+__global__ __launch_bounds__(256) void kd_node_bbox_kernel(const f32x4* __restrict__ p, uint32_t n, uint32_t shift,
+                                                           uint32_t* __restrict__ box) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i0 = b * 16u;
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  if (i0 < n) {
+    const uint32_t i1 = i0 + 16u < n ? i0 + 16u : n;
+    for (uint32_t i = i0; i < i1; ++i) {
+      const f32x4 v = p[i];
+      const uint32_t o[3] = {f2ord(v.x), f2ord(v.y), f2ord(v.z)};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = o[a] < lo[a] ? o[a] : lo[a];
+        hi[a] = o[a] > hi[a] ? o[a] : hi[a];
+      }
+    }
+  }
+  uint32_t first = i0;  // a position inside this thread's node
+  if (shift >= 10) {    // wave-uniform node: combine first, one set of atomics per wave
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo[a], o), h2 = __shfl_xor(hi[a], o);
+        lo[a] = l2 < lo[a] ? l2 : lo[a];
+        hi[a] = h2 > hi[a] ? h2 : hi[a];
+      }
+    first = (b & ~63u) * 16u;
+    if ((threadIdx.x & 63) != 0) return;
+  }
+  if (lo[0] > hi[0]) return;  // no point in this block / wave
+  uint32_t* o = box + 6 * (size_t)(first >> shift);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    atomicMin(o + a, lo[a]);
+    atomicMax(o + 3 + a, hi[a]);
+  }
+}
+
+__global__ void kd_keys_kernel(const f32x4* __restrict__ p, uint32_t n, uint32_t shift, const uint32_t* __restrict__ box,
+                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t node = i >> shift;
+  const uint32_t* b = box + 6 * (size_t)node;
+  const float ex = ord2f(b[3]) - ord2f(b[0]), ey = ord2f(b[4]) - ord2f(b[1]), ez = ord2f(b[5]) - ord2f(b[2]);
+  int axis = 0;           // the widest axis; ties -> the lower axis
+  float e = ex;
+  if (ey > e) { axis = 1; e = ey; }
+  if (ez > e) axis = 2;
+  const f32x4 v = p[i];
+  const float c = axis == 0 ? v.x : (axis == 1 ? v.y : v.z);
+  keys[i] = ((unsigned long long)node << 32) | f2ord(c);
+  vals[i] = i;
+}
+
+__global__ void kd_gather_kernel(const f32x4* __restrict__ p_in, const uint32_t* __restrict__ h_in,
+                                 const uint32_t* __restrict__ perm, uint32_t n, f32x4* __restrict__ p_out,
+                                 uint32_t* __restrict__ h_out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t s = perm[j];
+  p_out[j] = p_in[s];
+  h_out[j] = h_in[s];
+}
+
+__global__ void kd_iota_kernel(uint32_t* __restrict__ h, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i] = i;
+}
+
+// the re-sorted points back into the scan: pts (kd order, padded), inv (original index -> kd position), kpos
+// (curve position -> kd position)
+__global__ void kd_finish_kernel(const f32x4* __restrict__ p, const uint32_t* __restrict__ h, uint32_t n, uint32_t n_pad,
+                                 f32x4* __restrict__ pts, uint32_t* __restrict__ inv, uint32_t* __restrict__ kpos) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pad) return;
+  if (j >= n) {
+    pts[j] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
+    return;
+  }
+  const f32x4 v = p[j];
+  pts[j] = v;
+  inv[__float_as_uint(v.w)] = j;
+  kpos[h[j]] = j;
+}
+
 namespace {
 
 struct Layout {
@@ -272,9 +377,9 @@ Layout layout_for(size_t n) {
   L.b1 = L.c1 * (CH / SB / 2) * 3;  // float4 per scan of the paired sub-block boxes
   L.u1 = std::max<size_t>(nsup, 1);
   L.g1 = (L.n1 + 63) / 64;
-  // header | pts4 | box_lo | box_hi | sb2 | sup_lo | sup_hi | xyz | keys | inv | order (cs = 1 | 2 | 4)
+  // header | pts4 | box_lo | box_hi | sb2 | sup_lo | sup_hi | xyz | keys | inv | order (cs = 1 | 2 | 4) | kpos
   L.bytes = sizeof(ScanHeader) + sizeof(f32x4) * (L.np + 2 * L.c1 + L.b1 + 2 * L.u1) +
-            sizeof(float) * 3 * L.n1 + sizeof(uint32_t) * (2 * L.n1 + 2 * L.g1 + 2);
+            sizeof(float) * 3 * L.n1 + sizeof(uint32_t) * (3 * L.n1 + 2 * L.g1 + 2);
   return L;
 }
 
@@ -355,6 +460,74 @@ int store_build_order(gloc_scan_store* st, DevScan& s, int cs) {
   return GLOC_OK;
 }
 
+
+int store_build_target_index(gloc_scan_store* st, DevScan& s) {
+  if (s.kd || s.n <= (size_t)SB) {
+    s.kd = true;  // (a scan of one sub-block is in kd order as it is)
+    return GLOC_OK;
+  }
+  hipStream_t q = st->stream;
+  const uint32_t n = (uint32_t)s.n;
+  uint32_t L = 0;
+  while (((size_t)SB << L) < s.n) ++L;  // P = SB * 2^L positions
+  const Layout lay = layout_for(s.n);
+  GLOC_TRY(st->kd_k0.ensure(sizeof(unsigned long long) * n, q));
+  GLOC_TRY(st->kd_k1.ensure(sizeof(unsigned long long) * n, q));
+  GLOC_TRY(st->kd_v0.ensure(sizeof(uint32_t) * n, q));
+  GLOC_TRY(st->kd_v1.ensure(sizeof(uint32_t) * n, q));
+  GLOC_TRY(st->kd_p0.ensure((sizeof(f32x4) + sizeof(uint32_t)) * (size_t)n, q));
+  GLOC_TRY(st->kd_p1.ensure((sizeof(f32x4) + sizeof(uint32_t)) * (size_t)n, q));
+  GLOC_TRY(st->kd_box.ensure(sizeof(uint32_t) * 6 * ((size_t)1 << (L ? L - 1 : 0)), q));
+  f32x4* pp[2] = {st->kd_p0.as<f32x4>(), st->kd_p1.as<f32x4>()};
+  uint32_t* hh[2] = {reinterpret_cast<uint32_t*>(pp[0] + n), reinterpret_cast<uint32_t*>(pp[1] + n)};
+  const unsigned nb = (n + 255) / 256, nblk = ((n + SB - 1) / SB + 255) / 256;
+  GLOC_HIP(hipMemcpyAsync(pp[0], s.idx.pts, sizeof(f32x4) * n, hipMemcpyDeviceToDevice, q));
+  hipLaunchKernelGGL(kd_iota_kernel, dim3(nb), dim3(256), 0, q, hh[0], n);
+  int cur = 0;
+  size_t tmp_cap = 0;
+  for (uint32_t l = 0; l < L; ++l) {
+    const uint32_t shift = 4 + L - l;  // log2 of the node size at this level (SB = 16 = 2^4)
+    static_assert(SB == 16, "shift arithmetic assumes 16-point leaves");
+    const uint32_t nodes = 1u << l;
+    hipLaunchKernelGGL(kd_box_init_kernel, dim3((nodes + 255) / 256), dim3(256), 0, q, st->kd_box.as<uint32_t>(), nodes);
+    hipLaunchKernelGGL(kd_node_bbox_kernel, dim3(nblk), dim3(256), 0, q, pp[cur], n, shift, st->kd_box.as<uint32_t>());
+    hipLaunchKernelGGL(kd_keys_kernel, dim3(nb), dim3(256), 0, q, pp[cur], n, shift, st->kd_box.as<uint32_t>(),
+                       st->kd_k0.as<unsigned long long>(), st->kd_v0.as<uint32_t>());
+    GLOC_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, st->kd_k0.as<unsigned long long>(),
+                                                st->kd_k1.as<unsigned long long>(), st->kd_v0.as<uint32_t>(),
+                                                st->kd_v1.as<uint32_t>(), (int)n, 0, (int)(32 + l), q));
+    if (tmp_bytes > tmp_cap) {
+      GLOC_TRY(st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q));
+      tmp_cap = tmp_bytes;
+    }
+    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp.p, tmp_bytes, st->kd_k0.as<unsigned long long>(),
+                                                st->kd_k1.as<unsigned long long>(), st->kd_v0.as<uint32_t>(),
+                                                st->kd_v1.as<uint32_t>(), (int)n, 0, (int)(32 + l), q));
+    hipLaunchKernelGGL(kd_gather_kernel, dim3(nb), dim3(256), 0, q, pp[cur], hh[cur], st->kd_v1.as<uint32_t>(), n,
+                       pp[cur ^ 1], hh[cur ^ 1]);
+    cur ^= 1;
+  }
+  // write back and rebuild what depends on the order: inv, kpos, all boxes, the launch orders
+  f32x4* p4 = const_cast<f32x4*>(s.idx.pts);
+  uint32_t* inv = const_cast<uint32_t*>(s.idx.inv);
+  const size_t nch = (s.n + CH - 1) / CH, nsup = (nch + 63) / 64;
+  hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)((lay.np + 255) / 256)), dim3(256), 0, q, pp[cur], hh[cur], n,
+                     (uint32_t)lay.np, p4, inv, s.kpos_mem);
+  hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, q, p4, n, const_cast<f32x4*>(s.idx.box_lo),
+                     const_cast<f32x4*>(s.idx.box_hi));
+  hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((lay.b1 / 3 + 255) / 256)), dim3(256), 0, q, p4, n,
+                     (uint32_t)(lay.b1 / 3), const_cast<f32x4*>(s.idx.sb2));
+  hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, q, s.idx.box_lo, s.idx.box_hi, (uint32_t)nch,
+                     const_cast<f32x4*>(s.idx.sup_lo), const_cast<f32x4*>(s.idx.sup_hi));
+  GLOC_HIP(hipGetLastError());
+  s.idx.kpos = s.kpos_mem;
+  s.kd = true;
+  s.order_built = 0;  // the launch orders list groups of the old order
+  return store_build_order(st, s, 2);  // synchronises the stream
+}
+
 int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
                     DevScan* out) {
   DevScan s;
@@ -375,6 +548,7 @@ int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stri
   s.order_base = inv + L.n1;
   s.order_g1 = L.g1;
   s.order = nullptr;
+  s.kpos_mem = s.order_base + 2 * L.g1 + 2;
   s.idx = ScanIndexDev{p4, lo, hi, sb2, nullptr, keys, inv, hdr, ulo, uhi, (uint32_t)n, (uint32_t)nch,
                        (uint32_t)nsup, 0u};
   hipStream_t q = st->stream;
@@ -516,7 +690,9 @@ int gloc_scan_store_destroy(gloc_scan_store* st) {
   for (auto& s : st->scans)
     if (s.block) (void)hipFree(s.block);
   for (auto& kv : st->free_blocks) (void)hipFree(kv.second);
-  for (DevBuf* b : {&st->sort_tmp, &st->sort_keys, &st->sort_vals, &st->sort_perm, &st->stage}) b->release();
+  for (DevBuf* b : {&st->sort_tmp, &st->sort_keys, &st->sort_vals, &st->sort_perm, &st->stage, &st->kd_k0, &st->kd_k1,
+                    &st->kd_v0, &st->kd_v1, &st->kd_p0, &st->kd_p1, &st->kd_box})
+    b->release();
   (void)hipStreamDestroy(st->stream);
   delete st;
   return GLOC_OK;
@@ -560,6 +736,14 @@ int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const flo
   DevScan s;
   GLOC_TRY(store_make_scan(st, dout, base.n, 3, true, &s));
   return store_insert(st, s, scan_id);
+}
+
+int gloc_scan_store_build_target_index(gloc_scan_store* st, uint32_t scan_id) {
+  GLOC_REQUIRE(st, GLOC_ERR_INVALID, "null store");
+  GLOC_HIP(hipSetDevice(st->device));
+  std::lock_guard<std::mutex> lk(st->mu);
+  GLOC_REQUIRE(scan_id < st->scans.size() && st->scans[scan_id].live, GLOC_ERR_INVALID, "unknown scan id %u", scan_id);
+  return store_build_target_index(st, st->scans[scan_id]);
 }
 
 int gloc_scan_store_release(gloc_scan_store* st, uint32_t scan_id) {

@@ -25,11 +25,13 @@ struct DevScan {
   uint32_t* order_base = nullptr;
   uint32_t* order = nullptr;
   unsigned order_built = 0;  // bit (cs) set: order_of(cs) is valid
+  uint32_t* kpos_mem = nullptr;  // room for the target index's curve position -> kd position table
   size_t order_g1 = 0;       // groups at cs = 1
   uint32_t* order_of(int cs) const {
     return order_base + (cs == 1 ? 0 : cs == 2 ? order_g1 : order_g1 + (order_g1 + 1) / 2);
   }
   bool live = false;
+  bool kd = false;  // the index is in kd order (target index)
 };
 
 struct gloc_scan_store {
@@ -41,6 +43,7 @@ struct gloc_scan_store {
   std::multimap<size_t, void*> free_blocks;  // released allocations by capacity, reused by later adds
   size_t live_count = 0, live_bytes = 0, cached_bytes = 0;
   gloc::DevBuf sort_tmp, sort_keys, sort_vals, sort_perm, stage;
+  gloc::DevBuf kd_k0, kd_k1, kd_v0, kd_v1, kd_p0, kd_p1, kd_box;  // scratch of the kd re-sort
   std::atomic<int> attached{0};  // registration handles using this store
 };
 
@@ -52,6 +55,9 @@ namespace reg {
 int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
                     DevScan* out);
 void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block);
+// Re-sort an indexed scan into kd order (target index) and rebuild everything that depends on the order.
+// Caller holds store->mu; nothing may be reading the scan; returns after the work has completed.
+int store_build_target_index(gloc_scan_store* st, DevScan& s);
 // Build (once) the launch order of a scan for `cs` source points per lane into its own array and point
 // s.order at it.  Caller holds store->mu.
 int store_build_order(gloc_scan_store* st, DevScan& s, int cs);

@@ -83,7 +83,8 @@ class RpyPCLoopDetector:
         """loop_detector.cpp:10-20: append one place (descriptor + its scan [n,3|4])."""
         d = np.ascontiguousarray(descriptor, np.float32).reshape(1, self.k_dim_)
         self._index.add(d)
-        self._db_scan_ids.append(self._reg.scan_upload(scan))
+        # a database place is a registration TARGET for the rest of the run: kd-ordered index (once, ~1 ms)
+        self._db_scan_ids.append(self._reg.scan_build_target_index(self._reg.scan_upload(scan)))
         self._db_grid_ids.append(self._coarse.add_scan(scan))   # loop_detector.cpp:16-19: the place's grid
         self._last_descriptor = d
 

@@ -27,11 +27,13 @@ def scans():
     return dict(A=np.ascontiguousarray(A), B=np.ascontiguousarray(B), C=np.ascontiguousarray(C_), T=T)
 
 
-@pytest.fixture(scope="module", params=["culled", "exhaustive"])
+@pytest.fixture(scope="module", params=["culled", "culled-kd", "exhaustive"])
 def reg(capi, request):
-    """Every registration test runs on both 1-NN search modes: the results must not differ."""
+    """Every registration test runs on both 1-NN search modes, the culled one on both orders of the target
+    index (curve order, and the kd order of gloc_scan_store_build_target_index): the results must not differ."""
     r = capi.Registrar()
-    r.set_option(capi.REG_OPT_NN_MODE, dict(culled=capi.REG_NN_CULLED, exhaustive=capi.REG_NN_EXHAUSTIVE)[request.param])
+    r.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_EXHAUSTIVE if request.param == "exhaustive" else capi.REG_NN_CULLED)
+    r.set_option(capi.REG_OPT_TEMP_TARGET_INDEX, 1 if request.param == "culled-kd" else 0)
     yield r
     r.close()
 
@@ -347,6 +349,52 @@ def test_scan_as_query_and_candidate_with_other_sources_per_lane(capi, scans):
     for r in regs:
         r.close()
     store.close()
+
+
+def test_target_index_changes_no_bit_of_any_result(capi, scans):
+    """gloc_scan_store_build_target_index re-sorts a scan's index into kd order: correspondences, distances,
+    poses, inlier counts -- every output bit stays what it was (the search is exact, ties go to the smallest
+    original index, moments are summed in the SOURCE's order); a scan can still be the source afterwards; ragged
+    sizes (one sub-block, one point more than a power of two, an empty scan) re-sort without harm."""
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    rng = np.random.default_rng(3)
+    clouds = [A, np.ascontiguousarray(Cc[::3]), np.ascontiguousarray(A[:16]), np.ascontiguousarray(A[:2049]),
+              np.ascontiguousarray(B[5::7]), rng.uniform(-30, 30, (4097, 3)).astype(np.float32)]
+    q = [store.add(B), store.add(np.ascontiguousarray(A[3::11]))]
+    ids = [store.add(c) for c in clouds]
+    cand = np.array([ids, ids[::-1]], np.uint32)
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6)
+    r = capi.Registrar(store=store)
+    before = r.batch_multi(q, cand, params=prm)
+    corr_before = [r.debug_corr(j, len(B)) for j in range(len(ids))]
+    for i in ids:
+        store.build_target_index(i)
+    store.build_target_index(ids[0])                      # idempotent
+    after = r.batch_multi(q, cand, params=prm)
+    for k in ("T", "rmse"):
+        assert (bits(after[k]) == bits(before[k])).all(), k
+    assert (after["inliers"] == before["inliers"]).all() and (after["ok"] == before["ok"]).all()
+    for j, (ci, cd) in enumerate(corr_before):            # the last pass's correspondences, caller's index space
+        ai, ad = r.debug_corr(j, len(B))
+        assert (ai == ci).all() and (bits(ad) == bits(cd)).all(), j
+    assert (store.download(ids[3]) == clouds[3]).all()    # the caller's copy of the points is untouched
+    # a re-sorted scan as the SOURCE of a registration (its launch orders are rebuilt), and as both at once
+    s2 = r.batch_multi([ids[0], q[0]], np.array([[q[0], ids[1]], [ids[0], ids[1]]], np.uint32), params=prm)
+    fresh = capi.ScanStore()
+    f_ids = [fresh.add(x) for x in (A, B, clouds[1])]
+    r2 = capi.Registrar(store=fresh)
+    s1 = r2.batch_multi([f_ids[0], f_ids[1]], np.array([[f_ids[1], f_ids[2]], [f_ids[0], f_ids[2]]], np.uint32), params=prm)
+    # (the source's own order changed with its index: its moments are summed per wave of that order)
+    assert (s2["inliers"] == s1["inliers"]).all() and (s2["ok"] == s1["ok"]).all() and np.abs(s2["T"] - s1["T"]).max() < 2e-6
+    e = store.add(np.zeros((0, 3), np.float32))
+    store.build_target_index(e)
+    with pytest.raises(capi.GlocError):
+        store.build_target_index(12345)
+    r.close()
+    r2.close()
+    store.close()
+    fresh.close()
 
 
 def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):

@@ -656,11 +656,11 @@ def main():
         a, b = my_slice(i, Bq)
         if args.mode == "throughput":
             tables = qreg.register_many(ids, cand, dev, register_multi, capi_knn=capi_knn)   # [world*B, 20, 19]
-            sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
         else:
-            table = sreg.register(ids[0], cand[0], dev)
-            tables = table[None]
-            sel = [sreg.select_first_ok(table)]
+            tables = sreg.register(ids[0], cand[0], dev)[None]
+        if not isinstance(tables, np.ndarray):
+            tables = tables.detach().cpu().numpy()     # one D2H of the gathered tables; the selection rule runs on the host
+        sel = [sharded.ShardedRegistrar.select_first_ok(t) for t in tables]
         for sid in ids:
             reg.scan_release(sid)
             if cm is not None:
@@ -697,7 +697,7 @@ def main():
             sels_.extend(sel)
             if keep:
                 cands_.append(cand)
-                tabs_.append(tables.detach().cpu().numpy())
+                tabs_.append(tables)
         fence()
         return time.time() - t0, sels_, cands_, tabs_
 

@@ -147,7 +147,11 @@ class ShardedRegistrar:
 
     @staticmethod
     def select_first_ok(table):
-        """Lowest retrieval rank whose registration succeeded, or -1 (global_localization.cpp:519)."""
+        """Lowest retrieval rank whose registration succeeded, or -1 (global_localization.cpp:519).
+        table: [n, RESULT_COLS], numpy or torch."""
+        if isinstance(table, np.ndarray):
+            ok = np.flatnonzero(table[:, 18] > 0.5)
+            return int(ok[0]) if ok.size else -1
         ok = (table[:, 18] > 0.5).nonzero()
         return int(ok[0, 0]) if ok.numel() else -1
 
@@ -186,15 +190,15 @@ class QueryParallelRegistrar:
         rows r*K .. r*K+K-1 of cand_global_all [G*K, n].  register_multi(query handles [K], global place
         ids [K, n] (-1 = none)) -> float32 [K, n, RESULT_COLS] registers them in ONE batch (every kernel
         launch covers the K x n candidates: gloc_reg_batch_multi).  One all-gather of the K result
-        tables.  Returns [G*K, n, RESULT_COLS]."""
+        tables.  Returns [G*K, n, RESULT_COLS] (a numpy array at G = 1, else a tensor on `device`)."""
         cand = np.asarray(cand_global_all, dtype=np.int64)
         K, n = len(my_queries), cand.shape[1]
         assert cand.shape[0] == self.world * K
         tables = np.ascontiguousarray(register_multi(my_queries, cand[self.rank * K:(self.rank + 1) * K]),
                                       np.float32)
-        t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
         if self.world == 1:
-            return t.to(device).view(K, n, RESULT_COLS)
+            return tables.reshape(K, n, RESULT_COLS)   # (host memory: the results already are there, nothing to exchange)
+        t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
         if capi_knn is not None:   # the all-gather through the C ABI's communicator
             return capi_knn.all_gather_tables(t.to(device).view(K, n, RESULT_COLS))
         t = t.to(self.comm_device or device)

@@ -1,6 +1,6 @@
-"""profiles/r02_pmc_traffic_nn_compact.json from a tools/profile_bench.sh PMC summary (pmc_summary.py --json).
+"""profiles/rNN_pmc_traffic_nn_compact.json from a tools/profile_bench.sh PMC summary (pmc_summary.py --json).
 
-Usage: python tools/pmc_traffic_json.py gpurun_out/<tag>_pmc_summary.json gpurun_out/<tag>_under_rocprof.json > profiles/r02_pmc_traffic_nn_compact.json
+Usage: python tools/pmc_traffic_json.py gpurun_out/<tag>_pmc_summary.json gpurun_out/<tag>_under_rocprof.json [round] > profiles/r03_pmc_traffic_nn_compact.json
 The second file is the bench line of the same command (algorithmic bytes and jobs per launch come from it).
 """
 import json, sys
@@ -16,9 +16,9 @@ waves = c["SQ_WAVES"]
 # SQ_BUSY_CYCLES sums the 32 shader engines; SQ_ACTIVE_INST_VALU counts quad-cycles over the 1024 SIMDs
 busy_cycles = c["SQ_BUSY_CYCLES"] / 32.0
 out = {
-    "round": 2,
+    "round": int(sys.argv[3]) if len(sys.argv) > 3 else 3,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_HIT_sum TCC_MISS_sum (separate passes, "
-              "tools/profile_bench.sh) over `python3 bench.py --no-cpu-baseline --no-lone-query --steps 4 --warmup 1 --reps 1`: "
+              "tools/profile_bench.sh) over `python3 bench.py --no-cpu-baseline --no-legs --steps 4 --warmup 1 --reps 1`: "
               f"{c['dispatches']} launches of {roof['jobs_per_launch']:.0f} jobs each; written by tools/pmc_traffic_json.py",
     "kernel": k.replace("void ", ""),
     "jobs_per_launch": roof["jobs_per_launch"],
@@ -38,8 +38,6 @@ out = {
     "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / busy_cycles,
     "valu_busy_note": "SQ_ACTIVE_INST_VALU (quad-cycles, summed over 1024 SIMDs) x 4 / 1024 over SQ_BUSY_CYCLES / 32 shader engines",
     "job_group": 24,
-    "job_group_60_fetch_size_kb_per_launch": 3403387.9,
-    "job_group_note": "round-2 first state (job group 60, not a multiple of the 8 XCDs): FETCH_SIZE 3.40e6 KB per launch -> 3.0x "
-                      "the algorithmic bytes; with 24 every job's work-groups stay on one XCD and its scans in that L2",
+    "database_scans_target_index": bench["config"].get("database_scans_target_index"),
 }
 print(json.dumps(out, indent=1))

@@ -3,7 +3,7 @@ set -e
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; bench.build_views('/tmp/views.npz')"
-B="python3 $R/bench.py --no-cpu-baseline --no-lone-query --views-cache /tmp/views.npz --steps 2 --warmup 1 --reps 1"
+B="python3 $R/bench.py --no-cpu-baseline --no-legs --views-cache /tmp/views.npz --steps 2 --warmup 1 --reps 1"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $O/valu1 -o p -- $B > /dev/null 2> $O/valu1.err
 cd $R
 python3 tools/pmc_summary.py $O/valu1 --match nn_compact --json $O/valu_summary.json > $O/valu_summary.txt

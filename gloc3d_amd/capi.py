@@ -131,6 +131,8 @@ _PROTOS = [
     ("gloc_scan_store_add_device", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_scan_store_add_variant", _i, [_vp, _u32, _vp, C.c_float, _u64, C.POINTER(_u32)]),
     ("gloc_scan_store_build_target_index", _i, [_vp, _u32]),
+    ("gloc_scan_store_build_target_index_batch", _i, [_vp, _vp, _sz]),
+    ("gloc_scan_store_add_batch", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     ("gloc_scan_store_release", _i, [_vp, _u32]),
     ("gloc_scan_store_clear", _i, [_vp]),
     ("gloc_scan_store_count", _i, [_vp, C.POINTER(_sz)]),
@@ -448,10 +450,38 @@ class ScanStore:
                                                 float(noise_sigma), int(seed), C.byref(sid)))
         return sid.value
 
+    def add_batch(self, scans):
+        """Several scans ([n_i, c] float32 arrays with the same number of columns) in one launch sequence."""
+        arrs = [np.ascontiguousarray(p, np.float32) for p in scans]
+        cols = arrs[0].shape[1]
+        assert all(a.ndim == 2 and a.shape[1] == cols for a in arrs) and 3 <= cols <= 16
+        k = len(arrs)
+        ptrs = (C.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        cnts = (C.c_size_t * k)(*[a.shape[0] for a in arrs])
+        ids = np.empty(k, np.uint32)
+        check(lib().gloc_scan_store_add_batch(self._h, ptrs, cnts, k, cols, _np_ptr(ids)))
+        return [int(i) for i in ids]
+
     def build_target_index(self, scan_id):
         """Re-sort the scan's index into kd order: for scans that serve as registration targets (database places)."""
         check(lib().gloc_scan_store_build_target_index(self._h, int(scan_id)))
         return scan_id
+
+    def debug_index(self, scan_id):
+        """Test aid: the scan's index as the search sees it -- dict(perm, keys, kpos, order2, kd)."""
+        f = lib().gloc_scan_store_debug_index
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        n = self.points(scan_id)
+        perm, keys, kpos = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint32)
+        order2 = np.empty((n + 127) // 128, np.uint32)
+        kd = C.c_int()
+        check(f(self._h, int(scan_id), _np_ptr(perm), _np_ptr(keys), _np_ptr(kpos), _np_ptr(order2), C.byref(kd)))
+        return dict(perm=perm, keys=keys, kpos=kpos, order2=order2, kd=bool(kd.value))
+
+    def build_target_index_batch(self, scan_ids):
+        ids = np.ascontiguousarray(scan_ids, np.uint32).reshape(-1)
+        check(lib().gloc_scan_store_build_target_index_batch(self._h, _np_ptr(ids), ids.shape[0]))
 
     def release(self, scan_id):
         check(lib().gloc_scan_store_release(self._h, int(scan_id)))

@@ -2,37 +2,52 @@
 // scan of the reference's GlocEvaluator (db_files_, read again from disk for every candidate at
 // registration/global_localization.cpp:521-525) is kept in HBM together with its search index, shared
 // by any number of registration handles; query scans are added, used and released.
-// Indexing runs entirely on the device (no host pass over the points).
+// Indexing runs entirely on the device (no host pass over the points), and for ANY NUMBER OF SCANS AT ONCE
+// with the same launches: every kernel takes the scan from blockIdx.y and a descriptor table, every sort is
+// the segmented radix sort of seg_sort.hpp with one segment per scan.  Adding the 25 query scans of a step is
+// one sequence of ~35 launches (round 2: ~25 launches per scan, a third of them inside hipCUB's merge sort);
+// re-sorting a KITTI-00-sized database into kd order is 71 batches of 64 scans.
 #include <algorithm>
 #include <new>
 
-#include <hipcub/hipcub.hpp>
-
 #include "scan_store.hpp"
+#include "seg_sort.hpp"
 #include "synth_kernels.hpp"
 
 namespace gloc {
 namespace reg {
 
-__global__ void scan_header_init_kernel(ScanHeader* hdr) {
-  if (threadIdx.x == 0) {
-    hdr->ox = hdr->oy = hdr->oz = 0.f;
-    hdr->inv_cell = 4.f;
-    for (int a = 0; a < 3; ++a) {
-      hdr->lo[a] = 0xFFFFFFFFu;
-      hdr->hi[a] = 0u;
-    }
-  }
-}
+constexpr int PACK_BLOCKS = 128;  // work-groups of the bounding-box pass per scan
+
+// Device-visible description of one scan being indexed (one per blockIdx.y).
+struct ScanBuild {
+  const float* in;  // source points on the device, `stride` floats apart
+  ScanHeader* hdr;
+  float* xyz;
+  f32x4* pts;
+  f32x4* lo;
+  f32x4* hi;
+  f32x4* sb2;
+  f32x4* ulo;
+  f32x4* uhi;
+  uint32_t* keys;
+  uint32_t* inv;
+  uint32_t* order;  // the launch order being built (one sources-per-lane setting)
+  uint32_t n, stride, n_pad, nch, nsup, npairs, n_groups, group;
+  uint32_t key_off;  // this scan's slice of the concatenated sort arrays (points)
+  uint32_t grp_off;  // ... and of the group arrays
+  uint32_t pad_[2];
+};
 
 // strided (x, y, z, ...) -> packed xyz, and the bounding box: every work-group leaves its partial box
-// in `part` ([gridDim.x][6] order-preserving integers), reduced by scan_header_finish_kernel -- no
+// in `part` ([scan][PACK_BLOCKS][6] order-preserving integers), reduced by header_finish_kernel -- no
 // atomics (the first version's six atomics per wave on one cache line cost 134 us per 123k-point scan).
-constexpr int PACK_BLOCKS = 128;
-__global__ __launch_bounds__(256) void pack_bbox_kernel(const float* __restrict__ in, uint32_t n,
-                                                        uint32_t stride, float* __restrict__ xyz,
-                                                        uint32_t* __restrict__ part) {
+__global__ __launch_bounds__(256) void pack_bbox_kernel(const ScanBuild* __restrict__ sbs, uint32_t* __restrict__ part_all) {
   __shared__ uint32_t red[4][6];
+  const ScanBuild& sb = sbs[blockIdx.y];
+  const uint32_t n = sb.n, stride = sb.stride;
+  const float* __restrict__ in = sb.in;
+  float* __restrict__ xyz = sb.xyz;
   uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float v[3];
@@ -68,21 +83,24 @@ __global__ __launch_bounds__(256) void pack_bbox_kernel(const float* __restrict_
       const uint32_t x = red[ww][threadIdx.x];
       v = threadIdx.x < 3 ? (x < v ? x : v) : (x > v ? x : v);
     }
-    part[blockIdx.x * 6 + threadIdx.x] = v;
+    part_all[((size_t)blockIdx.y * PACK_BLOCKS + blockIdx.x) * 6 + threadIdx.x] = v;
   }
 }
 
-// one wave: reduce the partial boxes, derive the key grid
-__global__ __launch_bounds__(64) void scan_header_finish_kernel(ScanHeader* hdr, const uint32_t* __restrict__ part,
-                                                                uint32_t n_part) {
+// one wave per scan: reduce the partial boxes, derive the key grid (an empty scan gets a default header)
+__global__ __launch_bounds__(64) void header_finish_kernel(const ScanBuild* __restrict__ sbs, const uint32_t* __restrict__ part_all) {
+  const ScanBuild& sb = sbs[blockIdx.x];
+  ScanHeader* hdr = sb.hdr;
+  const uint32_t* part = part_all + (size_t)blockIdx.x * PACK_BLOCKS * 6;
   uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-  for (uint32_t b = threadIdx.x; b < n_part; b += 64)
+  if (sb.n)
+    for (uint32_t b = threadIdx.x; b < PACK_BLOCKS; b += 64)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const uint32_t l = part[b * 6 + a], h = part[b * 6 + 3 + a];
-      lo[a] = l < lo[a] ? l : lo[a];
-      hi[a] = h > hi[a] ? h : hi[a];
-    }
+      for (int a = 0; a < 3; ++a) {
+        const uint32_t l = part[b * 6 + a], h = part[b * 6 + 3 + a];
+        lo[a] = l < lo[a] ? l : lo[a];
+        hi[a] = h > hi[a] ? h : hi[a];
+      }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
     for (int o = 32; o > 0; o >>= 1) {
@@ -95,6 +113,11 @@ __global__ __launch_bounds__(64) void scan_header_finish_kernel(ScanHeader* hdr,
     hdr->lo[a] = lo[a];
     hdr->hi[a] = hi[a];
   }
+  if (!sb.n) {
+    hdr->ox = hdr->oy = hdr->oz = 0.f;
+    hdr->inv_cell = 4.f;
+    return;
+  }
   const float mn0 = ord2f(lo[0]), mn1 = ord2f(lo[1]), mn2 = ord2f(lo[2]);
   const float e0 = ord2f(hi[0]) - mn0, e1 = ord2f(hi[1]) - mn1, e2 = ord2f(hi[2]) - mn2;
   const float ext = fmaxf(fmaxf(e0, e1), e2);
@@ -105,36 +128,40 @@ __global__ __launch_bounds__(64) void scan_header_finish_kernel(ScanHeader* hdr,
   hdr->inv_cell = 1.0f / cell;
 }
 
-__global__ void morton_keys_kernel(const float* __restrict__ xyz, uint32_t n,
-                                   const ScanHeader* __restrict__ hdr, uint32_t* __restrict__ keys,
-                                   uint32_t* __restrict__ vals) {
+__global__ void curve_keys_kernel(const ScanBuild* __restrict__ sbs, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const ScanBuild& sb = sbs[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = morton_key(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], hdr->ox,
-                       hdr->oy, hdr->oz, hdr->inv_cell);
-  vals[i] = i;
+  if (i >= sb.n) return;
+  const float* xyz = sb.xyz;
+  const ScanHeader* hdr = sb.hdr;
+  keys[sb.key_off + i] = morton_key(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], hdr->ox, hdr->oy,
+                                    hdr->oz, hdr->inv_cell);
+  vals[sb.key_off + i] = i;
 }
 
-__global__ void gather_sorted_kernel(const float* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                     uint32_t n, uint32_t n_pad, f32x4* __restrict__ pts,
-                                     uint32_t* __restrict__ inv) {
+__global__ void gather_sorted_kernel(const ScanBuild* __restrict__ sbs, const uint32_t* __restrict__ skeys,
+                                     const uint32_t* __restrict__ perm) {
+  const ScanBuild& sb = sbs[blockIdx.y];
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_pad) return;
-  if (s >= n) {  // padding of the last chunk: farther than any real point, an index that never wins a tie
-    pts[s] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
+  if (s >= sb.n_pad) return;
+  if (s >= sb.n) {  // padding of the last chunk: farther than any real point, an index that never wins a tie
+    sb.pts[s] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
     return;
   }
-  const uint32_t o = perm[s];
-  pts[s] = f32x4{xyz[3 * (size_t)o], xyz[3 * (size_t)o + 1], xyz[3 * (size_t)o + 2],
-                 __uint_as_float(o)};
-  inv[o] = s;
+  const uint32_t o = perm[sb.key_off + s];
+  const float* xyz = sb.xyz;
+  sb.pts[s] = f32x4{xyz[3 * (size_t)o], xyz[3 * (size_t)o + 1], xyz[3 * (size_t)o + 2], __uint_as_float(o)};
+  sb.inv[o] = s;
+  sb.keys[s] = skeys[sb.key_off + s];
 }
 
 // one wave per chunk
-__global__ __launch_bounds__(64) void chunk_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n,
-                                                         f32x4* __restrict__ lo,
-                                                         f32x4* __restrict__ hi) {
+__global__ __launch_bounds__(64) void chunk_boxes_kernel(const ScanBuild* __restrict__ sbs) {
+  const ScanBuild& sb = sbs[blockIdx.y];
   const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  if (c >= sb.nch) return;
+  const f32x4* __restrict__ pts = sb.pts;
+  const uint32_t n = sb.n;
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   for (uint32_t t = lane; t < CH; t += 64) {
     const uint32_t j = c * CH + t;
@@ -151,19 +178,19 @@ __global__ __launch_bounds__(64) void chunk_boxes_kernel(const f32x4* __restrict
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
     }
   if (lane == 0) {
-    lo[c] = f32x4{mn[0], mn[1], mn[2], 0.f};
-    hi[c] = f32x4{mx[0], mx[1], mx[2], 0.f};
+    sb.lo[c] = f32x4{mn[0], mn[1], mn[2], 0.f};
+    sb.hi[c] = f32x4{mx[0], mx[1], mx[2], 0.f};
   }
 }
 
 // one wave per super-chunk: the union of 64 chunk boxes
-__global__ __launch_bounds__(64) void super_boxes_kernel(const f32x4* __restrict__ lo, const f32x4* __restrict__ hi,
-                                                         uint32_t nchunks, f32x4* __restrict__ slo,
-                                                         f32x4* __restrict__ shi) {
+__global__ __launch_bounds__(64) void super_boxes_kernel(const ScanBuild* __restrict__ sbs) {
+  const ScanBuild& sb = sbs[blockIdx.y];
+  if (blockIdx.x >= sb.nsup) return;
   const uint32_t c = blockIdx.x * 64 + threadIdx.x;
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-  if (c < nchunks) {
-    const f32x4 a = lo[c], b = hi[c];
+  if (c < sb.nch) {
+    const f32x4 a = sb.lo[c], b = sb.hi[c];
     mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
     mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
   }
@@ -173,17 +200,18 @@ __global__ __launch_bounds__(64) void super_boxes_kernel(const f32x4* __restrict
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
     }
   if (threadIdx.x == 0) {
-    slo[blockIdx.x] = f32x4{mn[0], mn[1], mn[2], 0.f};
-    shi[blockIdx.x] = f32x4{mx[0], mx[1], mx[2], 0.f};
+    sb.ulo[blockIdx.x] = f32x4{mn[0], mn[1], mn[2], 0.f};
+    sb.uhi[blockIdx.x] = f32x4{mx[0], mx[1], mx[2], 0.f};
   }
 }
 
-// one thread per sub-block of SB points
 // one thread per PAIR of sub-blocks; a sub-block past the end of the scan gets an empty (inverted) box
-__global__ void subblock_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n, uint32_t npairs,
-                                      f32x4* __restrict__ sb2) {
+__global__ void subblock_boxes_kernel(const ScanBuild* __restrict__ sbs) {
+  const ScanBuild& sb = sbs[blockIdx.y];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= npairs) return;
+  if (b >= sb.npairs) return;
+  const f32x4* __restrict__ pts = sb.pts;
+  const uint32_t n = sb.n;
   float mn[2][3], mx[2][3];
   for (int h = 0; h < 2; ++h) {
     for (int a = 0; a < 3; ++a) {
@@ -200,21 +228,25 @@ __global__ void subblock_boxes_kernel(const f32x4* __restrict__ pts, uint32_t n,
       }
     }
   }
+  f32x4* sb2 = sb.sb2;
   sb2[3 * (size_t)b + 0] = f32x4{mn[0][0], mn[1][0], mn[0][1], mn[1][1]};
   sb2[3 * (size_t)b + 1] = f32x4{mn[0][2], mn[1][2], mx[0][0], mx[1][0]};
   sb2[3 * (size_t)b + 2] = f32x4{mx[0][1], mx[1][1], mx[0][2], mx[1][2]};
 }
 
-// Spatial extent of every group of `group` consecutive (Hilbert-sorted) points: the squared diagonal
-// of its bounding box.  A wave's sweep cost grows with the extent of its sources (more chunk boxes
-// pass the wave-level test), so launching the widest groups first keeps the stragglers off the tail.
-// One wave per group.
-__global__ __launch_bounds__(256) void group_extent_kernel(const f32x4* __restrict__ pts, uint32_t n,
-                                                            uint32_t group, uint32_t n_groups,
-                                                            float* __restrict__ ext, uint32_t* __restrict__ ids) {
+// Spatial extent of every group of `group` consecutive sorted points: the squared diagonal of its bounding
+// box.  A wave's sweep cost grows with the extent of its sources (more chunk boxes pass the wave-level test),
+// so launching the widest groups first keeps the stragglers off the tail.  One wave per group.  The sort key
+// is the complement of the extent's order-preserving integer: ascending keys = widest first, and equal
+// extents keep ascending group ids (the sort is stable).
+__global__ __launch_bounds__(256) void group_extent_kernel(const ScanBuild* __restrict__ sbs, uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ ids) {
+  const ScanBuild& sb = sbs[blockIdx.y];
   const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (g >= n_groups) return;
+  if (g >= sb.n_groups) return;
+  const f32x4* __restrict__ pts = sb.pts;
+  const uint32_t n = sb.n, group = sb.group;
   float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   for (uint32_t i = g * group + lane; i < (g + 1) * group && i < n; i += 64) {
     const f32x4 p = pts[i];
@@ -230,9 +262,15 @@ __global__ __launch_bounds__(256) void group_extent_kernel(const f32x4* __restri
     }
   if (lane == 0) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    ext[g] = dx * dx + dy * dy + dz * dz;
-    ids[g] = g;
+    keys[sb.grp_off + g] = ~f2ord(dx * dx + dy * dy + dz * dz);
+    ids[sb.grp_off + g] = g;
   }
+}
+
+__global__ void copy_order_kernel(const ScanBuild* __restrict__ sbs, const uint32_t* __restrict__ ids) {
+  const ScanBuild& sb = sbs[blockIdx.y];
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < sb.n_groups) sb.order[g] = ids[sb.grp_off + g];
 }
 
 
@@ -256,27 +294,52 @@ __global__ void scan_variant_kernel(const float* __restrict__ xyz, uint32_t n, c
   out[3 * (size_t)i + 2] = z + nz;
 }
 
-
 // ---- kd order (target index): see scan_index.hpp -------------------------------------------------------
 // The scan is already in curve order.  P = 16 * 2^L >= n positions form a complete binary tree; at level
 // l a node is the aligned block of (P >> l) positions.  Level by level (top down) every node's points are
 // sorted along the widest axis of their bounding box, so that its lower half -- the left child -- holds the
-// smaller coordinates: one device-wide radix sort per level by (node, coordinate), stable, so that equal
+// smaller coordinates: one segmented radix sort per level by (node, coordinate), stable, so that equal
 // coordinates keep their current (deterministic) order.  Positions >= n are never materialised: they stand
-// for points at +infinity, which stay at the end of their node under every sort.
-__global__ void kd_box_init_kernel(uint32_t* __restrict__ box, uint32_t nodes) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nodes) return;
+// for points at +infinity, which stay at the end of their node under every sort.  All scans of a batch go
+// through every level together (a scan with fewer levels keeps its order once it is done).
+struct ScanKd {
+  f32x4* pts;      // the scan's sorted points (read first, written back last)
+  uint32_t* inv;
+  uint32_t* kpos;
+  uint32_t n, n_pad, levels;
+  uint32_t off;      // slice of the concatenated working arrays
+  uint32_t box_off;  // slice of the node boxes (6 words per node)
+  uint32_t pad_;
+};
+
+__global__ void kd_load_kernel(const ScanKd* __restrict__ ks, f32x4* __restrict__ p, uint32_t* __restrict__ h) {
+  const ScanKd& k = ks[blockIdx.y];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k.n) return;
+  p[k.off + i] = k.pts[i];
+  h[k.off + i] = i;  // its position in curve order
+}
+
+__global__ void kd_box_init_kernel(const ScanKd* __restrict__ ks, uint32_t level, uint32_t* __restrict__ box) {
+  const ScanKd& k = ks[blockIdx.y];
+  const uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (level >= k.levels || nd >= (1u << level)) return;
+  uint32_t* b = box + k.box_off + 6 * (size_t)nd;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    box[6 * k + a] = 0xFFFFFFFFu;
-    box[6 * k + 3 + a] = 0u;
+    b[a] = 0xFFFFFFFFu;
+    b[3 + a] = 0u;
   }
 }
 
 // one thread per block of 16 points; a wave's 64 blocks lie in ONE node when the node holds >= 1024 positions
-__global__ __launch_bounds__(256) void kd_node_bbox_kernel(const f32x4* __restrict__ p, uint32_t n, uint32_t shift,
-                                                           uint32_t* __restrict__ box) {
+__global__ __launch_bounds__(256) void kd_node_bbox_kernel(const ScanKd* __restrict__ ks, uint32_t level,
+                                                           const f32x4* __restrict__ p_all, uint32_t* __restrict__ box) {
+  const ScanKd& k = ks[blockIdx.y];
+  if (level >= k.levels) return;
+  const uint32_t shift = 4 + k.levels - level;  // log2 of the node size (SB = 16 = 2^4 points per leaf)
+  const uint32_t n = k.n;
+  const f32x4* __restrict__ p = p_all + k.off;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i0 = b * 16u;
   uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
@@ -305,7 +368,7 @@ __global__ __launch_bounds__(256) void kd_node_bbox_kernel(const f32x4* __restri
     if ((threadIdx.x & 63) != 0) return;
   }
   if (lo[0] > hi[0]) return;  // no point in this block / wave
-  uint32_t* o = box + 6 * (size_t)(first >> shift);
+  uint32_t* o = box + k.box_off + 6 * (size_t)(first >> shift);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     atomicMin(o + a, lo[a]);
@@ -313,52 +376,55 @@ __global__ __launch_bounds__(256) void kd_node_bbox_kernel(const f32x4* __restri
   }
 }
 
-__global__ void kd_keys_kernel(const f32x4* __restrict__ p, uint32_t n, uint32_t shift, const uint32_t* __restrict__ box,
-                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void kd_keys_kernel(const ScanKd* __restrict__ ks, uint32_t level, const f32x4* __restrict__ p_all,
+                               const uint32_t* __restrict__ box, unsigned long long* __restrict__ keys,
+                               uint32_t* __restrict__ vals) {
+  const ScanKd& k = ks[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= k.n) return;
+  vals[k.off + i] = i;
+  if (level >= k.levels) {  // this scan is done: keep its order
+    keys[k.off + i] = i;
+    return;
+  }
+  const uint32_t shift = 4 + k.levels - level;
   const uint32_t node = i >> shift;
-  const uint32_t* b = box + 6 * (size_t)node;
+  const uint32_t* b = box + k.box_off + 6 * (size_t)node;
   const float ex = ord2f(b[3]) - ord2f(b[0]), ey = ord2f(b[4]) - ord2f(b[1]), ez = ord2f(b[5]) - ord2f(b[2]);
-  int axis = 0;           // the widest axis; ties -> the lower axis
+  int axis = 0;  // the widest axis; ties -> the lower axis
   float e = ex;
   if (ey > e) { axis = 1; e = ey; }
   if (ez > e) axis = 2;
-  const f32x4 v = p[i];
+  const f32x4 v = p_all[k.off + i];
   const float c = axis == 0 ? v.x : (axis == 1 ? v.y : v.z);
-  keys[i] = ((unsigned long long)node << 32) | f2ord(c);
-  vals[i] = i;
+  keys[k.off + i] = ((unsigned long long)node << 32) | f2ord(c);
 }
 
-__global__ void kd_gather_kernel(const f32x4* __restrict__ p_in, const uint32_t* __restrict__ h_in,
-                                 const uint32_t* __restrict__ perm, uint32_t n, f32x4* __restrict__ p_out,
-                                 uint32_t* __restrict__ h_out) {
+__global__ void kd_gather_kernel(const ScanKd* __restrict__ ks, const f32x4* __restrict__ p_in,
+                                 const uint32_t* __restrict__ h_in, const uint32_t* __restrict__ perm,
+                                 f32x4* __restrict__ p_out, uint32_t* __restrict__ h_out) {
+  const ScanKd& k = ks[blockIdx.y];
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t s = perm[j];
-  p_out[j] = p_in[s];
-  h_out[j] = h_in[s];
-}
-
-__global__ void kd_iota_kernel(uint32_t* __restrict__ h, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) h[i] = i;
+  if (j >= k.n) return;
+  const uint32_t s = perm[k.off + j];
+  p_out[k.off + j] = p_in[k.off + s];
+  h_out[k.off + j] = h_in[k.off + s];
 }
 
 // the re-sorted points back into the scan: pts (kd order, padded), inv (original index -> kd position), kpos
 // (curve position -> kd position)
-__global__ void kd_finish_kernel(const f32x4* __restrict__ p, const uint32_t* __restrict__ h, uint32_t n, uint32_t n_pad,
-                                 f32x4* __restrict__ pts, uint32_t* __restrict__ inv, uint32_t* __restrict__ kpos) {
+__global__ void kd_finish_kernel(const ScanKd* __restrict__ ks, const f32x4* __restrict__ p, const uint32_t* __restrict__ h) {
+  const ScanKd& k = ks[blockIdx.y];
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_pad) return;
-  if (j >= n) {
-    pts[j] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
+  if (j >= k.n_pad) return;
+  if (j >= k.n) {
+    k.pts[j] = f32x4{NN_FAR, NN_FAR, NN_FAR, __uint_as_float(0xFFFFFFFFu)};
     return;
   }
-  const f32x4 v = p[j];
-  pts[j] = v;
-  inv[__float_as_uint(v.w)] = j;
-  kpos[h[j]] = j;
+  const f32x4 v = p[k.off + j];
+  k.pts[j] = v;
+  k.inv[__float_as_uint(v.w)] = j;
+  k.kpos[h[k.off + j]] = j;
 }
 
 namespace {
@@ -413,6 +479,68 @@ int take_block(gloc_scan_store* st, size_t bytes, void** out, size_t* cap) {
   return GLOC_OK;
 }
 
+ScanBuild build_desc(const DevScan& s, const Layout& L) {
+  ScanBuild b{};
+  b.hdr = const_cast<ScanHeader*>(s.idx.hdr);
+  b.xyz = s.xyz;
+  b.pts = const_cast<f32x4*>(s.idx.pts);
+  b.lo = const_cast<f32x4*>(s.idx.box_lo);
+  b.hi = const_cast<f32x4*>(s.idx.box_hi);
+  b.sb2 = const_cast<f32x4*>(s.idx.sb2);
+  b.ulo = const_cast<f32x4*>(s.idx.sup_lo);
+  b.uhi = const_cast<f32x4*>(s.idx.sup_hi);
+  b.keys = const_cast<uint32_t*>(s.idx.keys);
+  b.inv = const_cast<uint32_t*>(s.idx.inv);
+  b.n = (uint32_t)s.n;
+  b.stride = 3;
+  b.n_pad = (uint32_t)L.np;
+  b.nch = s.idx.nchunks;
+  b.nsup = s.idx.nsup;
+  b.npairs = (uint32_t)(L.b1 / 3);
+  return b;
+}
+
+// boxes of all levels from the sorted points (whatever order they are in)
+void launch_boxes(hipStream_t q, const ScanBuild* d_sb, uint32_t count, uint32_t max_nch, uint32_t max_npairs,
+                  uint32_t max_nsup) {
+  if (!max_nch) return;
+  hipLaunchKernelGGL(chunk_boxes_kernel, dim3(max_nch, count), dim3(64), 0, q, d_sb);
+  hipLaunchKernelGGL(subblock_boxes_kernel, dim3((max_npairs + 255) / 256, count), dim3(256), 0, q, d_sb);
+  hipLaunchKernelGGL(super_boxes_kernel, dim3(max_nsup, count), dim3(64), 0, q, d_sb);
+}
+
+// launch orders for `cs` sources per lane of scans whose descriptors (with order / n_groups / group / grp_off set)
+// are already on the device; total_groups = sum of n_groups
+int launch_orders(gloc_scan_store* st, const ScanBuild* d_sb, const std::vector<ScanBuild>& hb, uint32_t count) {
+  hipStream_t q = st->stream;
+  uint32_t total = 0, max_ng = 0;
+  std::vector<segsort::Seg> segs(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    segs[i] = segsort::Seg{hb[i].grp_off, hb[i].n_groups};
+    total = std::max(total, hb[i].grp_off + hb[i].n_groups);
+    max_ng = std::max(max_ng, hb[i].n_groups);
+  }
+  if (!max_ng) return GLOC_OK;
+  GLOC_TRY(st->grp_k0.ensure(sizeof(uint32_t) * total, q));
+  GLOC_TRY(st->grp_k1.ensure(sizeof(uint32_t) * total, q));
+  GLOC_TRY(st->grp_v0.ensure(sizeof(uint32_t) * total, q));
+  GLOC_TRY(st->grp_v1.ensure(sizeof(uint32_t) * total, q));
+  GLOC_TRY(st->grp_segs.ensure(sizeof(segsort::Seg) * count, q));
+  GLOC_TRY(st->sort_hist.ensure(segsort::scratch_bytes(count, max_ng), q));
+  GLOC_HIP(hipMemcpyAsync(st->grp_segs.p, segs.data(), sizeof(segsort::Seg) * count, hipMemcpyHostToDevice, q));
+  hipLaunchKernelGGL(group_extent_kernel, dim3((max_ng + 3) / 4, count), dim3(256), 0, q, d_sb, st->grp_k0.as<uint32_t>(),
+                     st->grp_v0.as<uint32_t>());
+  const int r = segsort::sort_pairs<uint32_t>(q, st->grp_k0.as<uint32_t>(), st->grp_k1.as<uint32_t>(),
+                                              st->grp_v0.as<uint32_t>(), st->grp_v1.as<uint32_t>(),
+                                              st->grp_segs.as<segsort::Seg>(), count, max_ng, 0, 32,
+                                              st->sort_hist.as<uint32_t>());
+  hipLaunchKernelGGL(copy_order_kernel, dim3((max_ng + 255) / 256, count), dim3(256), 0, q, d_sb,
+                     r ? st->grp_v1.as<uint32_t>() : st->grp_v0.as<uint32_t>());
+  GLOC_HIP(hipGetLastError());
+  GLOC_HIP(hipStreamSynchronize(q));  // (segs is a local: the copy must have been consumed)
+  return GLOC_OK;
+}
+
 }  // namespace
 
 void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block) {
@@ -439,179 +567,256 @@ int store_build_order(gloc_scan_store* st, DevScan& s, int cs) {
   s.order = s.order_of(cs);
   if ((s.order_built & (1u << cs)) || s.n == 0) return GLOC_OK;
   hipStream_t q = st->stream;
-  const uint32_t group = 64u * (uint32_t)cs;
-  const uint32_t ng = (uint32_t)((s.n + group - 1) / group);
-  GLOC_TRY(st->sort_keys.ensure(sizeof(float) * std::max<size_t>(ng, s.n), q));
-  GLOC_TRY(st->sort_vals.ensure(sizeof(uint32_t) * std::max<size_t>(ng, s.n), q));
-  GLOC_TRY(st->sort_perm.ensure(sizeof(float) * std::max<size_t>(ng, s.n), q));
-  hipLaunchKernelGGL(group_extent_kernel, dim3((ng + 3) / 4), dim3(256), 0, q, s.idx.pts, (uint32_t)s.n, group,
-                     ng, st->sort_keys.as<float>(), st->sort_vals.as<uint32_t>());
-  size_t tmp_bytes = 0;
-  GLOC_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, st->sort_keys.as<float>(),
-                                                        st->sort_perm.as<float>(), st->sort_vals.as<uint32_t>(),
-                                                        s.order, (int)ng, 0, 32, q));
-  GLOC_TRY(st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q));
-  GLOC_HIP(hipcub::DeviceRadixSort::SortPairsDescending(st->sort_tmp.p, tmp_bytes, st->sort_keys.as<float>(),
-                                                        st->sort_perm.as<float>(), st->sort_vals.as<uint32_t>(),
-                                                        s.order, (int)ng, 0, 32, q));
-  GLOC_HIP(hipGetLastError());
-  GLOC_HIP(hipStreamSynchronize(q));
+  std::vector<ScanBuild> hb(1, build_desc(s, layout_for(s.n)));
+  hb[0].group = 64u * (uint32_t)cs;
+  hb[0].n_groups = (uint32_t)((s.n + hb[0].group - 1) / hb[0].group);
+  hb[0].order = s.order;
+  GLOC_TRY(st->builds.ensure(sizeof(ScanBuild), q));
+  GLOC_HIP(hipMemcpyAsync(st->builds.p, hb.data(), sizeof(ScanBuild), hipMemcpyHostToDevice, q));
+  GLOC_TRY(launch_orders(st, st->builds.as<ScanBuild>(), hb, 1));
   s.order_built |= 1u << cs;
   return GLOC_OK;
 }
 
-
-int store_build_target_index(gloc_scan_store* st, DevScan& s) {
-  if (s.kd || s.n <= (size_t)SB) {
-    s.kd = true;  // (a scan of one sub-block is in kd order as it is)
-    return GLOC_OK;
-  }
+// Index `count` scans in one launch sequence.  out[i] receives scan i (live = false until the caller inserts it);
+// on failure everything allocated here is released.  Returns after the work has completed on the store's stream.
+int store_make_scans(gloc_scan_store* st, size_t count, const float* const* pts, const size_t* n, size_t stride,
+                     bool device_src, DevScan* out) {
+  if (!count) return GLOC_OK;
   hipStream_t q = st->stream;
-  const uint32_t n = (uint32_t)s.n;
-  uint32_t L = 0;
-  while (((size_t)SB << L) < s.n) ++L;  // P = SB * 2^L positions
-  const Layout lay = layout_for(s.n);
-  GLOC_TRY(st->kd_k0.ensure(sizeof(unsigned long long) * n, q));
-  GLOC_TRY(st->kd_k1.ensure(sizeof(unsigned long long) * n, q));
-  GLOC_TRY(st->kd_v0.ensure(sizeof(uint32_t) * n, q));
-  GLOC_TRY(st->kd_v1.ensure(sizeof(uint32_t) * n, q));
-  GLOC_TRY(st->kd_p0.ensure((sizeof(f32x4) + sizeof(uint32_t)) * (size_t)n, q));
-  GLOC_TRY(st->kd_p1.ensure((sizeof(f32x4) + sizeof(uint32_t)) * (size_t)n, q));
-  GLOC_TRY(st->kd_box.ensure(sizeof(uint32_t) * 6 * ((size_t)1 << (L ? L - 1 : 0)), q));
-  f32x4* pp[2] = {st->kd_p0.as<f32x4>(), st->kd_p1.as<f32x4>()};
-  uint32_t* hh[2] = {reinterpret_cast<uint32_t*>(pp[0] + n), reinterpret_cast<uint32_t*>(pp[1] + n)};
-  const unsigned nb = (n + 255) / 256, nblk = ((n + SB - 1) / SB + 255) / 256;
-  GLOC_HIP(hipMemcpyAsync(pp[0], s.idx.pts, sizeof(f32x4) * n, hipMemcpyDeviceToDevice, q));
-  hipLaunchKernelGGL(kd_iota_kernel, dim3(nb), dim3(256), 0, q, hh[0], n);
-  int cur = 0;
-  size_t tmp_cap = 0;
-  for (uint32_t l = 0; l < L; ++l) {
-    const uint32_t shift = 4 + L - l;  // log2 of the node size at this level (SB = 16 = 2^4)
-    static_assert(SB == 16, "shift arithmetic assumes 16-point leaves");
-    const uint32_t nodes = 1u << l;
-    hipLaunchKernelGGL(kd_box_init_kernel, dim3((nodes + 255) / 256), dim3(256), 0, q, st->kd_box.as<uint32_t>(), nodes);
-    hipLaunchKernelGGL(kd_node_bbox_kernel, dim3(nblk), dim3(256), 0, q, pp[cur], n, shift, st->kd_box.as<uint32_t>());
-    hipLaunchKernelGGL(kd_keys_kernel, dim3(nb), dim3(256), 0, q, pp[cur], n, shift, st->kd_box.as<uint32_t>(),
-                       st->kd_k0.as<unsigned long long>(), st->kd_v0.as<uint32_t>());
-    GLOC_HIP(hipGetLastError());
-    size_t tmp_bytes = 0;
-    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, st->kd_k0.as<unsigned long long>(),
-                                                st->kd_k1.as<unsigned long long>(), st->kd_v0.as<uint32_t>(),
-                                                st->kd_v1.as<uint32_t>(), (int)n, 0, (int)(32 + l), q));
-    if (tmp_bytes > tmp_cap) {
-      GLOC_TRY(st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q));
-      tmp_cap = tmp_bytes;
-    }
-    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp.p, tmp_bytes, st->kd_k0.as<unsigned long long>(),
-                                                st->kd_k1.as<unsigned long long>(), st->kd_v0.as<uint32_t>(),
-                                                st->kd_v1.as<uint32_t>(), (int)n, 0, (int)(32 + l), q));
-    hipLaunchKernelGGL(kd_gather_kernel, dim3(nb), dim3(256), 0, q, pp[cur], hh[cur], st->kd_v1.as<uint32_t>(), n,
-                       pp[cur ^ 1], hh[cur ^ 1]);
-    cur ^= 1;
-  }
-  // write back and rebuild what depends on the order: inv, kpos, all boxes, the launch orders
-  f32x4* p4 = const_cast<f32x4*>(s.idx.pts);
-  uint32_t* inv = const_cast<uint32_t*>(s.idx.inv);
-  const size_t nch = (s.n + CH - 1) / CH, nsup = (nch + 63) / 64;
-  hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)((lay.np + 255) / 256)), dim3(256), 0, q, pp[cur], hh[cur], n,
-                     (uint32_t)lay.np, p4, inv, s.kpos_mem);
-  hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, q, p4, n, const_cast<f32x4*>(s.idx.box_lo),
-                     const_cast<f32x4*>(s.idx.box_hi));
-  hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((lay.b1 / 3 + 255) / 256)), dim3(256), 0, q, p4, n,
-                     (uint32_t)(lay.b1 / 3), const_cast<f32x4*>(s.idx.sb2));
-  hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, q, s.idx.box_lo, s.idx.box_hi, (uint32_t)nch,
-                     const_cast<f32x4*>(s.idx.sup_lo), const_cast<f32x4*>(s.idx.sup_hi));
-  GLOC_HIP(hipGetLastError());
-  s.idx.kpos = s.kpos_mem;
-  s.kd = true;
-  s.order_built = 0;  // the launch orders list groups of the old order
-  return store_build_order(st, s, 2);  // synchronises the stream
-}
-
-int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
-                    DevScan* out) {
-  DevScan s;
-  s.n = n;
-  const Layout L = layout_for(n);
-  const size_t nch = (n + CH - 1) / CH, nsup = (nch + 63) / 64;
-  GLOC_TRY(take_block(st, L.bytes, &s.block, &s.block_bytes));
-  ScanHeader* hdr = reinterpret_cast<ScanHeader*>(s.block);
-  f32x4* p4 = reinterpret_cast<f32x4*>(hdr + 1);
-  f32x4* lo = p4 + L.np;
-  f32x4* hi = lo + L.c1;
-  f32x4* sb2 = hi + L.c1;
-  f32x4* ulo = sb2 + L.b1;
-  f32x4* uhi = ulo + L.u1;
-  s.xyz = reinterpret_cast<float*>(uhi + L.u1);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * L.n1);
-  uint32_t* inv = keys + L.n1;
-  s.order_base = inv + L.n1;
-  s.order_g1 = L.g1;
-  s.order = nullptr;
-  s.kpos_mem = s.order_base + 2 * L.g1 + 2;
-  s.idx = ScanIndexDev{p4, lo, hi, sb2, nullptr, keys, inv, hdr, ulo, uhi, (uint32_t)n, (uint32_t)nch,
-                       (uint32_t)nsup, 0u};
-  hipStream_t q = st->stream;
+  std::vector<ScanBuild> hb(count);
+  std::vector<segsort::Seg> segs(count);
+  size_t made = 0;
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(q);
-    store_free_scan(st, s, true);
+    for (size_t i = 0; i < made; ++i) store_free_scan(st, out[i], true);
     return code;
   };
-  hipLaunchKernelGGL(scan_header_init_kernel, dim3(1), dim3(64), 0, q, hdr);
-  if (n) {
-    const float* d_in = pts;
-    if (!device_src) {
-      // host points travel as they are (stride included) into a staging buffer; the pack kernel
-      // drops the extra channels on the device
-      if (int rc = st->stage.ensure(sizeof(float) * stride * n, q)) return fail(rc);
-      const hipError_t eu = hipMemcpyAsync(st->stage.p, pts, sizeof(float) * stride * n, hipMemcpyHostToDevice, q);
-      if (eu != hipSuccess) {
-        (void)hipGetLastError();
-        set_err("scan upload failed: %s", hipGetErrorString(eu));
-        return fail(GLOC_ERR_HIP);
+  size_t stage_floats = 0, total_pts = 0, total_grp = 0;
+  uint32_t max_n = 0, max_np = 0, max_nch = 0, max_npairs = 0, max_nsup = 0;
+  for (size_t i = 0; i < count; ++i) {
+    DevScan s;
+    s.n = n[i];
+    const Layout L = layout_for(n[i]);
+    const size_t nch = (n[i] + CH - 1) / CH, nsup = (nch + 63) / 64;
+    if (int rc = take_block(st, L.bytes, &s.block, &s.block_bytes)) return fail(rc);
+    ScanHeader* hdr = reinterpret_cast<ScanHeader*>(s.block);
+    f32x4* p4 = reinterpret_cast<f32x4*>(hdr + 1);
+    f32x4* lo = p4 + L.np;
+    f32x4* hi = lo + L.c1;
+    f32x4* sb2 = hi + L.c1;
+    f32x4* ulo = sb2 + L.b1;
+    f32x4* uhi = ulo + L.u1;
+    s.xyz = reinterpret_cast<float*>(uhi + L.u1);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(s.xyz + 3 * L.n1);
+    uint32_t* inv = keys + L.n1;
+    s.order_base = inv + L.n1;
+    s.order_g1 = L.g1;
+    s.order = nullptr;
+    s.kpos_mem = s.order_base + 2 * L.g1 + 2;
+    s.idx = ScanIndexDev{p4, lo, hi, sb2, nullptr, keys, inv, hdr, ulo, uhi, (uint32_t)n[i], (uint32_t)nch,
+                         (uint32_t)nsup, 0u};
+    out[i] = s;
+    made = i + 1;
+    ScanBuild b = build_desc(s, L);
+    b.stride = (uint32_t)stride;
+    b.group = 128;  // the default sources-per-lane setting (2)
+    b.n_groups = (uint32_t)((n[i] + b.group - 1) / b.group);
+    b.order = s.order_of(2);
+    b.key_off = (uint32_t)total_pts;
+    b.grp_off = (uint32_t)total_grp;
+    segs[i] = segsort::Seg{b.key_off, b.n};
+    total_pts += (n[i] + 3) & ~(size_t)3;
+    total_grp += b.n_groups;
+    if (total_pts >= (1ull << 31)) {
+      set_err("batch of scans too large (%zu points)", total_pts);
+      return fail(GLOC_ERR_INVALID);
+    }
+    stage_floats += device_src ? 0 : stride * n[i];
+    max_n = std::max(max_n, b.n);
+    max_np = std::max(max_np, b.n_pad);
+    max_nch = std::max(max_nch, b.nch);
+    max_npairs = std::max(max_npairs, b.npairs);
+    max_nsup = std::max(max_nsup, b.nsup);
+    hb[i] = b;
+  }
+  // sources: device pointers as they are; host points travel as they are (stride included) into a staging
+  // buffer, the pack kernel drops the extra channels on the device
+  if (!device_src) {
+    if (int rc = st->stage.ensure(sizeof(float) * std::max<size_t>(stage_floats, 4), q)) return fail(rc);
+    size_t off = 0;
+    for (size_t i = 0; i < count; ++i) {
+      hb[i].in = st->stage.as<float>() + off;
+      if (n[i]) {
+        const hipError_t eu = hipMemcpyAsync(st->stage.as<float>() + off, pts[i], sizeof(float) * stride * n[i],
+                                             hipMemcpyHostToDevice, q);
+        if (eu != hipSuccess) {
+          (void)hipGetLastError();
+          set_err("scan upload failed: %s", hipGetErrorString(eu));
+          return fail(GLOC_ERR_HIP);
+        }
       }
-      d_in = st->stage.as<float>();
+      off += stride * n[i];
     }
-    for (auto need : {std::make_pair(&st->sort_keys, sizeof(uint32_t) * n), std::make_pair(&st->sort_vals, sizeof(uint32_t) * n),
-                      std::make_pair(&st->sort_perm, sizeof(uint32_t) * n),
-                      std::make_pair(&st->sort_tmp, sizeof(uint32_t) * 6 * PACK_BLOCKS)})
-      if (int rc = need.first->ensure(need.second, q)) return fail(rc);  // (the actual code: NOMEM or a HIP error)
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    const unsigned npk = std::min<unsigned>(nb, PACK_BLOCKS);
-    uint32_t* part = st->sort_tmp.as<uint32_t>();  // free until the radix sort below
-    hipLaunchKernelGGL(pack_bbox_kernel, dim3(npk), dim3(256), 0, q, d_in, (uint32_t)n, (uint32_t)stride, s.xyz, part);
-    hipLaunchKernelGGL(scan_header_finish_kernel, dim3(1), dim3(64), 0, q, hdr, part, npk);
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(nb), dim3(256), 0, q, s.xyz, (uint32_t)n, hdr,
-                       st->sort_keys.as<uint32_t>(), st->sort_vals.as<uint32_t>());
-    size_t tmp_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, st->sort_keys.as<uint32_t>(), keys,
-                                           st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
-                                           (int)n, 0, 30, q) != hipSuccess)
-      return fail(GLOC_ERR_HIP);
-    if (int rc = st->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16), q)) return fail(rc);
-    if (hipcub::DeviceRadixSort::SortPairs(st->sort_tmp.p, tmp_bytes, st->sort_keys.as<uint32_t>(), keys,
-                                           st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
-                                           (int)n, 0, 30, q) != hipSuccess)
-      return fail(GLOC_ERR_HIP);
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, q, s.xyz,
-                       st->sort_perm.as<uint32_t>(), (uint32_t)n, (uint32_t)L.np, p4, inv);
-    hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)nch), dim3(64), 0, q, p4, (uint32_t)n, lo, hi);
-    hipLaunchKernelGGL(subblock_boxes_kernel, dim3((unsigned)((L.b1 / 3 + 255) / 256)), dim3(256), 0, q, p4,
-                       (uint32_t)n, (uint32_t)(L.b1 / 3), sb2);
-    hipLaunchKernelGGL(super_boxes_kernel, dim3((unsigned)nsup), dim3(64), 0, q, lo, hi, (uint32_t)nch, ulo, uhi);
-    const hipError_t ei = hipGetLastError();  // (read once: the call clears the error)
-    if (ei != hipSuccess) {
-      set_err("scan indexing failed: %s", hipGetErrorString(ei));
-      return fail(GLOC_ERR_HIP);
-    }
-    int rc = store_build_order(st, s, 2);  // the default sources-per-lane; synchronises the stream
-    if (rc != GLOC_OK) return fail(rc);
+  } else {
+    for (size_t i = 0; i < count; ++i) hb[i].in = pts[i];
+  }
+  const size_t tp = std::max<size_t>(total_pts, 4);
+  for (auto need : {std::make_pair(&st->sort_keys, sizeof(uint32_t) * tp), std::make_pair(&st->sort_keys2, sizeof(uint32_t) * tp),
+                    std::make_pair(&st->sort_vals, sizeof(uint32_t) * tp), std::make_pair(&st->sort_perm, sizeof(uint32_t) * tp),
+                    std::make_pair(&st->part, sizeof(uint32_t) * 6 * PACK_BLOCKS * count),
+                    std::make_pair(&st->builds, sizeof(ScanBuild) * count), std::make_pair(&st->segs, sizeof(segsort::Seg) * count),
+                    std::make_pair(&st->sort_hist, segsort::scratch_bytes((uint32_t)count, std::max<uint32_t>(max_n, 1)))})
+    if (int rc = need.first->ensure(need.second, q)) return fail(rc);  // (the actual code: NOMEM or a HIP error)
+  hipError_t e = hipMemcpyAsync(st->builds.p, hb.data(), sizeof(ScanBuild) * count, hipMemcpyHostToDevice, q);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->segs.p, segs.data(), sizeof(segsort::Seg) * count, hipMemcpyHostToDevice, q);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_err("scan indexing: descriptor upload failed: %s", hipGetErrorString(e));
+    return fail(GLOC_ERR_HIP);
+  }
+  const ScanBuild* d_sb = st->builds.as<ScanBuild>();
+  const uint32_t cnt = (uint32_t)count;
+  if (max_n) hipLaunchKernelGGL(pack_bbox_kernel, dim3(PACK_BLOCKS, cnt), dim3(256), 0, q, d_sb, st->part.as<uint32_t>());
+  hipLaunchKernelGGL(header_finish_kernel, dim3(cnt), dim3(64), 0, q, d_sb, st->part.as<uint32_t>());
+  if (max_n) {
+    hipLaunchKernelGGL(curve_keys_kernel, dim3((max_n + 255) / 256, cnt), dim3(256), 0, q, d_sb, st->sort_keys.as<uint32_t>(),
+                       st->sort_vals.as<uint32_t>());
+    const int r = segsort::sort_pairs<uint32_t>(q, st->sort_keys.as<uint32_t>(), st->sort_keys2.as<uint32_t>(),
+                                                st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
+                                                st->segs.as<segsort::Seg>(), cnt, max_n, 0, 30, st->sort_hist.as<uint32_t>());
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((max_np + 255) / 256, cnt), dim3(256), 0, q, d_sb,
+                       r ? st->sort_keys2.as<uint32_t>() : st->sort_keys.as<uint32_t>(),
+                       r ? st->sort_perm.as<uint32_t>() : st->sort_vals.as<uint32_t>());
+    launch_boxes(q, d_sb, cnt, max_nch, max_npairs, max_nsup);
+  }
+  const hipError_t ei = hipGetLastError();  // (read once: the call clears the error)
+  if (ei != hipSuccess) {
+    set_err("scan indexing failed: %s", hipGetErrorString(ei));
+    return fail(GLOC_ERR_HIP);
+  }
+  if (max_n) {
+    if (int rc = launch_orders(st, d_sb, hb, cnt)) return fail(rc);  // synchronises the stream
   } else if (hipStreamSynchronize(q) != hipSuccess) {
     return fail(GLOC_ERR_HIP);
   }
-  s.live = true;
-  *out = s;
+  for (size_t i = 0; i < count; ++i) {
+    out[i].order_built = n[i] ? (1u << 2) : 0u;
+    out[i].live = true;
+  }
   return GLOC_OK;
+}
+
+int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src, DevScan* out) {
+  return store_make_scans(st, 1, &pts, &n, stride, device_src, out);
+}
+
+// Re-sort `count` indexed scans into kd order (target index).  Scans already in kd order are skipped.
+int store_build_target_indices(gloc_scan_store* st, DevScan* const* scans, size_t count) {
+  hipStream_t q = st->stream;
+  constexpr size_t MAX_BATCH_POINTS = size_t(8) << 20;  // 64 B of scratch per point: 512 MB
+  size_t a = 0;
+  while (a < count) {
+    std::vector<ScanKd> hk;
+    std::vector<ScanBuild> hb;
+    std::vector<DevScan*> todo;
+    std::vector<segsort::Seg> segs;
+    size_t total = 0, box_words = 0, total_grp = 0;
+    uint32_t max_n = 0, max_np = 0, max_levels = 0, max_nch = 0, max_npairs = 0, max_nsup = 0;
+    size_t b = a;
+    for (; b < count; ++b) {
+      DevScan& s = *scans[b];
+      if (s.kd) continue;
+      if (s.n <= (size_t)SB) {
+        s.kd = true;  // (one sub-block is in kd order as it is)
+        continue;
+      }
+      if (!todo.empty() && total + s.n > MAX_BATCH_POINTS) break;
+      uint32_t L = 0;
+      while (((size_t)SB << L) < s.n) ++L;  // P = SB * 2^L positions
+      const Layout lay = layout_for(s.n);
+      ScanKd k{};
+      k.pts = const_cast<f32x4*>(s.idx.pts);
+      k.inv = const_cast<uint32_t*>(s.idx.inv);
+      k.kpos = s.kpos_mem;
+      k.n = (uint32_t)s.n;
+      k.n_pad = (uint32_t)lay.np;
+      k.levels = L;
+      k.off = (uint32_t)total;
+      k.box_off = (uint32_t)box_words;
+      ScanBuild sb = build_desc(s, lay);
+      sb.group = 128;
+      sb.n_groups = (uint32_t)((s.n + 127) / 128);
+      sb.order = s.order_of(2);
+      sb.grp_off = (uint32_t)total_grp;
+      segs.push_back(segsort::Seg{k.off, k.n});
+      total += (s.n + 3) & ~(size_t)3;
+      box_words += (size_t)6 << (L - 1);
+      total_grp += sb.n_groups;
+      max_n = std::max(max_n, k.n);
+      max_np = std::max(max_np, k.n_pad);
+      max_levels = std::max(max_levels, L);
+      max_nch = std::max(max_nch, sb.nch);
+      max_npairs = std::max(max_npairs, sb.npairs);
+      max_nsup = std::max(max_nsup, sb.nsup);
+      hk.push_back(k);
+      hb.push_back(sb);
+      todo.push_back(&s);
+    }
+    a = b;
+    if (todo.empty()) continue;
+    const uint32_t cnt = (uint32_t)todo.size();
+    GLOC_TRY(st->kd_k0.ensure(sizeof(unsigned long long) * total, q));
+    GLOC_TRY(st->kd_k1.ensure(sizeof(unsigned long long) * total, q));
+    GLOC_TRY(st->kd_v0.ensure(sizeof(uint32_t) * total, q));
+    GLOC_TRY(st->kd_v1.ensure(sizeof(uint32_t) * total, q));
+    GLOC_TRY(st->kd_p0.ensure(sizeof(f32x4) * total, q));
+    GLOC_TRY(st->kd_p1.ensure(sizeof(f32x4) * total, q));
+    GLOC_TRY(st->kd_h0.ensure(sizeof(uint32_t) * total, q));
+    GLOC_TRY(st->kd_h1.ensure(sizeof(uint32_t) * total, q));
+    GLOC_TRY(st->kd_box.ensure(sizeof(uint32_t) * box_words, q));
+    GLOC_TRY(st->kd_desc.ensure(sizeof(ScanKd) * cnt, q));
+    GLOC_TRY(st->builds.ensure(sizeof(ScanBuild) * cnt, q));
+    GLOC_TRY(st->segs.ensure(sizeof(segsort::Seg) * cnt, q));
+    GLOC_TRY(st->sort_hist.ensure(segsort::scratch_bytes(cnt, max_n), q));
+    GLOC_HIP(hipMemcpyAsync(st->kd_desc.p, hk.data(), sizeof(ScanKd) * cnt, hipMemcpyHostToDevice, q));
+    GLOC_HIP(hipMemcpyAsync(st->builds.p, hb.data(), sizeof(ScanBuild) * cnt, hipMemcpyHostToDevice, q));
+    GLOC_HIP(hipMemcpyAsync(st->segs.p, segs.data(), sizeof(segsort::Seg) * cnt, hipMemcpyHostToDevice, q));
+    const ScanKd* d_k = st->kd_desc.as<ScanKd>();
+    f32x4* pp[2] = {st->kd_p0.as<f32x4>(), st->kd_p1.as<f32x4>()};
+    uint32_t* hh[2] = {st->kd_h0.as<uint32_t>(), st->kd_h1.as<uint32_t>()};
+    unsigned long long* kk[2] = {st->kd_k0.as<unsigned long long>(), st->kd_k1.as<unsigned long long>()};
+    uint32_t* vv[2] = {st->kd_v0.as<uint32_t>(), st->kd_v1.as<uint32_t>()};
+    const dim3 gpt((max_n + 255) / 256, cnt), gblk(((max_n + SB - 1) / SB + 255) / 256, cnt);
+    hipLaunchKernelGGL(kd_load_kernel, gpt, dim3(256), 0, q, d_k, pp[0], hh[0]);
+    int cur = 0;
+    static_assert(SB == 16, "the node size arithmetic assumes 16-point leaves");
+    for (uint32_t l = 0; l < max_levels; ++l) {
+      hipLaunchKernelGGL(kd_box_init_kernel, dim3(((1u << l) + 255) / 256, cnt), dim3(256), 0, q, d_k, l, st->kd_box.as<uint32_t>());
+      hipLaunchKernelGGL(kd_node_bbox_kernel, gblk, dim3(256), 0, q, d_k, l, pp[cur], st->kd_box.as<uint32_t>());
+      hipLaunchKernelGGL(kd_keys_kernel, gpt, dim3(256), 0, q, d_k, l, pp[cur], st->kd_box.as<uint32_t>(), kk[0], vv[0]);
+      const int r = segsort::sort_pairs<unsigned long long>(q, kk[0], kk[1], vv[0], vv[1], st->segs.as<segsort::Seg>(), cnt,
+                                                            max_n, 0, (int)(32 + l), st->sort_hist.as<uint32_t>());
+      hipLaunchKernelGGL(kd_gather_kernel, gpt, dim3(256), 0, q, d_k, pp[cur], hh[cur], vv[r], pp[cur ^ 1], hh[cur ^ 1]);
+      cur ^= 1;
+    }
+    // write back and rebuild what depends on the order: inv, kpos, all boxes, the launch orders
+    hipLaunchKernelGGL(kd_finish_kernel, dim3((max_np + 255) / 256, cnt), dim3(256), 0, q, d_k, pp[cur], hh[cur]);
+    launch_boxes(q, st->builds.as<ScanBuild>(), cnt, max_nch, max_npairs, max_nsup);
+    GLOC_HIP(hipGetLastError());
+    GLOC_TRY(launch_orders(st, st->builds.as<ScanBuild>(), hb, cnt));  // synchronises the stream
+    for (DevScan* s : todo) {
+      s->idx.kpos = s->kpos_mem;
+      s->kd = true;
+      s->order_built = 1u << 2;  // the other launch orders listed groups of the old order: rebuilt on demand
+    }
+  }
+  return GLOC_OK;
+}
+
+int store_build_target_index(gloc_scan_store* st, DevScan& s) {
+  DevScan* p = &s;
+  return store_build_target_indices(st, &p, 1);
 }
 
 int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out) {
@@ -690,9 +895,7 @@ int gloc_scan_store_destroy(gloc_scan_store* st) {
   for (auto& s : st->scans)
     if (s.block) (void)hipFree(s.block);
   for (auto& kv : st->free_blocks) (void)hipFree(kv.second);
-  for (DevBuf* b : {&st->sort_tmp, &st->sort_keys, &st->sort_vals, &st->sort_perm, &st->stage, &st->kd_k0, &st->kd_k1,
-                    &st->kd_v0, &st->kd_v1, &st->kd_p0, &st->kd_p1, &st->kd_box})
-    b->release();
+  for (DevBuf* b : st->scratch()) b->release();
   (void)hipStreamDestroy(st->stream);
   delete st;
   return GLOC_OK;
@@ -705,6 +908,23 @@ int gloc_scan_store_add(gloc_scan_store* st, const float* pts, size_t n, size_t 
 int gloc_scan_store_add_device(gloc_scan_store* st, const float* d_pts, size_t n, size_t stride_floats,
                                uint32_t* scan_id) {
   return add_common(st, d_pts, n, stride_floats, true, scan_id);
+}
+
+int gloc_scan_store_add_batch(gloc_scan_store* st, const float* const* pts, const size_t* n, size_t count,
+                              size_t stride_floats, uint32_t* scan_ids) {
+  GLOC_REQUIRE(st && scan_ids && pts && n, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(count >= 1 && count <= 4096, GLOC_ERR_INVALID, "count = %zu outside [1,4096]", count);
+  GLOC_REQUIRE(stride_floats >= 3 && stride_floats <= 16, GLOC_ERR_INVALID, "stride_floats = %zu outside [3,16]", stride_floats);
+  for (size_t i = 0; i < count; ++i) {
+    GLOC_REQUIRE(pts[i] || n[i] == 0, GLOC_ERR_INVALID, "scan %zu is null", i);
+    GLOC_REQUIRE(n[i] < (1ull << 31), GLOC_ERR_INVALID, "scan too large");
+  }
+  GLOC_HIP(hipSetDevice(st->device));
+  std::lock_guard<std::mutex> lk(st->mu);
+  std::vector<DevScan> s(count);
+  GLOC_TRY(store_make_scans(st, count, pts, n, stride_floats, false, s.data()));
+  for (size_t i = 0; i < count; ++i) store_insert(st, s[i], &scan_ids[i]);
+  return GLOC_OK;
 }
 
 int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const float* T16, float noise_sigma,
@@ -738,12 +958,21 @@ int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const flo
   return store_insert(st, s, scan_id);
 }
 
-int gloc_scan_store_build_target_index(gloc_scan_store* st, uint32_t scan_id) {
-  GLOC_REQUIRE(st, GLOC_ERR_INVALID, "null store");
+int gloc_scan_store_build_target_index_batch(gloc_scan_store* st, const uint32_t* scan_ids, size_t count) {
+  GLOC_REQUIRE(st && (scan_ids || !count), GLOC_ERR_INVALID, "null argument");
   GLOC_HIP(hipSetDevice(st->device));
   std::lock_guard<std::mutex> lk(st->mu);
-  GLOC_REQUIRE(scan_id < st->scans.size() && st->scans[scan_id].live, GLOC_ERR_INVALID, "unknown scan id %u", scan_id);
-  return store_build_target_index(st, st->scans[scan_id]);
+  std::vector<DevScan*> ps(count);
+  for (size_t i = 0; i < count; ++i) {
+    GLOC_REQUIRE(scan_ids[i] < st->scans.size() && st->scans[scan_ids[i]].live, GLOC_ERR_INVALID, "unknown scan id %u",
+                 scan_ids[i]);
+    ps[i] = &st->scans[scan_ids[i]];
+  }
+  return store_build_target_indices(st, ps.data(), count);
+}
+
+int gloc_scan_store_build_target_index(gloc_scan_store* st, uint32_t scan_id) {
+  return gloc_scan_store_build_target_index_batch(st, &scan_id, 1);
 }
 
 int gloc_scan_store_release(gloc_scan_store* st, uint32_t scan_id) {
@@ -797,6 +1026,42 @@ int gloc_scan_store_points(gloc_scan_store* st, uint32_t scan_id, size_t* n_poin
   GLOC_REQUIRE(scan_id < st->scans.size() && st->scans[scan_id].live, GLOC_ERR_INVALID, "unknown scan id %u",
                scan_id);
   *n_points = st->scans[scan_id].n;
+  return GLOC_OK;
+}
+
+// Developer / test aid (not part of include/gloc3d.h): the index of a scan as the search sees it -- per sorted
+// position the original index of the point (perm), the sorted curve keys, the curve position -> sorted position
+// table of a target index (kpos; identity for a scan in curve order), the launch order for 2 sources per lane
+// (order2, ceil(n / 128) entries).  Any output may be null.  *is_kd: the index is in kd order.
+int gloc_scan_store_debug_index(gloc_scan_store* st, uint32_t scan_id, uint32_t* perm, uint32_t* keys, uint32_t* kpos,
+                                uint32_t* order2, int* is_kd) {
+  GLOC_REQUIRE(st, GLOC_ERR_INVALID, "null store");
+  GLOC_HIP(hipSetDevice(st->device));
+  std::lock_guard<std::mutex> lk(st->mu);
+  GLOC_REQUIRE(scan_id < st->scans.size() && st->scans[scan_id].live, GLOC_ERR_INVALID, "unknown scan id %u", scan_id);
+  DevScan& s = st->scans[scan_id];
+  if (is_kd) *is_kd = s.kd ? 1 : 0;
+  if (!s.n) return GLOC_OK;
+  hipStream_t q = st->stream;
+  if (perm) {
+    std::vector<f32x4> p(s.n);
+    GLOC_HIP(hipMemcpyAsync(p.data(), s.idx.pts, sizeof(f32x4) * s.n, hipMemcpyDeviceToHost, q));
+    GLOC_HIP(hipStreamSynchronize(q));
+    for (size_t i = 0; i < s.n; ++i) perm[i] = __builtin_bit_cast(uint32_t, p[i].w);
+  }
+  if (keys) GLOC_HIP(hipMemcpyAsync(keys, s.idx.keys, sizeof(uint32_t) * s.n, hipMemcpyDeviceToHost, q));
+  if (kpos) {
+    if (s.idx.kpos) {
+      GLOC_HIP(hipMemcpyAsync(kpos, s.idx.kpos, sizeof(uint32_t) * s.n, hipMemcpyDeviceToHost, q));
+    } else {
+      for (size_t i = 0; i < s.n; ++i) kpos[i] = (uint32_t)i;
+    }
+  }
+  if (order2) {
+    GLOC_TRY(store_build_order(st, s, 2));
+    GLOC_HIP(hipMemcpyAsync(order2, s.order_of(2), sizeof(uint32_t) * ((s.n + 127) / 128), hipMemcpyDeviceToHost, q));
+  }
+  GLOC_HIP(hipStreamSynchronize(q));
   return GLOC_OK;
 }
 

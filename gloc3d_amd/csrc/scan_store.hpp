@@ -42,8 +42,15 @@ struct gloc_scan_store {
   std::vector<uint32_t> free_ids;
   std::multimap<size_t, void*> free_blocks;  // released allocations by capacity, reused by later adds
   size_t live_count = 0, live_bytes = 0, cached_bytes = 0;
-  gloc::DevBuf sort_tmp, sort_keys, sort_vals, sort_perm, stage;
-  gloc::DevBuf kd_k0, kd_k1, kd_v0, kd_v1, kd_p0, kd_p1, kd_box;  // scratch of the kd re-sort
+  // scratch of the indexing pipeline (scan_store.hip): sort ping-pong arrays over all scans of a batch, descriptor
+  // tables, bounding-box partials, radix histograms; the same for the source-group sort and the kd re-sort
+  gloc::DevBuf sort_keys, sort_keys2, sort_vals, sort_perm, sort_hist, stage, part, builds, segs;
+  gloc::DevBuf grp_k0, grp_k1, grp_v0, grp_v1, grp_segs;
+  gloc::DevBuf kd_k0, kd_k1, kd_v0, kd_v1, kd_p0, kd_p1, kd_h0, kd_h1, kd_box, kd_desc;
+  std::vector<gloc::DevBuf*> scratch() {
+    return {&sort_keys, &sort_keys2, &sort_vals, &sort_perm, &sort_hist, &stage, &part, &builds, &segs, &grp_k0, &grp_k1,
+            &grp_v0, &grp_v1, &grp_segs, &kd_k0, &kd_k1, &kd_v0, &kd_v1, &kd_p0, &kd_p1, &kd_h0, &kd_h1, &kd_box, &kd_desc};
+  }
   std::atomic<int> attached{0};  // registration handles using this store
 };
 
@@ -54,10 +61,14 @@ namespace reg {
 // returns after the indexing work has completed on the store's stream.  Caller holds store->mu.
 int store_make_scan(gloc_scan_store* st, const float* pts, size_t n, size_t stride, bool device_src,
                     DevScan* out);
+// The same for `count` scans in ONE launch sequence (kernels take the scan from blockIdx.y, sorts are segmented).
+int store_make_scans(gloc_scan_store* st, size_t count, const float* const* pts, const size_t* n, size_t stride,
+                     bool device_src, DevScan* out);
 void store_free_scan(gloc_scan_store* st, DevScan& s, bool cache_block);
 // Re-sort an indexed scan into kd order (target index) and rebuild everything that depends on the order.
 // Caller holds store->mu; nothing may be reading the scan; returns after the work has completed.
 int store_build_target_index(gloc_scan_store* st, DevScan& s);
+int store_build_target_indices(gloc_scan_store* st, DevScan* const* scans, size_t count);  // batches of <= 8 M points
 // Build (once) the launch order of a scan for `cs` source points per lane into its own array and point
 // s.order at it.  Caller holds store->mu.
 int store_build_order(gloc_scan_store* st, DevScan& s, int cs);

@@ -1,0 +1,187 @@
+// seg_sort.hpp -- segmented least-significant-digit radix sort of (key, value) pairs, hand-written for gfx950.
+//
+// Every sort on the scan-indexing path goes through here: the curve keys of a scan (30 bits), the extents of its
+// source groups (32 bits), the (node, coordinate) keys of a kd level (up to 49 bits) -- for ONE scan or for a
+// whole batch of scans with the same three launches per 8-bit digit: a segment is one scan's slice of the
+// concatenated key / value arrays, blockIdx.y walks the segments.  (Rounds 1-2 called hipCUB per scan: at 124 k
+// elements rocPRIM picks a merge sort of 9 launches, a kd level costs 14 launches, a KITTI-00-sized database
+// 1.2 M launches; batched, the launch count does not depend on the number of scans.)
+//
+// Per digit:  hist_kernel     a work-group counts the digits of its tile of 2048 elements
+//             scan_kernel     one work-group per segment: exclusive prefix over (digit, tile), digit-major
+//             scatter_kernel  a work-group re-reads its tile, ranks every element among the equal digits before
+//                             it (stable: tiles in order, waves in order, chunks of 64 in order, lanes in order)
+//                             and writes it to its place
+// Equal digits inside a wave are found with eight ballots (one per bit of the digit) instead of LDS atomics:
+// the kd keys of the upper levels and the top digit of the curve keys have very few distinct digits, and a
+// thousand same-address atomics per tile would serialise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gloc {
+namespace segsort {
+
+constexpr int TILE = 2048;  // elements per work-group
+constexpr int THREADS = 256;
+constexpr int RADIX = 256;
+constexpr int CHUNKS = TILE / THREADS;  // chunks of 64 per wave: a wave owns 512 consecutive elements of the tile
+
+struct Seg {
+  uint32_t begin, n;  // elements [begin, begin + n) of the key / value arrays
+};
+
+// lanes (among the active ones) that hold the same 8-bit digit as this lane
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool active) {
+  unsigned long long peers = __builtin_amdgcn_ballot_w64(active);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+template <typename K>
+__global__ __launch_bounds__(THREADS) void hist_kernel(const K* __restrict__ keys, const Seg* __restrict__ segs,
+                                                       uint32_t max_tiles, uint32_t shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t cnt[RADIX];
+  const Seg sg = segs[blockIdx.y];
+  const uint32_t t0 = blockIdx.x * TILE;
+  if (t0 >= sg.n) return;  // uniform over the work-group
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const K* k = keys + sg.begin + t0;
+  const uint32_t m = sg.n - t0 < (uint32_t)TILE ? sg.n - t0 : (uint32_t)TILE;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const uint32_t e = c * THREADS + threadIdx.x;  // (counting does not care about the order)
+    const bool act = e < m;
+    const uint32_t d = act ? (uint32_t)(k[e] >> shift) & 255u : 0u;
+    const unsigned long long peers = match_digit(d, act);
+    if (act && lane == __builtin_ctzll(peers)) atomicAdd(&cnt[d], (uint32_t)__popcll(peers));  // one add per (wave, digit)
+  }
+  __syncthreads();
+  hist[((size_t)blockIdx.y * RADIX + threadIdx.x) * max_tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// hist[seg][digit][tile] -> exclusive prefix in the order (digit, tile): where the first element of that digit of that
+// tile goes, relative to the start of the segment
+__global__ __launch_bounds__(RADIX) void scan_kernel(const Seg* __restrict__ segs, uint32_t max_tiles,
+                                                     uint32_t* __restrict__ hist) {
+  __shared__ uint32_t tot[RADIX];
+  const Seg sg = segs[blockIdx.x];
+  const uint32_t nt = (sg.n + TILE - 1) / TILE;
+  uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x) * max_tiles;
+  uint32_t run = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    const uint32_t v = h[t];
+    h[t] = run;
+    run += v;
+  }
+  tot[threadIdx.x] = run;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t j = 0; j < threadIdx.x; ++j) base += tot[j];
+  for (uint32_t t = 0; t < nt; ++t) h[t] += base;
+}
+
+template <typename K>
+__global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                          K* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                          const Seg* __restrict__ segs, uint32_t max_tiles, uint32_t shift,
+                                                          const uint32_t* __restrict__ hist) {
+  __shared__ uint32_t cnt[THREADS / 64][RADIX];  // per wave: digit counts, then the running output position
+  const Seg sg = segs[blockIdx.y];
+  const uint32_t t0 = blockIdx.x * TILE;
+  if (t0 >= sg.n) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < (THREADS / 64) * RADIX; i += THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t m = sg.n - t0 < (uint32_t)TILE ? sg.n - t0 : (uint32_t)TILE;
+  const size_t in0 = (size_t)sg.begin + t0;
+  K key[CHUNKS];
+  uint32_t val[CHUNKS];
+  bool act[CHUNKS];
+  // a wave owns elements [w * 512, w * 512 + 512) of the tile, chunk c = 64 consecutive elements: order is kept
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const uint32_t e = w * (TILE / (THREADS / 64)) + c * 64 + lane;
+    act[c] = e < m;
+    key[c] = act[c] ? kin[in0 + e] : (K)0;
+    val[c] = act[c] ? vin[in0 + e] : 0u;
+  }
+  // 1: digit counts of this wave's elements (one lane per distinct digit adds: no atomics, no conflicts)
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+    const unsigned long long peers = match_digit(d, act[c]);
+    if (act[c] && lane == __builtin_ctzll(peers)) cnt[w][d] += (uint32_t)__popcll(peers);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();
+  // 2: where each wave's first element of every digit goes: the tile's place for that digit + the earlier waves' counts
+  {
+    const uint32_t d = threadIdx.x;
+    uint32_t b = hist[((size_t)blockIdx.y * RADIX + d) * max_tiles + blockIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < THREADS / 64; ++ww) {
+      const uint32_t c = cnt[ww][d];
+      cnt[ww][d] = b;
+      b += c;
+    }
+  }
+  __syncthreads();
+  // 3: rank among the equal digits before it, write out, advance the running position
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+    const unsigned long long peers = match_digit(d, act[c]);
+    const uint32_t pos = cnt[w][d] + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read the position before a leader moves it on
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (act[c] && lane == __builtin_ctzll(peers)) cnt[w][d] += (uint32_t)__popcll(peers);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (act[c]) {
+      kout[(size_t)sg.begin + pos] = key[c];
+      vout[(size_t)sg.begin + pos] = val[c];
+    }
+  }
+}
+
+// bytes of `hist` scratch for a sort of n_segs segments of at most max_n elements
+inline size_t scratch_bytes(uint32_t n_segs, uint32_t max_n) {
+  const size_t max_tiles = ((size_t)max_n + TILE - 1) / TILE;
+  return sizeof(uint32_t) * RADIX * (max_tiles ? max_tiles : 1) * (n_segs ? n_segs : 1);
+}
+
+// Sorts every segment by bits [begin_bit, end_bit) of its keys (bits at and above end_bit must be zero), stable.
+// The pairs ping-pong between (k0, v0) and (k1, v1); returns the index (0 / 1) of the buffers that hold the result.
+template <typename K>
+int sort_pairs(hipStream_t q, K* k0, K* k1, uint32_t* v0, uint32_t* v1, const Seg* d_segs, uint32_t n_segs,
+               uint32_t max_n, int begin_bit, int end_bit, uint32_t* d_hist) {
+  if (!n_segs || !max_n) return 0;
+  const uint32_t max_tiles = (max_n + TILE - 1) / TILE;
+  K* k[2] = {k0, k1};
+  uint32_t* v[2] = {v0, v1};
+  int cur = 0;
+  for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    hipLaunchKernelGGL((hist_kernel<K>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], d_segs, max_tiles,
+                       (uint32_t)shift, d_hist);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_segs), dim3(RADIX), 0, q, d_segs, max_tiles, d_hist);
+    hipLaunchKernelGGL((scatter_kernel<K>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], v[cur], k[cur ^ 1],
+                       v[cur ^ 1], d_segs, max_tiles, (uint32_t)shift, d_hist);
+    cur ^= 1;
+  }
+  return cur;
+}
+
+}  // namespace segsort
+}  // namespace gloc

@@ -233,6 +233,11 @@ int gloc_scan_store_add(gloc_scan_store* st, const float* pts, size_t n, size_t 
 /* Same with the points already in device memory on the store's device. */
 int gloc_scan_store_add_device(gloc_scan_store* st, const float* d_pts, size_t n,
                                size_t stride_floats, uint32_t* scan_id);
+/* `count` scans (host buffers pts[i] of n[i] points) uploaded and indexed in ONE launch sequence: the launch count
+ * does not depend on `count` (every indexing kernel covers all the scans, the sorts are segmented).  The query scans
+ * of a batch of localizations in flight go in together.  Each scan ends up exactly as gloc_scan_store_add leaves it. */
+int gloc_scan_store_add_batch(gloc_scan_store* st, const float* const* pts, const size_t* n, size_t count,
+                              size_t stride_floats, uint32_t* scan_ids);
 /* Re-sort a resident scan's search index into kd order (the TARGET index): chunks and sub-blocks become
  * disjoint kd cells fitted to the point density instead of runs of a space-filling curve, and the culled 1-NN
  * search of every registration AGAINST this scan tests ~35 % fewer boxes and evaluates ~30 % fewer pairs.
@@ -241,6 +246,8 @@ int gloc_scan_store_add_device(gloc_scan_store* st, const float* d_pts, size_t n
  * query scans, which are added, used as the source once and released.  Results never depend on it (the search is
  * exact either way).  The scan must not be in use by a registration in flight. */
 int gloc_scan_store_build_target_index(gloc_scan_store* st, uint32_t scan_id);
+/* The same for many scans, in batches of up to 8 M points per launch sequence (a database build). */
+int gloc_scan_store_build_target_index_batch(gloc_scan_store* st, const uint32_t* scan_ids, size_t count);
 /* Frees the scan's id and memory for reuse by later adds (ids of other scans do not change). */
 int gloc_scan_store_release(gloc_scan_store* st, uint32_t scan_id);
 int gloc_scan_store_clear(gloc_scan_store* st);

@@ -447,8 +447,8 @@ def main():
     for g in range(n_store):
         base = base_b[(g // NEG_EVERY) % POOL_B] if is_negative(g) else base_a[g % POOL_A]
         place_scan[g] = store.add_variant(base, place_perturbation(g), 0.01, seed=7000 + g)
-        if not args.no_target_index:
-            store.build_target_index(int(place_scan[g]))   # a database place: the kd-ordered target index, once
+    if not args.no_target_index:
+        store.build_target_index_batch(place_scan)   # the database places: kd-ordered target index, once (batches of 64 scans)
     live_b, _ = store.bytes()
     mean_pts = float(np.mean([p.shape[0] for p in pool_a]))
     log(f"scan store: {n_store} distinct resident scans (+{POOL_A + POOL_B} base views), "
@@ -611,7 +611,7 @@ def main():
         (gloc_scan_store_add, on the store's stream); the step's descriptors go H2D."""
         t0 = time.time()
         a, b = my_slice(i, Bq)
-        ids = [store.add(q_scan_host[j].numpy()) for j in range(a, b)]
+        ids = store.add_batch([q_scan_host[j].numpy() for j in range(a, b)])   # one launch sequence for all of them
         if cm is not None:
             with cm_lock:
                 for sid in ids:
@@ -888,8 +888,8 @@ def main():
         def with_override(make):
             for g in leg_places:
                 scan_override[g] = make(g)
-                if not args.no_target_index:
-                    store.build_target_index(scan_override[g][0])
+            if not args.no_target_index:
+                store.build_target_index_batch([scan_override[g][0] for g in leg_places])
 
         def drop_override():
             for g, (sid, _) in list(scan_override.items()):
@@ -988,7 +988,8 @@ def main():
                    "scan_store_gib": live_b / 2**30, "database_scans_target_index": "kd order" if not args.no_target_index else "curve order",
                    "negatives_per_query": (TOP_K // NEG_EVERY) if neg_on else 0,
                    "query_prep_in_timed_region": True,
-                   "query_prep": "per query: scan H2D from pinned host memory + device indexing + descriptor H2D, "
+                   "query_prep": "the step's query scans: H2D from pinned host memory + device indexing in one launch sequence "
+                                 "(gloc_scan_store_add_batch) + descriptor H2D, "
                                  + ("inline" if args.no_prefetch else "prefetched one step ahead on a second host thread + stream"),
                    "ransac_iters_cap": RANSAC_ITERS, "ransac_confidence": float(params.ransac_confidence),
                    "min_inlier_ratio": MIN_INLIER_RATIO, "max_rmse": MAX_RMSE, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,

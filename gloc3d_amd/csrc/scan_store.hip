@@ -139,6 +139,8 @@ __global__ void curve_keys_kernel(const ScanBuild* __restrict__ sbs, uint32_t* _
   vals[sb.key_off + i] = i;
 }
 
+
+
 __global__ void gather_sorted_kernel(const ScanBuild* __restrict__ sbs, const uint32_t* __restrict__ skeys,
                                      const uint32_t* __restrict__ perm) {
   const ScanBuild& sb = sbs[blockIdx.y];
@@ -530,12 +532,18 @@ int launch_orders(gloc_scan_store* st, const ScanBuild* d_sb, const std::vector<
   GLOC_HIP(hipMemcpyAsync(st->grp_segs.p, segs.data(), sizeof(segsort::Seg) * count, hipMemcpyHostToDevice, q));
   hipLaunchKernelGGL(group_extent_kernel, dim3((max_ng + 3) / 4, count), dim3(256), 0, q, d_sb, st->grp_k0.as<uint32_t>(),
                      st->grp_v0.as<uint32_t>());
-  const int r = segsort::sort_pairs<uint32_t>(q, st->grp_k0.as<uint32_t>(), st->grp_k1.as<uint32_t>(),
-                                              st->grp_v0.as<uint32_t>(), st->grp_v1.as<uint32_t>(),
-                                              st->grp_segs.as<segsort::Seg>(), count, max_ng, 0, 32,
-                                              st->sort_hist.as<uint32_t>());
-  hipLaunchKernelGGL(copy_order_kernel, dim3((max_ng + 255) / 256, count), dim3(256), 0, q, d_sb,
-                     r ? st->grp_v1.as<uint32_t>() : st->grp_v0.as<uint32_t>());
+  if (max_ng <= (uint32_t)segsort::SMALL_MAX) {  // one launch: a work-group per scan sorts its groups in LDS
+    hipLaunchKernelGGL(segsort::small_sort_kernel, dim3(count), dim3(1024), 0, q, st->grp_k0.as<uint32_t>(),
+                       st->grp_v0.as<uint32_t>(), st->grp_segs.as<segsort::Seg>(), st->grp_v1.as<uint32_t>());
+    hipLaunchKernelGGL(copy_order_kernel, dim3((max_ng + 255) / 256, count), dim3(256), 0, q, d_sb, st->grp_v1.as<uint32_t>());
+  } else {
+    const int r = segsort::sort_pairs<uint32_t, 8>(q, st->grp_k0.as<uint32_t>(), st->grp_k1.as<uint32_t>(),
+                                                    st->grp_v0.as<uint32_t>(), st->grp_v1.as<uint32_t>(),
+                                                    st->grp_segs.as<segsort::Seg>(), count, max_ng, 0, 32,
+                                                    st->sort_hist.as<uint32_t>());
+    hipLaunchKernelGGL(copy_order_kernel, dim3((max_ng + 255) / 256, count), dim3(256), 0, q, d_sb,
+                       r ? st->grp_v1.as<uint32_t>() : st->grp_v0.as<uint32_t>());
+  }
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipStreamSynchronize(q));  // (segs is a local: the copy must have been consumed)
   return GLOC_OK;
@@ -682,9 +690,9 @@ int store_make_scans(gloc_scan_store* st, size_t count, const float* const* pts,
   if (max_n) {
     hipLaunchKernelGGL(curve_keys_kernel, dim3((max_n + 255) / 256, cnt), dim3(256), 0, q, d_sb, st->sort_keys.as<uint32_t>(),
                        st->sort_vals.as<uint32_t>());
-    const int r = segsort::sort_pairs<uint32_t>(q, st->sort_keys.as<uint32_t>(), st->sort_keys2.as<uint32_t>(),
-                                                st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
-                                                st->segs.as<segsort::Seg>(), cnt, max_n, 0, 30, st->sort_hist.as<uint32_t>());
+    const int r = segsort::sort_pairs<uint32_t, 8>(q, st->sort_keys.as<uint32_t>(), st->sort_keys2.as<uint32_t>(),
+                                                    st->sort_vals.as<uint32_t>(), st->sort_perm.as<uint32_t>(),
+                                                    st->segs.as<segsort::Seg>(), cnt, max_n, 0, 30, st->sort_hist.as<uint32_t>());
     hipLaunchKernelGGL(gather_sorted_kernel, dim3((max_np + 255) / 256, cnt), dim3(256), 0, q, d_sb,
                        r ? st->sort_keys2.as<uint32_t>() : st->sort_keys.as<uint32_t>(),
                        r ? st->sort_perm.as<uint32_t>() : st->sort_vals.as<uint32_t>());
@@ -795,8 +803,8 @@ int store_build_target_indices(gloc_scan_store* st, DevScan* const* scans, size_
       hipLaunchKernelGGL(kd_box_init_kernel, dim3(((1u << l) + 255) / 256, cnt), dim3(256), 0, q, d_k, l, st->kd_box.as<uint32_t>());
       hipLaunchKernelGGL(kd_node_bbox_kernel, gblk, dim3(256), 0, q, d_k, l, pp[cur], st->kd_box.as<uint32_t>());
       hipLaunchKernelGGL(kd_keys_kernel, gpt, dim3(256), 0, q, d_k, l, pp[cur], st->kd_box.as<uint32_t>(), kk[0], vv[0]);
-      const int r = segsort::sort_pairs<unsigned long long>(q, kk[0], kk[1], vv[0], vv[1], st->segs.as<segsort::Seg>(), cnt,
-                                                            max_n, 0, (int)(32 + l), st->sort_hist.as<uint32_t>());
+      const int r = segsort::sort_pairs<unsigned long long, 8>(q, kk[0], kk[1], vv[0], vv[1], st->segs.as<segsort::Seg>(), cnt,
+                                                                max_n, 0, (int)(32 + l), st->sort_hist.as<uint32_t>());
       hipLaunchKernelGGL(kd_gather_kernel, gpt, dim3(256), 0, q, d_k, pp[cur], hh[cur], vv[r], pp[cur ^ 1], hh[cur ^ 1]);
       cur ^= 1;
     }
@@ -1047,7 +1055,8 @@ int gloc_scan_store_debug_index(gloc_scan_store* st, uint32_t scan_id, uint32_t*
     std::vector<f32x4> p(s.n);
     GLOC_HIP(hipMemcpyAsync(p.data(), s.idx.pts, sizeof(f32x4) * s.n, hipMemcpyDeviceToHost, q));
     GLOC_HIP(hipStreamSynchronize(q));
-    for (size_t i = 0; i < s.n; ++i) perm[i] = __builtin_bit_cast(uint32_t, p[i].w);
+    // (memcpy, not __builtin_bit_cast on the vector element: this clang's host side hands back element 0 for that)
+    for (size_t i = 0; i < s.n; ++i) std::memcpy(&perm[i], reinterpret_cast<const char*>(&p[i]) + 12, 4);
   }
   if (keys) GLOC_HIP(hipMemcpyAsync(keys, s.idx.keys, sizeof(uint32_t) * s.n, hipMemcpyDeviceToHost, q));
   if (kpos) {

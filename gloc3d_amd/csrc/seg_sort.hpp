@@ -2,7 +2,7 @@
 //
 // Every sort on the scan-indexing path goes through here: the curve keys of a scan (30 bits), the extents of its
 // source groups (32 bits), the (node, coordinate) keys of a kd level (up to 49 bits) -- for ONE scan or for a
-// whole batch of scans with the same three launches per 8-bit digit: a segment is one scan's slice of the
+// whole batch of scans with the same three launches per digit: a segment is one scan's slice of the
 // concatenated key / value arrays, blockIdx.y walks the segments.  (Rounds 1-2 called hipCUB per scan: at 124 k
 // elements rocPRIM picks a merge sort of 9 launches, a kd level costs 14 launches, a KITTI-00-sized database
 // 1.2 M launches; batched, the launch count does not depend on the number of scans.)
@@ -12,7 +12,7 @@
 //             scatter_kernel  a work-group re-reads its tile, ranks every element among the equal digits before
 //                             it (stable: tiles in order, waves in order, chunks of 64 in order, lanes in order)
 //                             and writes it to its place
-// Equal digits inside a wave are found with eight ballots (one per bit of the digit) instead of LDS atomics:
+// Equal digits inside a wave are found with one ballot per bit of the digit instead of LDS atomics:
 // the kd keys of the upper levels and the top digit of the curve keys have very few distinct digits, and a
 // thousand same-address atomics per tile would serialise.
 #pragma once
@@ -24,18 +24,22 @@ namespace segsort {
 
 constexpr int TILE = 2048;  // elements per work-group
 constexpr int THREADS = 256;
-constexpr int RADIX = 256;
 constexpr int CHUNKS = TILE / THREADS;  // chunks of 64 per wave: a wave owns 512 consecutive elements of the tile
+// Digit width: a template parameter (8, 10 or 11 bits).  Wider digits mean fewer passes of three launches each, but
+// scan_kernel walks (digits x tiles) counters per segment with one work-group: measured on 124 k-element segments,
+// 8 bits is the fastest (one scan added in 0.34 ms against 0.55 ms at 10 bits; a kd re-sort 3.6 against 13.6 ms at
+// 11), so every caller uses 8.
 
 struct Seg {
   uint32_t begin, n;  // elements [begin, begin + n) of the key / value arrays
 };
 
-// lanes (among the active ones) that hold the same 8-bit digit as this lane
+// lanes (among the active ones) that hold the same digit as this lane
+template <int BITS>
 __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool active) {
   unsigned long long peers = __builtin_amdgcn_ballot_w64(active);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < BITS; ++b) {
     const bool bit = (d >> b) & 1u;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
     peers &= bit ? m : ~m;
@@ -43,14 +47,15 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool activ
   return peers;
 }
 
-template <typename K>
+template <typename K, int BITS>
 __global__ __launch_bounds__(THREADS) void hist_kernel(const K* __restrict__ keys, const Seg* __restrict__ segs,
                                                        uint32_t max_tiles, uint32_t shift, uint32_t* __restrict__ hist) {
+  constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t cnt[RADIX];
   const Seg sg = segs[blockIdx.y];
   const uint32_t t0 = blockIdx.x * TILE;
   if (t0 >= sg.n) return;  // uniform over the work-group
-  cnt[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < RADIX; i += THREADS) cnt[i] = 0;
   __syncthreads();
   const K* k = keys + sg.begin + t0;
   const uint32_t m = sg.n - t0 < (uint32_t)TILE ? sg.n - t0 : (uint32_t)TILE;
@@ -59,40 +64,51 @@ __global__ __launch_bounds__(THREADS) void hist_kernel(const K* __restrict__ key
   for (int c = 0; c < CHUNKS; ++c) {
     const uint32_t e = c * THREADS + threadIdx.x;  // (counting does not care about the order)
     const bool act = e < m;
-    const uint32_t d = act ? (uint32_t)(k[e] >> shift) & 255u : 0u;
-    const unsigned long long peers = match_digit(d, act);
+    const uint32_t d = act ? (uint32_t)(k[e] >> shift) & (uint32_t)(RADIX - 1) : 0u;
+    const unsigned long long peers = match_digit<BITS>(d, act);
     if (act && lane == __builtin_ctzll(peers)) atomicAdd(&cnt[d], (uint32_t)__popcll(peers));  // one add per (wave, digit)
   }
   __syncthreads();
-  hist[((size_t)blockIdx.y * RADIX + threadIdx.x) * max_tiles + blockIdx.x] = cnt[threadIdx.x];
+  for (int i = threadIdx.x; i < RADIX; i += THREADS) hist[((size_t)blockIdx.y * RADIX + i) * max_tiles + blockIdx.x] = cnt[i];
 }
 
 // hist[seg][digit][tile] -> exclusive prefix in the order (digit, tile): where the first element of that digit of that
 // tile goes, relative to the start of the segment
-__global__ __launch_bounds__(RADIX) void scan_kernel(const Seg* __restrict__ segs, uint32_t max_tiles,
-                                                     uint32_t* __restrict__ hist) {
-  __shared__ uint32_t tot[RADIX];
+template <int BITS>
+__global__ __launch_bounds__(THREADS) void scan_kernel(const Seg* __restrict__ segs, uint32_t max_tiles,
+                                                       uint32_t* __restrict__ hist) {
+  constexpr int RADIX = 1 << BITS, PER = RADIX / THREADS;  // a thread owns PER consecutive digits
+  __shared__ uint32_t tot[THREADS];
   const Seg sg = segs[blockIdx.x];
   const uint32_t nt = (sg.n + TILE - 1) / TILE;
-  uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x) * max_tiles;
-  uint32_t run = 0;
-  for (uint32_t t = 0; t < nt; ++t) {
-    const uint32_t v = h[t];
-    h[t] = run;
-    run += v;
+  uint32_t run = 0;  // elements of this thread's digits, in (digit, tile) order
+#pragma unroll 1
+  for (int j = 0; j < PER; ++j) {
+    uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x * PER + j) * max_tiles;
+    for (uint32_t t = 0; t < nt; ++t) {
+      const uint32_t v = h[t];
+      h[t] = run;
+      run += v;
+    }
   }
   tot[threadIdx.x] = run;
   __syncthreads();
   uint32_t base = 0;
   for (uint32_t j = 0; j < threadIdx.x; ++j) base += tot[j];
-  for (uint32_t t = 0; t < nt; ++t) h[t] += base;
+  if (base)
+#pragma unroll 1
+    for (int j = 0; j < PER; ++j) {
+      uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x * PER + j) * max_tiles;
+      for (uint32_t t = 0; t < nt; ++t) h[t] += base;
+    }
 }
 
-template <typename K>
+template <typename K, int BITS>
 __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                           K* __restrict__ kout, uint32_t* __restrict__ vout,
                                                           const Seg* __restrict__ segs, uint32_t max_tiles, uint32_t shift,
                                                           const uint32_t* __restrict__ hist) {
+  constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t cnt[THREADS / 64][RADIX];  // per wave: digit counts, then the running output position
   const Seg sg = segs[blockIdx.y];
   const uint32_t t0 = blockIdx.x * TILE;
@@ -116,8 +132,8 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   // 1: digit counts of this wave's elements (one lane per distinct digit adds: no atomics, no conflicts)
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
-    const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-    const unsigned long long peers = match_digit(d, act[c]);
+    const uint32_t d = (uint32_t)(key[c] >> shift) & (uint32_t)(RADIX - 1);
+    const unsigned long long peers = match_digit<BITS>(d, act[c]);
     if (act[c] && lane == __builtin_ctzll(peers)) cnt[w][d] += (uint32_t)__popcll(peers);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -125,8 +141,7 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   }
   __syncthreads();
   // 2: where each wave's first element of every digit goes: the tile's place for that digit + the earlier waves' counts
-  {
-    const uint32_t d = threadIdx.x;
+  for (uint32_t d = threadIdx.x; d < (uint32_t)RADIX; d += THREADS) {
     uint32_t b = hist[((size_t)blockIdx.y * RADIX + d) * max_tiles + blockIdx.x];
 #pragma unroll
     for (int ww = 0; ww < THREADS / 64; ++ww) {
@@ -139,8 +154,8 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   // 3: rank among the equal digits before it, write out, advance the running position
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
-    const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-    const unsigned long long peers = match_digit(d, act[c]);
+    const uint32_t d = (uint32_t)(key[c] >> shift) & (uint32_t)(RADIX - 1);
+    const unsigned long long peers = match_digit<BITS>(d, act[c]);
     const uint32_t pos = cnt[w][d] + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every lane has read the position before a leader moves it on
@@ -156,31 +171,65 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   }
 }
 
-// bytes of `hist` scratch for a sort of n_segs segments of at most max_n elements
+// bytes of `hist` scratch for a sort of n_segs segments of at most max_n elements (any digit width up to 11 bits)
 inline size_t scratch_bytes(uint32_t n_segs, uint32_t max_n) {
   const size_t max_tiles = ((size_t)max_n + TILE - 1) / TILE;
-  return sizeof(uint32_t) * RADIX * (max_tiles ? max_tiles : 1) * (n_segs ? n_segs : 1);
+  return sizeof(uint32_t) * 2048 * (max_tiles ? max_tiles : 1) * (n_segs ? n_segs : 1);
 }
 
-// Sorts every segment by bits [begin_bit, end_bit) of its keys (bits at and above end_bit must be zero), stable.
-// The pairs ping-pong between (k0, v0) and (k1, v1); returns the index (0 / 1) of the buffers that hold the result.
-template <typename K>
+// Sorts every segment by bits [begin_bit, end_bit) of its keys (bits at and above end_bit must be zero), stable,
+// BITS bits per pass.  The pairs ping-pong between (k0, v0) and (k1, v1); returns the index (0 / 1) of the buffers
+// that hold the result.
+template <typename K, int BITS>
 int sort_pairs(hipStream_t q, K* k0, K* k1, uint32_t* v0, uint32_t* v1, const Seg* d_segs, uint32_t n_segs,
                uint32_t max_n, int begin_bit, int end_bit, uint32_t* d_hist) {
+  static_assert(BITS == 8 || BITS == 10 || BITS == 11, "digit widths with kernels instantiated");
   if (!n_segs || !max_n) return 0;
   const uint32_t max_tiles = (max_n + TILE - 1) / TILE;
   K* k[2] = {k0, k1};
   uint32_t* v[2] = {v0, v1};
   int cur = 0;
-  for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    hipLaunchKernelGGL((hist_kernel<K>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], d_segs, max_tiles,
+  for (int shift = begin_bit; shift < end_bit; shift += BITS) {
+    hipLaunchKernelGGL((hist_kernel<K, BITS>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], d_segs, max_tiles,
                        (uint32_t)shift, d_hist);
-    hipLaunchKernelGGL(scan_kernel, dim3(n_segs), dim3(RADIX), 0, q, d_segs, max_tiles, d_hist);
-    hipLaunchKernelGGL((scatter_kernel<K>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], v[cur], k[cur ^ 1],
+    hipLaunchKernelGGL((scan_kernel<BITS>), dim3(n_segs), dim3(THREADS), 0, q, d_segs, max_tiles, d_hist);
+    hipLaunchKernelGGL((scatter_kernel<K, BITS>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], v[cur], k[cur ^ 1],
                        v[cur ^ 1], d_segs, max_tiles, (uint32_t)shift, d_hist);
     cur ^= 1;
   }
   return cur;
+}
+
+// ---- small segments in one launch: a work-group sorts one segment of up to 4096 (key, value) pairs in LDS ----------
+// Bitonic network on (key << 32 | value): the value makes every element distinct, so the result is the stable order
+// whenever values ascend with the input position (they do: values are the positions).  Used for the launch order of a
+// scan's source groups (969 groups at 124 k points): one launch instead of the twelve of a four-pass radix sort.
+constexpr int SMALL_MAX = 4096;
+__global__ __launch_bounds__(1024) void small_sort_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                          const Seg* __restrict__ segs, uint32_t* __restrict__ vals_out) {
+  __shared__ unsigned long long a[SMALL_MAX];
+  const Seg sg = segs[blockIdx.x];
+  uint32_t m = 1;
+  while (m < sg.n) m <<= 1;  // padded to a power of two with keys that sort last
+  for (uint32_t i = threadIdx.x; i < m; i += 1024)
+    a[i] = i < sg.n ? ((unsigned long long)keys[sg.begin + i] << 32) | vals[sg.begin + i] : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= m; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        const uint32_t p = i ^ j;
+        if (p > i) {
+          const unsigned long long x = a[i], y = a[p];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            a[i] = y;
+            a[p] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = threadIdx.x; i < sg.n; i += 1024) vals_out[sg.begin + i] = (uint32_t)a[i];
 }
 
 }  // namespace segsort

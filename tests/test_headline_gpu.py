@@ -59,8 +59,9 @@ def headline(capi):
     for g in sorted(set(int(x) for x in idx.reshape(-1))):
         P = bench.place_perturbation(g)
         base = base_b[(g // bench.NEG_EVERY) % N_B] if neg(g) else base_a[g % N_A]
-        place_sid[g] = store.build_target_index(store.add_variant(base, P, 0.01, seed=7000 + g))   # a database place
+        place_sid[g] = store.add_variant(base, P, 0.01, seed=7000 + g)
         place_pose[g] = bench.far_away_pose() if neg(g) else a_pose[g % N_A] @ np.linalg.inv(P)
+    store.build_target_index_batch(list(place_sid.values()))     # database places: the kd-ordered target index
     q_sid, q_poses = [], []
     for j in range(N_Q):
         Pq = bench.query_perturbation(j)

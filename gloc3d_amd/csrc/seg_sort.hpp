@@ -26,9 +26,9 @@ constexpr int TILE = 2048;  // elements per work-group
 constexpr int THREADS = 256;
 constexpr int CHUNKS = TILE / THREADS;  // chunks of 64 per wave: a wave owns 512 consecutive elements of the tile
 // Digit width: a template parameter (8, 10 or 11 bits).  Wider digits mean fewer passes of three launches each, but
-// scan_kernel walks (digits x tiles) counters per segment with one work-group: measured on 124 k-element segments,
-// 8 bits is the fastest (one scan added in 0.34 ms against 0.55 ms at 10 bits; a kd re-sort 3.6 against 13.6 ms at
-// 11), so every caller uses 8.
+// more ballots per element and 4 - 8 x the counters to clear, write and scan per tile: measured on 124 k-element
+// segments 8 bits wins (one scan indexed in 0.22 ms against 0.31 ms with 10-bit digits for the curve keys, a kd re-sort
+// in 2.1 ms against 7.3 ms with 11-bit digits), so every caller uses 8.
 
 struct Seg {
   uint32_t begin, n;  // elements [begin, begin + n) of the key / value arrays
@@ -72,42 +72,51 @@ __global__ __launch_bounds__(THREADS) void hist_kernel(const K* __restrict__ key
   for (int i = threadIdx.x; i < RADIX; i += THREADS) hist[((size_t)blockIdx.y * RADIX + i) * max_tiles + blockIdx.x] = cnt[i];
 }
 
-// hist[seg][digit][tile] -> exclusive prefix in the order (digit, tile): where the first element of that digit of that
-// tile goes, relative to the start of the segment
+// hist[seg][digit][tile] -> where the first element of that digit of that tile goes, relative to the start of the
+// segment = base[seg][digit] (exclusive prefix of the digit totals) + the exclusive prefix over the tiles of that digit,
+// which replaces the count in place.  One work-group of 16 waves per segment; a wave takes one digit at a time, its lanes
+// the tiles (64 at a time, the running sum carried on): the first version -- a thread per digit walking the tiles one
+// by one -- was a chain of dependent global round trips and took longer than the two kernels around it.
+constexpr int SCAN_THREADS = 1024;
 template <int BITS>
-__global__ __launch_bounds__(THREADS) void scan_kernel(const Seg* __restrict__ segs, uint32_t max_tiles,
-                                                       uint32_t* __restrict__ hist) {
-  constexpr int RADIX = 1 << BITS, PER = RADIX / THREADS;  // a thread owns PER consecutive digits
-  __shared__ uint32_t tot[THREADS];
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const Seg* __restrict__ segs, uint32_t max_tiles,
+                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ base) {
+  constexpr int RADIX = 1 << BITS;
+  __shared__ uint32_t tot[RADIX];
   const Seg sg = segs[blockIdx.x];
   const uint32_t nt = (sg.n + TILE - 1) / TILE;
-  uint32_t run = 0;  // elements of this thread's digits, in (digit, tile) order
-#pragma unroll 1
-  for (int j = 0; j < PER; ++j) {
-    uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x * PER + j) * max_tiles;
-    for (uint32_t t = 0; t < nt; ++t) {
-      const uint32_t v = h[t];
-      h[t] = run;
-      run += v;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int d = w; d < RADIX; d += SCAN_THREADS / 64) {
+    uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + d) * max_tiles;
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < nt; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const uint32_t v = t < nt ? h[t] : 0u;
+      uint32_t inc = v;  // inclusive prefix over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+      }
+      if (t < nt) h[t] = run + inc - v;
+      run += __shfl(inc, 63);
     }
+    if (lane == 0) tot[d] = run;
   }
-  tot[threadIdx.x] = run;
   __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t j = 0; j < threadIdx.x; ++j) base += tot[j];
-  if (base)
-#pragma unroll 1
-    for (int j = 0; j < PER; ++j) {
-      uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + threadIdx.x * PER + j) * max_tiles;
-      for (uint32_t t = 0; t < nt; ++t) h[t] += base;
-    }
+  // exclusive prefix of the digit totals (RADIX values: every thread sums what lies before its digits)
+  for (int d = threadIdx.x; d < RADIX; d += SCAN_THREADS) {
+    uint32_t b = 0;
+    for (int j = 0; j < d; ++j) b += tot[j];
+    base[(size_t)blockIdx.x * RADIX + d] = b;
+  }
 }
 
 template <typename K, int BITS>
 __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                           K* __restrict__ kout, uint32_t* __restrict__ vout,
                                                           const Seg* __restrict__ segs, uint32_t max_tiles, uint32_t shift,
-                                                          const uint32_t* __restrict__ hist) {
+                                                          const uint32_t* __restrict__ hist, const uint32_t* __restrict__ base) {
   constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t cnt[THREADS / 64][RADIX];  // per wave: digit counts, then the running output position
   const Seg sg = segs[blockIdx.y];
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   __syncthreads();
   // 2: where each wave's first element of every digit goes: the tile's place for that digit + the earlier waves' counts
   for (uint32_t d = threadIdx.x; d < (uint32_t)RADIX; d += THREADS) {
-    uint32_t b = hist[((size_t)blockIdx.y * RADIX + d) * max_tiles + blockIdx.x];
+    uint32_t b = hist[((size_t)blockIdx.y * RADIX + d) * max_tiles + blockIdx.x] + base[(size_t)blockIdx.y * RADIX + d];
 #pragma unroll
     for (int ww = 0; ww < THREADS / 64; ++ww) {
       const uint32_t c = cnt[ww][d];
@@ -171,10 +180,11 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const K* __restrict__ 
   }
 }
 
-// bytes of `hist` scratch for a sort of n_segs segments of at most max_n elements (any digit width up to 11 bits)
+// bytes of scratch (tile histograms + digit bases) for a sort of n_segs segments of at most max_n elements (any digit
+// width up to 11 bits)
 inline size_t scratch_bytes(uint32_t n_segs, uint32_t max_n) {
   const size_t max_tiles = ((size_t)max_n + TILE - 1) / TILE;
-  return sizeof(uint32_t) * 2048 * (max_tiles ? max_tiles : 1) * (n_segs ? n_segs : 1);
+  return sizeof(uint32_t) * 2048 * ((max_tiles ? max_tiles : 1) + 1) * (n_segs ? n_segs : 1);
 }
 
 // Sorts every segment by bits [begin_bit, end_bit) of its keys (bits at and above end_bit must be zero), stable,
@@ -186,15 +196,16 @@ int sort_pairs(hipStream_t q, K* k0, K* k1, uint32_t* v0, uint32_t* v1, const Se
   static_assert(BITS == 8 || BITS == 10 || BITS == 11, "digit widths with kernels instantiated");
   if (!n_segs || !max_n) return 0;
   const uint32_t max_tiles = (max_n + TILE - 1) / TILE;
+  uint32_t* d_base = d_hist + (size_t)(1 << BITS) * max_tiles * n_segs;  // (scratch_bytes() leaves room for it)
   K* k[2] = {k0, k1};
   uint32_t* v[2] = {v0, v1};
   int cur = 0;
   for (int shift = begin_bit; shift < end_bit; shift += BITS) {
     hipLaunchKernelGGL((hist_kernel<K, BITS>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], d_segs, max_tiles,
                        (uint32_t)shift, d_hist);
-    hipLaunchKernelGGL((scan_kernel<BITS>), dim3(n_segs), dim3(THREADS), 0, q, d_segs, max_tiles, d_hist);
+    hipLaunchKernelGGL((scan_kernel<BITS>), dim3(n_segs), dim3(SCAN_THREADS), 0, q, d_segs, max_tiles, d_hist, d_base);
     hipLaunchKernelGGL((scatter_kernel<K, BITS>), dim3(max_tiles, n_segs), dim3(THREADS), 0, q, k[cur], v[cur], k[cur ^ 1],
-                       v[cur ^ 1], d_segs, max_tiles, (uint32_t)shift, d_hist);
+                       v[cur ^ 1], d_segs, max_tiles, (uint32_t)shift, d_hist, d_base);
     cur ^= 1;
   }
   return cur;

@@ -487,13 +487,16 @@ def main():
     q_desc_host = torch.from_numpy(synth.queries_near(DB_SEED, q_place, DIM)).pin_memory()
     # the queries' scans: made on the device from the query views, read back into pinned host memory --
     # from then on they exist only on the host, like scans arriving from a sensor
+    # (a rank makes only the scans of the queries it will prepare: its B of every step's world x B)
     qbase = [store.add(v) for v in qviews]
-    q_scan_host = []
-    for j in range(total):
-        sid = store.add_variant(qbase[int(q_view[j])], query_perturbation(j), 0.01, seed=880000 + j)
-        h = torch.from_numpy(store.download(sid)).pin_memory()
-        store.release(sid)
-        q_scan_host.append(h)
+    q_scan_host = {}
+    for i in range(n_steps + n_warm):
+        q0 = i * per_step
+        mine = range(q0 + rank * B, q0 + rank * B + B) if args.mode == "throughput" else range(q0, q0 + 1)
+        for j in mine:
+            sid = store.add_variant(qbase[int(q_view[j])], query_perturbation(j), 0.01, seed=880000 + j)
+            q_scan_host[j] = torch.from_numpy(store.download(sid)).pin_memory()
+            store.release(sid)
     for sid in qbase:
         store.release(sid)
     store_scans_resident = len(store)

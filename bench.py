@@ -376,6 +376,8 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each step's queries inline")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N = 1: wait for a step's registration before the next step's is enqueued (round 2's loop)")
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
     ap.add_argument("--coarse", action="store_true",
                     help="also run the reference's 2-D step: the coarse (x, y, yaw) match of every (query, candidate) "
@@ -513,6 +515,38 @@ def main():
     if args.ransac_confidence is not None:
         params.ransac_confidence = args.ransac_confidence
     cur = {"params": params}       # (legs swap the parameters / the mode)
+    # Registration pipeline (N = 1): two handles with their own workspaces on ONE stream; batch i + 1 is enqueued
+    # (gloc_reg_batch_multi_begin) before batch i's results are waited for (gloc_reg_batch_multi_end), so the device runs
+    # batch after batch while the host unpacks, selects, releases and looks the next scans up
+    pipeline = world == 1 and args.mode == "throughput" and not args.no_pipeline
+    regs = [reg]
+    if pipeline:
+        reg_b = capi.Registrar(device=local_rank, store=store)
+        reg_b.set_option(capi.REG_OPT_PROFILE, 1)
+        reg_b.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
+        if args.nn_src_per_lane:
+            reg_b.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
+        if args.nn_job_group:
+            reg_b.set_option(capi.REG_OPT_NN_JOB_GROUP, args.nn_job_group)
+        reg_stream = torch.cuda.Stream(device=dev)
+        reg.set_stream(reg_stream.cuda_stream)
+        reg_b.set_stream(reg_stream.cuda_stream)
+        regs.append(reg_b)
+
+    def prof(name):
+        ms, n = 0.0, 0
+        for r_ in regs:
+            a_, b_ = r_.profile(name)
+            ms, n = ms + a_, n + b_
+        return ms, n
+
+    def prof_reset():
+        for r_ in regs:
+            r_.profile_reset()
+
+    def nn_stats_all():
+        a_ = [r_.nn_stats() for r_ in regs]
+        return sum(x[0] for x in a_), sum(x[1] for x in a_)
 
     capi_knn, collectives, rccl_ranks_seen = None, "none", None
     if world > 1 and args.collectives == "capi" and args.backend == "nccl" and not args.same_device:
@@ -693,8 +727,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_stream_pipelined(first, count, record, Bq, keep):
+        fence()
+        t0 = time.time()
+        pre.start(first, Bq)
+        sels_, cands_, tabs_, pend = [], [], [], None
+
+        def finish(p):
+            i_, ids_, cand_, h_ = p
+            t_a = time.time()
+            r = h_.batch_multi_end()                       # waits for THAT batch; the next one is already queued behind it
+            t_b = time.time()
+            tables = sharded.pack_results(r, cand_.shape)
+            sels_.extend(sharded.ShardedRegistrar.select_first_ok(t) for t in tables)
+            for sid in ids_:
+                store.release(sid)                         # (its batch has completed; no stream to wait for)
+                if cm is not None:
+                    with cm_lock:
+                        cm.release(cur_qgrids.pop(sid))
+            if keep:
+                cands_.append(cand_)
+                tabs_.append(tables)
+            if record:
+                stage["register"] += t_b - t_a
+                a_, _ = my_slice(i_, Bq)
+                for k in range(cand_.shape[0]):
+                    work_pairs.append((q_scan_host[a_ + k].shape[0], int(np.count_nonzero(cand_[k] >= 0))))
+
+        for i in range(first, first + count):
+            t_a = time.time()
+            ids, qd, t_prep = pre.take()
+            if i + 1 < first + count:
+                pre.start(i + 1, Bq)
+            t_b = time.time()
+            torch.cuda.current_stream().synchronize()       # the descriptors' H2D
+            idx, d2 = knn.search(qd, TOP_K)
+            cand = idx.cpu().numpy()
+            t_c = time.time()
+            init = coarse_init(ids, cand) if cm is not None else None
+            h = regs[i % 2]
+            h.batch_multi_begin(ids, scans_of(cand), params=cur["params"], init_T=init)
+            if record:
+                stage["prep_wait"] += t_b - t_a
+                stage["h2d_index"] += t_prep
+                stage["knn"] += t_c - t_b
+                stage["enqueue"] = stage.get("enqueue", 0.0) + time.time() - t_c
+            if pend is not None:
+                finish(pend)
+            pend = (i, ids, cand, h)
+        finish(pend)
+        fence()
+        return time.time() - t0, sels_, cands_, tabs_
+
     def run_stream(first, count, record=False, Bq=None, keep=False):
         """`count` steps starting at `first`, fenced on both sides.  Returns (seconds, selections, [cand], [tables])."""
+        if pipeline and not fs_state["on"] and not args.no_prefetch:
+            return run_stream_pipelined(first, count, record, Bq, keep)
         fence()
         t0 = time.time()
         if not args.no_prefetch:
@@ -719,7 +807,7 @@ def main():
     for rep in range(n_reps):
         if rep == n_reps - 1:
             fence()
-            reg.profile_reset()
+            prof_reset()
         elapsed, rsel, rc_, rt_ = run_stream(0, n_steps, record=rep == n_reps - 1, keep=rep == n_reps - 1)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev or dev)
@@ -736,10 +824,10 @@ def main():
     accuracy = accuracy_of(all_cand, sels, all_tabs, stream_q, place_pose, query_pose, lambda g: not is_negative(g % n_store))
 
     # ---- roofline of the dominant kernel (K4 point-NN), from the HIP events of the last repetition --
-    nn_ms, nn_launches = reg.profile("nn")
-    stage_ms = {n: reg.profile(n)[0] for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve")}
+    nn_ms, nn_launches = prof("nn")
+    stage_ms = {n: prof(n)[0] for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve")}
     passes = 1 + ICP_ITERS
-    pairs_eval, _ = reg.nn_stats()
+    pairs_eval, _ = nn_stats_all()
     avg_launch_s = (nn_ms / max(nn_launches, 1)) * 1e-3
     jobs_per_launch = float(np.mean([c for _, c in work_pairs])) * (B if args.mode == "throughput" else 1) \
         if work_pairs else 0.0
@@ -805,11 +893,11 @@ def main():
         """A leg = the same pipeline steps 0 .. n-1 under changed settings: q/s, stage times, pairs per source, accuracy."""
         Bq_ = B if Bq is None else Bq
         run_stream(n_steps if n_warm else 0, 1, Bq=Bq)      # one untimed step under the new settings
-        reg.profile_reset()
+        prof_reset()
         t, s_, c_, tb_ = run_stream(0, n_leg_steps, Bq=Bq, keep=True)
-        ms, nl = reg.profile("nn")
-        pe, _ = reg.nn_stats()
-        st = {n: reg.profile(n)[0] / n_leg_steps for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve")}
+        ms, nl = prof("nn")
+        pe, _ = nn_stats_all()
+        st = {n: prof(n)[0] / n_leg_steps for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve")}
         nq = n_leg_steps * Bq_
         cc = np.concatenate(c_)
         # queries of step i are stream ids i * per_step .. + Bq
@@ -828,7 +916,7 @@ def main():
     lone = None
     if run_legs:
         # one query alone (20 jobs per launch), its preparation included and NOT hidden: BASELINE configs[2]
-        reg.profile_reset()
+        prof_reset()
         t_lone = []
         for j in range(8):
             t0 = time.time()
@@ -872,7 +960,8 @@ def main():
 
         # leg 2: the brute-force 1-NN kernel north_star names (every (source, target) pair), a few whole queries
         log("leg: exhaustive 1-NN kernel")
-        reg.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_EXHAUSTIVE)
+        for r_ in regs:
+            r_.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_EXHAUSTIVE)
         n_ex = min(3, n_steps)
         legs["nn_exhaustive_sample"], sx = leg_run(n_ex, Bq=1, acc=False)
         lx = legs["nn_exhaustive_sample"]
@@ -885,7 +974,8 @@ def main():
                    "same_selection_as_culled": bool(sx == [sels[i * per_step] for i in range(n_ex)]),
                    "what": "GLOC_REG_NN_EXHAUSTIVE, one query (20 candidates) per batch; identical results to the culled search"})
         lx.pop("pairs_evaluated_per_source", None)
-        reg.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
+        for r_ in regs:
+            r_.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
 
         # legs 3, 4: harder data.  The places the leg's queries retrieve get other scans for the duration of the leg.
         leg_q = q_desc_host[:L * per_step].to(dev)
@@ -1003,6 +1093,8 @@ def main():
                    "min_inlier_ratio": MIN_INLIER_RATIO, "max_rmse": MAX_RMSE, "icp_iters": ICP_ITERS, "nn_passes_per_query": passes,
                    "nn_mode": args.nn_mode, "collectives": collectives, "rccl_ranks_seen": rccl_ranks_seen,
                    "coarse_2d_match": bool(args.coarse),
+                   "registration_pipeline": ("two handles on one stream: batch i + 1 enqueued before batch i's results are waited "
+                                             "for (gloc_reg_batch_multi_begin / _end)") if pipeline else "none",
                    "parallelism": (f"1 gpu, {B} queries registered per batch on one stream") if world == 1 else (
                        f"{B} queries per gpu per step; "
                        f"db rows interleave-sharded over {world} ranks (all-gather of per-shard top-k, merge); "

@@ -147,6 +147,8 @@ _PROTOS = [
     ("gloc_reg_scan_clear", _i, [_vp]),
     ("gloc_reg_batch_multi", _i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
                                   _vp]),
+    ("gloc_reg_batch_multi_begin", _i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, C.POINTER(RegParams)]),
+    ("gloc_reg_batch_multi_end", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("gloc_reg_batch", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp,
                             C.POINTER(RegParams), _vp, _vp, _vp, _vp]),
     ("gloc_reg_batch_ids", _i, [_vp, _u32, _vp, _sz, _vp, _vp, C.POINTER(RegParams), _vp, _vp, _vp,
@@ -549,6 +551,26 @@ class Registrar:
                                          None if sid is None else _np_ptr(sid),
                                          None if it is None else _np_ptr(it), C.byref(prm),
                                          _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
+        return dict(T=T.reshape(Q, n, 4, 4), rmse=rmse.reshape(Q, n), inliers=inl.reshape(Q, n),
+                    ok=ok.astype(bool).reshape(Q, n))
+
+    def batch_multi_begin(self, q_ids, cand_ids, init_T=None, params=None, stream_ids=None):
+        """Enqueue a batch and return at once; batch_multi_end() waits for it and returns what batch_multi returns."""
+        q = np.ascontiguousarray(q_ids, np.uint32).reshape(-1)
+        ids = np.ascontiguousarray(cand_ids, np.uint32).reshape(q.shape[0], -1)
+        Q, n = ids.shape
+        prm = params or default_reg_params()
+        it = None if init_T is None else np.ascontiguousarray(init_T, np.float32).reshape(Q * n, 16)
+        sid = None if stream_ids is None else np.ascontiguousarray(stream_ids, np.uint32).reshape(Q * n)
+        check(lib().gloc_reg_batch_multi_begin(self._h, Q, _np_ptr(q), _np_ptr(ids), n,
+                                               None if sid is None else _np_ptr(sid),
+                                               None if it is None else _np_ptr(it), C.byref(prm)))
+        self._pending_shape = (Q, n)
+
+    def batch_multi_end(self):
+        Q, n = self._pending_shape
+        T, rmse, inl, ok = self._outs(Q * n)
+        check(lib().gloc_reg_batch_multi_end(self._h, _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
         return dict(T=T.reshape(Q, n, 4, 4), rmse=rmse.reshape(Q, n), inliers=inl.reshape(Q, n),
                     ok=ok.astype(bool).reshape(Q, n))
 

@@ -19,6 +19,8 @@ using namespace gloc::reg;
 struct gloc_reg {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t done_ev = nullptr;  // a batch waits for ITS OWN results, not for the stream: handles that share a stream
+                                 // (gloc_reg_set_stream) queue their batches back to back while the host reads results
   gloc_scan_store* store = nullptr;  // scans are looked up here (attached, or the handle's own)
   gloc_scan_store* own_store = nullptr;
   DevBuf jobs, states;           // Job[], CandState[]
@@ -27,7 +29,21 @@ struct gloc_reg {
   DevBuf partials;               // [job][n_part][ACC_NV] fp64
   DevBuf export_idx, export_d2;  // gloc_reg_nn: results in the caller's index space
   DevBuf counters;               // pairs evaluated by the culled search: NN_STAT_SLOTS partial counts (profiling only)
-  std::vector<CandState> h_states;
+  // pinned host staging: job table up, per-job state up and down.  Pageable memory would make the "async" copies
+  // wait for the stream, i.e. for the batch BEFORE this one when handles share a stream
+  void* pin = nullptr;
+  size_t pin_cap = 0;
+  CandState* h_states = nullptr;  // [n_jobs], inside pin
+  Job* h_jobs = nullptr;          // [n_jobs], inside pin
+  // a batch between gloc_reg_batch_multi_begin and _end
+  struct Pending {
+    bool active = false;
+    std::vector<size_t> slot;     // job -> output row
+    std::vector<size_t> n_src;    // per job
+    std::vector<float> def_T;     // output rows before the jobs' results go in (initial guess / identity)
+    size_t total = 0;
+    float max_rmse = 0.f;
+  } pending;
   int nn_mode = 0;        // 0 culled + compacted (default), 1 exhaustive
   bool trace_on = false;  // dev only: per-wave trace of the culled kernel
   DevBuf trace;
@@ -124,15 +140,30 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
   return GLOC_OK;
 }
 
-// The whole pipeline for a batch of jobs, device resident: S1 -> S2 (RANSAC + refit) -> S3 (ICP).
-// Outputs are per job, in job order.
-int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params* prm, float* out_T,
-             float* out_rmse, uint32_t* out_inliers, int* out_ok, bool sync_and_read = true) {
+int ensure_pinned(gloc_reg* h, uint32_t n_jobs) {
+  const size_t need = (sizeof(CandState) + sizeof(Job)) * (size_t)n_jobs;
+  if (need > h->pin_cap) {
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+    const size_t cap = need + need / 2 + 4096;
+    GLOC_HIP(hipHostMalloc(&h->pin, cap, hipHostMallocDefault));
+    h->pin_cap = cap;
+  }
+  h->h_states = reinterpret_cast<CandState*>(h->pin);
+  h->h_jobs = reinterpret_cast<Job*>(h->h_states + n_jobs);
+  return GLOC_OK;
+}
+
+// The whole pipeline for a batch of jobs, device resident: S1 -> S2 (RANSAC + refit) -> S3 (ICP), ENQUEUED on the
+// handle's stream with the copy of the per-job results behind it and an event behind that: returns without waiting.
+int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params* prm) {
   const uint32_t n_jobs = (uint32_t)jh.size();
   if (n_jobs == 0) return GLOC_OK;
   const int cs = h->nn_src_per_lane;
   BatchDims bd{n_jobs, 0, 0, 0, 0};
-  std::vector<Job> jd(n_jobs);
+  GLOC_TRY(ensure_pinned(h, n_jobs));
+  Job* jd = h->h_jobs;
   bool can = false, any_tgt = false;
   for (uint32_t c = 0; c < n_jobs; ++c) {
     const DevScan &s = jh[c].src, &t = jh[c].tgt;
@@ -149,7 +180,6 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   h->last_ld = bd.ld;
   h->last_jobs = n_jobs;
   hipStream_t s = h->stream;
-  h->h_states.resize(n_jobs);
   for (uint32_t c = 0; c < n_jobs; ++c) {
     init_state(h->h_states[c], jh[c].init_T, prm->ransac_iters);
     if (jh[c].src.n < 3) h->h_states[c].frozen = 1;  // nothing to estimate: T stays the initial guess
@@ -163,9 +193,8 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   GLOC_TRY(h->corr.ensure(sizeof(uint32_t) * std::max<size_t>(bd.ld, 1) * n_jobs, s));
   GLOC_TRY(h->d2.ensure(sizeof(float) * std::max<size_t>(bd.ld, 1) * n_jobs, s));
   GLOC_TRY(h->partials.ensure(sizeof(double) * ACC_NV * (size_t)bd.n_part * n_jobs, s));
-  GLOC_HIP(hipMemcpyAsync(h->jobs.p, jd.data(), sizeof(Job) * n_jobs, hipMemcpyHostToDevice, s));
-  GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states.data(), sizeof(CandState) * n_jobs,
-                          hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(h->jobs.p, jd, sizeof(Job) * n_jobs, hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states, sizeof(CandState) * n_jobs, hipMemcpyHostToDevice, s));
   const bool culled = h->nn_mode != 1;
   const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
   bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
@@ -255,13 +284,20 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
       GLOC_HIP(hipGetLastError());
     }
   }
-  if (!sync_and_read) return GLOC_OK;
-  GLOC_HIP(hipMemcpyAsync(h->h_states.data(), h->states.p, sizeof(CandState) * n_jobs,
-                          hipMemcpyDeviceToHost, s));
-  GLOC_HIP(hipStreamSynchronize(s));
+  GLOC_HIP(hipMemcpyAsync(h->h_states, h->states.p, sizeof(CandState) * n_jobs, hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipEventRecord(h->done_ev, s));
+  return GLOC_OK;
+}
+
+// Waits for the results of the batch enqueue_jobs() queued last (its own event: not for the stream, which may carry the
+// next batch of a handle sharing it) and unpacks them, per job, in job order.
+int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max_rmse, float* out_T, float* out_rmse,
+                 uint32_t* out_inliers, int* out_ok) {
+  if (n_jobs == 0) return GLOC_OK;
+  GLOC_HIP(hipEventSynchronize(h->done_ev));
   for (uint32_t c = 0; c < n_jobs; ++c) {
     const CandState& st = h->h_states[c];
-    const size_t n_src = jh[c].src.n;
+    const size_t n_src = n_src_of[c];
     float* T = out_T + 16 * (size_t)c;
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) T[4 * i + j] = st.Tf[3 * i + j];
@@ -271,9 +307,17 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
     const float rmse = n_src ? (float)std::sqrt(st.sum_d2 / (double)n_src) : 0.f;
     if (out_rmse) out_rmse[c] = rmse;
     if (out_inliers) out_inliers[c] = st.best_inl;
-    if (out_ok) out_ok[c] = st.ok && !(prm->max_rmse > 0.f && !(rmse <= prm->max_rmse));
+    if (out_ok) out_ok[c] = st.ok && !(max_rmse > 0.f && !(rmse <= max_rmse));
   }
   return GLOC_OK;
+}
+
+int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params* prm, float* out_T, float* out_rmse,
+             uint32_t* out_inliers, int* out_ok) {
+  GLOC_TRY(enqueue_jobs(h, jh, prm));
+  std::vector<size_t> n_src(jh.size());
+  for (size_t c = 0; c < jh.size(); ++c) n_src[c] = jh[c].src.n;
+  return collect_jobs(h, (uint32_t)jh.size(), n_src.data(), prm->max_rmse, out_T, out_rmse, out_inliers, out_ok);
 }
 
 int check_params(const gloc_reg_params* p) {
@@ -343,6 +387,13 @@ int gloc_reg_create(int device, gloc_reg** out) {
     return GLOC_ERR_HIP;
   }
   h->stream = h->own_stream;
+  e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    set_err("hipEventCreate failed: %s", hipGetErrorString(e));
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return GLOC_ERR_HIP;
+  }
   *out = h;
   return GLOC_OK;
 }
@@ -378,6 +429,8 @@ int gloc_reg_destroy(gloc_reg* h) {
   for (DevBuf* b : {&h->jobs, &h->states, &h->corr, &h->d2, &h->pairs, &h->Rt, &h->valid, &h->inliers,
                     &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace})
     b->release();
+  if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return GLOC_OK;
@@ -486,19 +539,21 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   return rc;
 }
 
-int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
-                         const uint32_t* cand_scan_ids, size_t n_cand, const uint32_t* cand_stream_ids,
-                         const float* init_T, const gloc_reg_params* params, float* out_T,
-                         float* out_rmse, uint32_t* out_inliers, int* out_ok) {
-  GLOC_REQUIRE(h && out_T && q_scan_ids && cand_scan_ids, GLOC_ERR_INVALID, "null argument");
+int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids, const uint32_t* cand_scan_ids,
+                               size_t n_cand, const uint32_t* cand_stream_ids, const float* init_T,
+                               const gloc_reg_params* params) {
+  GLOC_REQUIRE(h && q_scan_ids && cand_scan_ids, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_queries >= 1 && n_cand >= 1 && n_queries * n_cand <= 65536, GLOC_ERR_INVALID,
                "n_queries x n_cand = %zu x %zu outside [1, 65536]", n_queries, n_cand);
   GLOC_REQUIRE(h->store, GLOC_ERR_INVALID, "no scan store: upload scans or attach a store first");
+  GLOC_REQUIRE(!h->pending.active, GLOC_ERR_STATE, "a batch is already in flight on this handle: call gloc_reg_batch_multi_end first");
   GLOC_TRY(check_params(params));
   GLOC_HIP(hipSetDevice(h->device));
   const size_t total = n_queries * n_cand;
   std::vector<JobHost> jh;
-  std::vector<size_t> slot;  // job -> output row
+  gloc_reg::Pending& P = h->pending;
+  P.slot.clear();
+  P.n_src.clear();
   jh.reserve(total);
   for (size_t q = 0; q < n_queries; ++q) {
     DevScan src;
@@ -512,30 +567,55 @@ int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_i
       j.stream_id = cand_stream_ids ? cand_stream_ids[o] : (uint32_t)c;
       j.init_T = init_T ? init_T + 16 * o : nullptr;
       jh.push_back(j);
-      slot.push_back(o);
+      P.slot.push_back(o);
+      P.n_src.push_back(src.n);
     }
   }
-  // defaults for skipped rows: the initial guess (identity), not ok
-  for (size_t o = 0; o < total; ++o) {
-    float* T = out_T + 16 * o;
-    for (int i = 0; i < 16; ++i) T[i] = init_T ? init_T[16 * o + i] : ((i % 5 == 0) ? 1.f : 0.f);
+  // rows without a candidate keep the initial guess (identity), not ok
+  P.def_T.resize(16 * total);
+  for (size_t o = 0; o < total; ++o)
+    for (int i = 0; i < 16; ++i) P.def_T[16 * o + i] = init_T ? init_T[16 * o + i] : ((i % 5 == 0) ? 1.f : 0.f);
+  P.total = total;
+  P.max_rmse = params->max_rmse;
+  GLOC_TRY(enqueue_jobs(h, jh, params));
+  P.active = true;
+  return GLOC_OK;
+}
+
+int gloc_reg_batch_multi_end(gloc_reg* h, float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  GLOC_REQUIRE(h && out_T, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(h->pending.active, GLOC_ERR_STATE, "no batch in flight on this handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  gloc_reg::Pending& P = h->pending;
+  P.active = false;
+  for (size_t o = 0; o < P.total; ++o) {
+    std::copy(P.def_T.begin() + 16 * o, P.def_T.begin() + 16 * (o + 1), out_T + 16 * o);
     if (out_rmse) out_rmse[o] = 0.f;
     if (out_inliers) out_inliers[o] = 0;
     if (out_ok) out_ok[o] = 0;
   }
-  const size_t nj = jh.size();
+  const size_t nj = P.slot.size();
   std::vector<float> T(16 * std::max<size_t>(nj, 1)), rm(std::max<size_t>(nj, 1));
   std::vector<uint32_t> inl(std::max<size_t>(nj, 1));
   std::vector<int> ok(std::max<size_t>(nj, 1));
-  GLOC_TRY(run_jobs(h, jh, params, T.data(), rm.data(), inl.data(), ok.data()));
+  GLOC_TRY(collect_jobs(h, (uint32_t)nj, P.n_src.data(), P.max_rmse, T.data(), rm.data(), inl.data(), ok.data()));
   for (size_t j = 0; j < nj; ++j) {
-    const size_t o = slot[j];
+    const size_t o = P.slot[j];
     std::copy(T.begin() + 16 * j, T.begin() + 16 * (j + 1), out_T + 16 * o);
     if (out_rmse) out_rmse[o] = rm[j];
     if (out_inliers) out_inliers[o] = inl[j];
     if (out_ok) out_ok[o] = ok[j];
   }
   return GLOC_OK;
+}
+
+int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
+                         const uint32_t* cand_scan_ids, size_t n_cand, const uint32_t* cand_stream_ids,
+                         const float* init_T, const gloc_reg_params* params, float* out_T,
+                         float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  GLOC_REQUIRE(out_T, GLOC_ERR_INVALID, "null argument");
+  GLOC_TRY(gloc_reg_batch_multi_begin(h, n_queries, q_scan_ids, cand_scan_ids, n_cand, cand_stream_ids, init_T, params));
+  return gloc_reg_batch_multi_end(h, out_T, out_rmse, out_inliers, out_ok);
 }
 
 int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,

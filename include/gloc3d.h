@@ -196,6 +196,10 @@ void gloc_reg_default_params(gloc_reg_params* p);
 
 int gloc_reg_create(int device, gloc_reg** out);
 int gloc_reg_destroy(gloc_reg* h);
+/* Use `hip_stream` for all work of this handle (NULL: back to its own).  Handles may SHARE a stream: a batch call
+ * returns when its own results have arrived (an event behind its last copy), not when the stream is idle, so two
+ * handles driven by two host threads queue their batches back to back on one stream -- the device never waits for the
+ * host between batches (bench.py's registration pipeline). */
 int gloc_reg_set_stream(gloc_reg* h, void* hip_stream);
 int gloc_reg_synchronize(gloc_reg* h);
 int gloc_reg_set_option(gloc_reg* h, int option, int64_t value);
@@ -299,6 +303,18 @@ int gloc_reg_batch_multi(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_i
                          const uint32_t* cand_stream_ids, const float* init_T,
                          const gloc_reg_params* params, float* out_T, float* out_rmse,
                          uint32_t* out_inliers, int* out_ok);
+
+/* The same in two halves.  begin: looks the scans up and ENQUEUES the whole launch sequence of the batch plus the copy of
+ * its results on the handle's stream, then returns without waiting (nothing it needs from the caller is read later).
+ * end: waits for THAT batch's results (its own event, not the stream) and writes the outputs, rows as in
+ * gloc_reg_batch_multi.  One batch per handle may be in flight.  Two handles that share a stream (gloc_reg_set_stream)
+ * pipeline a stream of batches from one host thread: begin(A, batch i + 1) goes in before end(B, batch i), so the
+ * device runs batch after batch while the host post-processes -- bench.py's registration pipeline.  The scans of a batch
+ * must stay in the store until its end. */
+int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_scan_ids,
+                               const uint32_t* cand_scan_ids, size_t n_cand, const uint32_t* cand_stream_ids,
+                               const float* init_T, const gloc_reg_params* params);
+int gloc_reg_batch_multi_end(gloc_reg* h, float* out_T, float* out_rmse, uint32_t* out_inliers, int* out_ok);
 
 /* The reference's candidate loop as it is written -- stop at the first match()==true
  * (registration/global_localization.cpp:519-572) -- for several queries at once: rank by rank, the

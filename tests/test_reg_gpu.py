@@ -424,6 +424,40 @@ def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
     store.close()
 
 
+def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
+    """gloc_reg_batch_multi_begin / _end: two handles with their own workspaces on ONE stream, batch i + 1 enqueued
+    before batch i's results are waited for (bench.py's registration pipeline).  Every batch equals the blocking call
+    bit for bit; one batch per handle in flight; end without begin is an error."""
+    import torch
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qs = [store.add(np.ascontiguousarray(x)) for x in (B[::20], A[5::33], B[3::45], Cc[1::50])]
+    cs = [store.add(np.ascontiguousarray(x)) for x in (A[::6], A[1::7], Cc[::6])]
+    store.build_target_index_batch(cs)
+    cand = np.array([cs, cs[::-1]], np.uint32)
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6)
+    ref = capi.Registrar(store=store)
+    want = [ref.batch_multi(qs[2 * b:2 * b + 2], cand, params=prm) for b in range(2)]
+    stream = torch.cuda.Stream()
+    h = [capi.Registrar(store=store), capi.Registrar(store=store)]
+    for r in h:
+        r.set_stream(stream.cuda_stream)
+    for rep in range(3):                                   # a stream of batches: 0 1 0 1 0 1, always one ahead
+        h[0].batch_multi_begin(qs[0:2], cand, params=prm)
+        with pytest.raises(capi.GlocError):
+            h[0].batch_multi_begin(qs[0:2], cand, params=prm)          # already one in flight on this handle
+        h[1].batch_multi_begin(qs[2:4], cand, params=prm)              # queued behind it, before it is waited for
+        got = [h[0].batch_multi_end(), h[1].batch_multi_end()]
+        for g, w in zip(got, want):
+            assert (bits(g["T"]) == bits(w["T"])).all() and (bits(g["rmse"]) == bits(w["rmse"])).all()
+            assert (g["inliers"] == w["inliers"]).all() and (g["ok"] == w["ok"]).all()
+    with pytest.raises(capi.GlocError):
+        h[0].batch_multi_end()
+    for r in h + [ref]:
+        r.close()
+    store.close()
+
+
 def test_first_success_equals_select_over_the_full_batch(capi, scans):
     """The reference's stop-at-first-success loop (global_localization.cpp:519-572) for several queries at once:
     the same rank and pose, bit for bit, as registering all candidates and selecting afterwards -- with fewer

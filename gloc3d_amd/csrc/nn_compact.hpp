@@ -15,8 +15,8 @@
 //     one listed source against TWO of the chunk's sub-block boxes (stored interleaved for packed fp32);
 //     every (source, sub-block) pair that can still hold a nearer (or equally near) point becomes a work
 //     item in a wave-private LDS queue, consumed 64 items at a time: a lane walks ITS sub-block's 16 staged
-//     targets and folds the minimum into the source's packed (d2 bits << 32 | sub-block << 1 | half) key
-//     with an LDS atomic min; the index recovery re-reads the 8 targets of the winning half.
+//     targets and folds the minimum into the source's packed (d2 bits << 32 | sub-block << 2 | quarter) key
+//     with an LDS atomic min; the index recovery re-reads the 4 targets of the winning quarter.
 // A box is skipped only when a conservative lower bound of its distance exceeds the current best
 // of the point (or of every point of the wave), so no candidate for the minimum (or for a tie) is missed.
 //
@@ -39,6 +39,9 @@ namespace reg {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GPTR(T) const T __attribute__((address_space(1)))*
+// the same memory seen as constant: a load through it with a wave-uniform address is a scalar load (s_load), which
+// costs no vector instruction -- the boxes of a scan do not change while a search runs
+#define CPTR(T) const T __attribute__((address_space(4)))*
 #ifndef GLOC_NN_WPB
 #define GLOC_NN_WPB 1  // waves per work-group; waves never synchronise with each other, and 1 measured 4 % faster than 4
 #endif
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
     f32x4 src[S + 1];               // moved source points; [S]: a dummy the padded tail of the list points at
-    unsigned long long key[S + 1];  // (bits(best d2) << 32) | (sub-block holding it << 1) | its half; [S]: bound -1 (nothing passes)
+    unsigned long long key[S + 1];  // (bits(best d2) << 32) | (sub-block holding it << 2) | its quarter; [S]: bound -1 (nothing passes)
     uint8_t tie[S];                 // (CS = 2: 6.8 KB per wave; five waves per SIMD -- 88 VGPRs -- need <= 8 KB)
     uint16_t list[S + 16];          // source slots that passed the chunk-level test, padded to a multiple of 16 with S
     uint16_t queue[QCAP];           // work items: (source slot << 3) | sub-block within the chunk
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     uint32_t n, nchunks;
     GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
     uint32_t nsup;
+    CPTR(f32x4) cbox_lo; CPTR(f32x4) cbox_hi;
   };
   // The index arrays are reached through pointers loaded from memory, which the compiler would
   // treat as generic (flat_load): view them in the global address space explicitly.
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
                      (GPTR(f32x4))ixg.sb2, (GPTR(uint32_t))ixg.keys, (GPTR(uint32_t))ixg.kpos,
                      (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
-                     (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup};
+                     (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup,
+                     (CPTR(f32x4))ixg.box_lo, (CPTR(f32x4))ixg.box_hi};
   GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
   float T[12];
 #pragma unroll
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       if (j < ix.n) {
         const f32x4 t = ix.pts[j];
         best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
-        b0 = j / (SB / 2);  // the key's low word: (sub-block << 1) | half of the sub-block
+        b0 = j / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
       } else {
         const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
         uint32_t lo = 0, hi = ix.n;  // lower_bound over the sorted keys
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
           if (dd < best[s]) {
             best[s] = dd;
-            b0 = pj / (SB / 2);
+            b0 = pj / (SB / 4);
           }
         }
       }
@@ -283,14 +288,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
-      const uint32_t c = c0 + b;
-      f32x4 lo, hi;
-      lo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.x), b));
-      lo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.y), b));
-      lo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo.z), b));
-      hi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.x), b));
-      hi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.y), b));
-      hi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi.z), b));
+      const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
+      // the chunk's box straight into scalar registers (round 3: six v_readlane from the lane that tested it before)
+      const f32x4 lo = ix.cbox_lo[c], hi = ix.cbox_hi[c];
       bool need[CS];
       unsigned long long nm[CS], nm_any = 0ull;  // the ballots, taken where the comparisons are made
       if constexpr (CS == 2) {  // box_lb() of the lane's two points per packed instruction
@@ -364,9 +364,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           const f32x4 p = L.src[slot];
           const float* sb = &L.stage[bi * SB_STRIDE];
           const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
-          // the minimum of each HALF of the sub-block: the key records which half holds the minimum, so the index
-          // recovery re-reads 8 targets instead of 16 (equal halves -- two targets at the minimum -- take the tie path)
-          float mh[2] = {3.402823466e+38f, 3.402823466e+38f};
+          // the minimum of each QUARTER of the sub-block: the key records which quarter holds the minimum, so the index
+          // recovery re-reads 4 targets instead of 16 (round 2: halves, 8); a minimum attained in two quarters -- two
+          // targets at the minimum distance -- takes the tie path
+          float mq[4] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
   #pragma unroll
           for (int i = 0; i < SB / 2; ++i) {
             const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
@@ -374,19 +375,22 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
             const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
             const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-            mh[i / (SB / 4)] = fminf(fminf(mh[i / (SB / 4)], d2.x), d2.y);
+            mq[i / (SB / 8)] = fminf(fminf(mq[i / (SB / 8)], d2.x), d2.y);
           }
-          const float m = fminf(mh[0], mh[1]);
+          const float m = fminf(fminf(fminf(mq[0], mq[1]), mq[2]), mq[3]);
           if (act) {
             const uint32_t blk = c * NSB + bi;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 2u + (mh[1] < mh[0] ? 1u : 0u));
+            const bool e0 = mq[0] == m, e1 = mq[1] == m, e2 = mq[2] == m, e3 = mq[3] == m;
+            const uint32_t quarter = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
+            const bool twice = (e0 && (e1 || e2 || e3)) || (e1 && (e2 || e3)) || (e2 && e3);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 4u + quarter);
             const unsigned long long old = atomicMin(&L.key[slot], key);
-            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in both halves of this
+            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in two quarters of this
             // one.  Both need an exact equality first: the rest is looked at only when some lane has one (rare).
             const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
-            const bool maybe = od == md || mh[0] == mh[1];
+            const bool maybe = od == md || twice;
             if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
-              if ((od == md && ((uint32_t)old >> 1) != blk) || (md <= od && mh[0] == mh[1])) L.tie[slot] = 1;
+              if ((od == md && ((uint32_t)old >> 2) != blk) || (md <= od && twice)) L.tie[slot] = 1;
             }
           }
         }
@@ -473,18 +477,18 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     bpos[s] = 0xFFFFFFFFu;
     if (!valid[s] || !ix.n) continue;
     const int slot = s * 64 + lane;
-    const uint32_t bch = (uint32_t)L.key[slot];  // (sub-block << 1) | half: 8 targets
+    const uint32_t bch = (uint32_t)L.key[slot];  // (sub-block << 2) | quarter: 4 targets
     const bool tie = L.tie[slot] != 0;
     uint32_t bj = 0xFFFFFFFFu;
     if (!tie) {
       // (the store pads the scan to whole chunks, so the loads are unconditional)
-      GPTR(f32x4) tp = ix.pts + (size_t)bch * (SB / 2);
+      GPTR(f32x4) tp = ix.pts + (size_t)bch * (SB / 4);
       const f32x2 pxy = {px[s], py[s]};
-      f32x4 t[SB / 2];
+      f32x4 t[SB / 4];
 #pragma unroll
-      for (int u = 0; u < SB / 2; ++u) t[u] = tp[u];
+      for (int u = 0; u < SB / 4; ++u) t[u] = tp[u];
 #pragma unroll
-      for (int u = 0; u < SB / 2; ++u) {
+      for (int u = 0; u < SB / 4; ++u) {
         // dist2(): x and y share one packed instruction (a loaded point's x, y are a register pair);
         // same roundings as the scalar form
         const f32x2 dxy = pxy - f32x2{t[u].x, t[u].y};
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
         if (d2 == best[s] && o < bj) {
           bj = o;
-          bpos[s] = bch * (SB / 2) + u;
+          bpos[s] = bch * (SB / 4) + u;
         }
       }
     } else {  // rare: every chunk that can hold a point at the minimum distance

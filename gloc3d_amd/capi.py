@@ -187,10 +187,10 @@ _PROTOS = [
     ("gloc_coarse_add_image", _i, [_vp, _vp, _u32, _u32, C.c_float, C.c_float, C.c_float, _vp, C.POINTER(_u32)]),
     ("gloc_coarse_add_scan", _i, [_vp, _vp, _sz, _sz, _vp, C.POINTER(_u32)]),
     ("gloc_coarse_add_store_scan", _i, [_vp, _vp, _u32, _vp, C.POINTER(_u32)]),
-    ("gloc_coarse_match_pairs", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    ("gloc_coarse_match_pairs", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("gloc_coarse_release", _i, [_vp, _u32]),
     ("gloc_coarse_cells", _i, [_vp, _u32, C.POINTER(_u32), _vp, _sz]),
-    ("gloc_coarse_match", _i, [_vp, _u32, _vp, _sz, _vp, _vp, _vp, _vp]),
+    ("gloc_coarse_match", _i, [_vp, _u32, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("gloc_ground_default_params", _i, [_vp]),
     ("gloc_ground_create", _i, [_i, C.POINTER(_vp)]),
     ("gloc_ground_destroy", _i, [_vp]),
@@ -901,8 +901,9 @@ class CoarseMatcher:
         n = qs.shape[0]
         assert ds.shape[0] == n
         xyyaw, ratio, ok = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        self.last_scale = np.empty(n, np.float32)     # the reference's `scale` output of the same match
         check(lib().gloc_coarse_match_pairs(self._h, _np_ptr(qs), _np_ptr(ds), n, C.byref(self.params), _np_ptr(xyyaw),
-                                            _np_ptr(ratio), _np_ptr(ok)))
+                                            _np_ptr(ratio), _np_ptr(ok), _np_ptr(self.last_scale)))
         return xyyaw, ratio, ok.astype(bool)
 
     def release(self, grid_id):
@@ -919,8 +920,9 @@ class CoarseMatcher:
         ids = np.ascontiguousarray(db_grids, np.uint32)
         n = ids.shape[0]
         xyyaw, ratio, ok = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        self.last_scale = np.empty(n, np.float32)     # the reference's `scale` output of the same match
         check(lib().gloc_coarse_match(self._h, int(q_grid), _np_ptr(ids), n, C.byref(self.params), _np_ptr(xyyaw),
-                                      _np_ptr(ratio), _np_ptr(ok)))
+                                      _np_ptr(ratio), _np_ptr(ok), _np_ptr(self.last_scale)))
         return xyyaw, ratio, ok.astype(bool)
 
 

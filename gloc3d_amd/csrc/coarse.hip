@@ -26,7 +26,7 @@ struct gloc_coarse {
   std::vector<float> res;         // would silently return a wrong (x, y, yaw), so it is rejected
   std::vector<uint32_t> free_ids;
   DevBuf scratch_bits, scratch_cnt, stage_img, tiny_img;
-  DevBuf d_grids, d_pq, d_pd, d_trig, d_yaw, d_yawout, d_cand, d_verify, d_out;
+  DevBuf d_grids, d_pq, d_pd, d_trig, d_yaw, d_yawout, d_cand, d_verify, d_out, d_scale;
   bool grids_dirty = true;
   uint32_t trig_n = 0;
   gloc_bev* bev = nullptr;        // created on first add_scan
@@ -146,7 +146,7 @@ int gloc_coarse_destroy(gloc_coarse* h) {
   for (void* b : h->blocks)
     if (b) (void)hipFree(b);
   for (DevBuf* b : {&h->scratch_bits, &h->scratch_cnt, &h->stage_img, &h->tiny_img, &h->d_grids, &h->d_pq, &h->d_pd, &h->d_trig,
-                    &h->d_yaw, &h->d_yawout, &h->d_cand, &h->d_verify, &h->d_out})
+                    &h->d_yaw, &h->d_yawout, &h->d_cand, &h->d_verify, &h->d_out, &h->d_scale})
     b->release();
   if (h->bev) (void)gloc_bev_destroy(h->bev);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -278,15 +278,17 @@ int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t 
 }
 
 int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
-                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok) {
+                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok,
+                      float* out_scale) {
   GLOC_REQUIRE(h && db_grids, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_db >= 1 && n_db <= 65536, GLOC_ERR_INVALID, "n_db = %zu outside [1,65536]", n_db);
   std::vector<uint32_t> q(n_db, q_grid);
-  return gloc_coarse_match_pairs(h, q.data(), db_grids, n_db, params, out_xy_yaw, out_ratio, out_ok);
+  return gloc_coarse_match_pairs(h, q.data(), db_grids, n_db, params, out_xy_yaw, out_ratio, out_ok, out_scale);
 }
 
 int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint32_t* db_grids, size_t n_pairs_in,
-                            const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok) {
+                            const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok,
+                            float* out_scale) {
   GLOC_REQUIRE(h && q_grids && db_grids && out_xy_yaw, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_pairs_in >= 1 && n_pairs_in <= 65536, GLOC_ERR_INVALID, "n_pairs = %zu outside [1,65536]", n_pairs_in);
   GLOC_TRY(check_params(params));
@@ -346,6 +348,12 @@ int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint3
                      h->d_pq.as<uint32_t>(), n_cand, n_pairs, n_yaw, (float)params->cell_px * params->resolution,
                      params->min_overlap,
                      h->d_yaw.as<float>(), h->d_out.as<MatchOut>());
+  GLOC_TRY(h->d_scale.ensure(sizeof(uint32_t) * N_SCALES * (size_t)n_pairs, s));
+  hipLaunchKernelGGL(scale_kernel, dim3(N_SCALES, n_pairs), dim3(256), 0, s, dg, dg, h->d_pq.as<uint32_t>(),
+                     h->d_pd.as<uint32_t>(), h->d_trig.as<float>(), (int)params->cell_px, (int)params->refine,
+                     h->d_out.as<MatchOut>(), h->d_scale.as<uint32_t>());
+  hipLaunchKernelGGL(scale_final_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, s, h->d_scale.as<uint32_t>(), n_pairs,
+                     h->d_out.as<MatchOut>());
   GLOC_HIP(hipGetLastError());
   std::vector<MatchOut> mo(n_pairs);
   GLOC_HIP(hipMemcpyAsync(mo.data(), h->d_out.p, sizeof(MatchOut) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -356,6 +364,7 @@ int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint3
     out_xy_yaw[3 * i + 2] = mo[i].yaw;
     if (out_ratio) out_ratio[i] = mo[i].ratio;
     if (out_ok) out_ok[i] = mo[i].ok;
+    if (out_scale) out_scale[i] = mo[i].scale;
   }
   return GLOC_OK;
 }

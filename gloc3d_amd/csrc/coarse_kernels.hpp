@@ -280,6 +280,9 @@ struct MatchOut {  // per pair
   float x, y, yaw, ratio;
   uint32_t overlap, n_query, k;
   int ok;
+  int tx, ty;      // the shift in cells (scale_kernel)
+  float scale;     // least-squares scale of the matched cells (scale_kernel)
+  uint32_t n_matched;
 };
 
 // per pair: the candidate with the largest overlap (ties: the earlier candidate); the identity candidate
@@ -307,7 +310,97 @@ __global__ void final_kernel(const VerifyOut* __restrict__ vo, const GridDev* __
   o.k = b.k;
   o.ratio = nq ? (float)b.overlap / (float)nq : 0.f;
   o.ok = (nq >= 16 && (float)b.overlap >= min_overlap * (float)nq) ? 1 : 0;
+  o.tx = b.tx;
+  o.ty = b.ty;
+  o.scale = 0.f;
+  o.n_matched = 0;
   out[pair] = o;
+}
+
+// The reference's match also estimates a SCALE (cv::estimateAffinePartial2D fits a similarity) and accepts only
+// |1 - scale| < 0.1 (loop_detector.cpp:262-272).  Here: under the chosen rotation, the overlap search of verify_kernel
+// is repeated with the query's cells scaled about the sensor by each of N_SCALES factors 0.88 .. 1.12 (p_db = s R p_q + t;
+// a cell 30 m out moves by three cells per 4 %, so the overlap is sharply peaked in s), each over the shifts within
+// `refine` of the chosen one; the estimate is the factor with the largest overlap (ties: the one nearest 1, then the
+// smaller), refined by the parabola through its neighbours' overlaps when it is not an end of the range -- integer
+// counts and a few fp64 operations, so the CPU restatement gets the same bits.  An end of the range means "10 % or
+// more": ok is withdrawn unless |1 - scale| < 0.1.
+constexpr int N_SCALES = 7;
+__host__ __device__ inline float scale_factor(int j) { return 0.88f + 0.04f * (float)j; }
+__host__ __device__ inline void rotate_scale_cell(uint32_t uv, float c, float s, float f, int cell_px, int& u, int& v) {
+  const float x = cell_centre_px((int)(uv & 0xFFFF), cell_px), y = cell_centre_px((int)(uv >> 16), cell_px);
+  const float a0 = c * x, a1 = s * y, b0 = s * x, b1 = c * y;
+  const float rx = a0 - a1, ry = b0 + b1;
+  u = cell_of_px(round_half_away_f(rx * f), cell_px);
+  v = cell_of_px(round_half_away_f(ry * f), cell_px);
+}
+// overlaps[N_SCALES] -> the estimate
+__host__ __device__ inline float scale_from_overlaps(const uint32_t* o) {
+  int best = N_SCALES / 2;  // 1.0 first: ties go to the factor nearest 1, then to the smaller one
+  for (int d = 1; d <= N_SCALES / 2; ++d) {
+    if (o[N_SCALES / 2 - d] > o[best]) best = N_SCALES / 2 - d;
+    if (o[N_SCALES / 2 + d] > o[best]) best = N_SCALES / 2 + d;
+  }
+  if (o[best] == 0u) return 0.f;
+  double est = (double)scale_factor(best);
+  if (best > 0 && best < N_SCALES - 1) {
+    const double a = (double)o[best - 1], b0 = (double)o[best], c = (double)o[best + 1];
+    const double den = a - 2.0 * b0 + c;
+    if (den < 0.0) est += 0.5 * 0.04 * (a - c) / den;
+  }
+  return (float)est;
+}
+
+// grid (N_SCALES, n_pairs), 256 threads: as verify_kernel, for the pair's chosen rotation and shift, one scale each
+__global__ __launch_bounds__(256) void scale_kernel(const GridDev* __restrict__ qgrids, const GridDev* __restrict__ dgrids,
+                                                    const uint32_t* __restrict__ pair_q, const uint32_t* __restrict__ pair_d,
+                                                    const float* __restrict__ trig, int cell_px, int refine,
+                                                    const MatchOut* __restrict__ mo_all, uint32_t* __restrict__ overlaps) {
+  __shared__ uint32_t bm[G * GW];
+  __shared__ uint32_t red[4];
+  __shared__ uint32_t best;
+  const int tid = threadIdx.x;
+  const uint32_t j = blockIdx.x, pair = blockIdx.y;
+  const MatchOut mo = mo_all[pair];
+  const GridDev q = qgrids[pair_q[pair]], d = dgrids[pair_d[pair]];
+  for (int i = tid; i < G * GW; i += 256) bm[i] = d.dil[i];
+  if (tid == 0) best = 0u;
+  __syncthreads();
+  const float c = trig[2 * mo.k], s = trig[2 * mo.k + 1], f = scale_factor((int)j);
+  const uint32_t n = *q.count;
+  const int side = 2 * refine + 1;
+  for (int o = 0; o < side * side; ++o) {
+    const int tx = mo.tx + o % side - refine, ty = mo.ty + o / side - refine;
+    uint32_t cnt = 0;
+    for (uint32_t i = tid; i < n; i += 256) {
+      int u, v;
+      rotate_scale_cell(q.cells[i], c, s, f, cell_px, u, v);
+      if (u < 0 || v < 0) continue;
+      u += tx;
+      v += ty;
+      if (u < 0 || u >= G || v < 0 || v >= G) continue;
+      cnt += (bm[v * GW + (u >> 5)] >> (u & 31)) & 1u;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t total = red[0] + red[1] + red[2] + red[3];
+      if (total > best) best = total;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) overlaps[(size_t)pair * N_SCALES + j] = best;
+}
+
+__global__ void scale_final_kernel(const uint32_t* __restrict__ overlaps, uint32_t n_pairs, MatchOut* __restrict__ out) {
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= n_pairs) return;
+  MatchOut mo = out[pair];
+  mo.scale = scale_from_overlaps(overlaps + (size_t)pair * N_SCALES);
+  mo.n_matched = overlaps[(size_t)pair * N_SCALES + N_SCALES / 2];
+  if (!(fabsf(1.f - mo.scale) < 0.1f)) mo.ok = 0;
+  out[pair] = mo;
 }
 
 }  // namespace coarse

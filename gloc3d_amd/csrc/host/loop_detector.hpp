@@ -77,27 +77,30 @@ class RpyPCLoopDetector {
   }
 
   // match(q_grid, db_idx, xy_yaw, scale) of the reference (loop_detector.cpp:186-288): the coarse pose of
-  // the query in place db_idx's frame, p_db = R(yaw) p_q + (x, y); the estimated scale is 1 by
-  // construction.  Here the query goes in as its scan (its grid is made on the device).
+  // the query in place db_idx's frame, p_db = R(yaw) p_q + (x, y), and the scale estimated from the matched cells;
+  // true iff the grids overlap enough AND |1 - scale| < 0.1 (loop_detector.cpp:268-272).  Here the query goes in as
+  // its scan (its grid is made on the device).
   bool match(const float* q_scan_xyzi, size_t n_pts, size_t db_idx, float xy_yaw[3], double& estimated_scale) {
-    std::vector<float> out(3);
+    std::vector<float> out(3), sc(1);
     std::vector<int> ok(1);
-    match_2d(q_scan_xyzi, n_pts, {db_idx}, out, ok);
+    match_2d(q_scan_xyzi, n_pts, {db_idx}, out, ok, &sc);
     xy_yaw[0] = out[0]; xy_yaw[1] = out[1]; xy_yaw[2] = out[2];
-    estimated_scale = 1.0;
+    estimated_scale = (double)sc[0];
     return ok[0] != 0;
   }
   void match_2d(const float* q_scan_xyzi, size_t n_pts, const std::vector<size_t>& db_indices,
-                std::vector<float>& xy_yaw /* n x 3 */, std::vector<int>& ok) {
+                std::vector<float>& xy_yaw /* n x 3 */, std::vector<int>& ok, std::vector<float>* scale = nullptr) {
     const size_t n = db_indices.size();
     xy_yaw.assign(3 * n, 0.f);
     ok.assign(n, 0);
+    if (scale) scale->assign(n, 0.f);
     if (n == 0) return;
     uint32_t qg = 0;
     check(gloc_coarse_add_scan(coarse_, q_scan_xyzi, n_pts, 4, &coarse_params_, &qg));
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = db_grid_ids_.at(db_indices[i]);
-    const int rc = gloc_coarse_match(coarse_, qg, ids.data(), n, &coarse_params_, xy_yaw.data(), nullptr, ok.data());
+    const int rc = gloc_coarse_match(coarse_, qg, ids.data(), n, &coarse_params_, xy_yaw.data(), nullptr, ok.data(),
+                                     scale ? scale->data() : nullptr);
     gloc_coarse_release(coarse_, qg);
     check(rc);
   }

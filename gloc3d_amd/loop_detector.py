@@ -115,10 +115,13 @@ class RpyPCLoopDetector:
     def match_2d(self, q_scan, db_indices):
         """RpyPCLoopDetector::match(q_grid, db_idx, xy_yaw, scale) (loop_detector.cpp:186-288) for several
         places at once: the coarse pose of the query in each place's frame, p_db = R(yaw) p_q + (x, y).
-        Returns (xy_yaw [n, 3], overlap ratio [n], ok [n]); the scale the reference estimates is 1 here."""
+        Returns (xy_yaw [n, 3], overlap ratio [n], ok [n]); ok includes the reference's |1 - scale| < 0.1, the
+        estimated scales are left in self.last_match_scale."""
         qg = self._coarse.add_scan(np.ascontiguousarray(q_scan, np.float32))
         try:
-            return self._coarse.match(qg, [self._db_grid_ids[int(i)] for i in db_indices])
+            out = self._coarse.match(qg, [self._db_grid_ids[int(i)] for i in db_indices])
+            self.last_match_scale = self._coarse.last_scale
+            return out
         finally:
             self._coarse.release(qg)
 

@@ -439,7 +439,8 @@ int gloc_bev_profile(gloc_bev* h, const char* kernel, double* total_ms, uint64_t
  * partial-affine fit (OpenCV + contrib, absent here); this finds it with an exhaustive integer search on
  * the GPU -- every yaw step x every shift, scored by how many occupied query cells land on occupied
  * database cells (coarse_kernels.hpp) -- so a reverse-direction revisit is handled as well as a small
- * offset.  The result seeds the 3-D registration (init_T of gloc_reg_batch*), as the reference seeds its pose
+ * offset, and a scale estimate with the reference's |1 - scale| < 0.1 acceptance on top (round 3).
+ * The result seeds the 3-D registration (init_T of gloc_reg_batch*), as the reference seeds its pose
  * composition (global_localization.cpp:526-570).  Parity: unpinned upstream (third-party arithmetic, no
  * fixtures); oracle/coarse_oracle.c states the search step by step and the GPU equals it exactly. */
 typedef struct gloc_coarse gloc_coarse;
@@ -475,13 +476,18 @@ int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id);
 int gloc_coarse_cells(gloc_coarse* h, uint32_t grid_id, uint32_t* n_cells, uint32_t* out_cells,
                       size_t capacity);
 /* One query grid against n_db database grids: out_xy_yaw [n_db][3] = (x, y, yaw in (-pi, pi]),
- * out_ratio = overlapping / occupied query cells, out_ok (either may be NULL). */
+ * out_ratio = overlapping / occupied query cells, out_scale = the `scale` of the reference's match (the similarity
+ * factor cv::estimateAffinePartial2D fits, loop_detector.cpp:262-266): here the factor in 0.88 .. 1.12 by which the
+ * query, scaled about the sensor under the chosen rotation, overlaps the database grid most (parabola-refined; an end of
+ * the range means "10 % or more off"; 0: no overlap at all); out_ok = enough overlap
+ * AND |1 - scale| < 0.1, the reference's acceptance (loop_detector.cpp:268-272).  Any of the three may be NULL. */
 int gloc_coarse_match(gloc_coarse* h, uint32_t q_grid, const uint32_t* db_grids, size_t n_db,
-                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok);
+                      const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio, int* out_ok,
+                      float* out_scale);
 /* n independent (query grid, database grid) pairs in one launch sequence (several queries in flight). */
 int gloc_coarse_match_pairs(gloc_coarse* h, const uint32_t* q_grids, const uint32_t* db_grids, size_t n_pairs,
                             const gloc_coarse_params* params, float* out_xy_yaw, float* out_ratio,
-                            int* out_ok);
+                            int* out_ok, float* out_scale);
 
 /* ============================ ground pre-alignment ("next" row N3) ========================= *
  * Replaces GroundEstimator::EsitmateGroundAndTransform (registration/ground_estimator.cpp:196-228),

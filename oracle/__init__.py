@@ -138,6 +138,7 @@ def lib():
         L.oracle_coarse_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_float, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_int),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_coarse_match_scale.argtypes = L.oracle_coarse_match.argtypes + [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -394,7 +395,8 @@ class CoarseGrid:
 
 def coarse_match(q, d, n_yaw=360, max_shift=64, top_yaw=12, refine=4, min_overlap=0.25):
     xyyaw = np.empty(3, np.float32)
-    ratio, ok, over, k = C.c_float(), C.c_int(), C.c_uint32(), C.c_uint32()
-    lib().oracle_coarse_match(q._g, d._g, q.res, q.cell_px, n_yaw, max_shift, top_yaw, refine, min_overlap, xyyaw,
-                              C.byref(ratio), C.byref(ok), C.byref(over), C.byref(k))
-    return dict(xy_yaw=xyyaw, ratio=ratio.value, ok=bool(ok.value), overlap=over.value, k=k.value)
+    ratio, ok, over, k, scale, nm = C.c_float(), C.c_int(), C.c_uint32(), C.c_uint32(), C.c_float(), C.c_uint32()
+    lib().oracle_coarse_match_scale(q._g, d._g, q.res, q.cell_px, n_yaw, max_shift, top_yaw, refine, min_overlap, xyyaw,
+                                    C.byref(ratio), C.byref(ok), C.byref(over), C.byref(k), C.byref(scale), C.byref(nm))
+    return dict(xy_yaw=xyyaw, ratio=ratio.value, ok=bool(ok.value), overlap=over.value, k=k.value, scale=scale.value,
+                matched=nm.value)

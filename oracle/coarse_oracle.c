@@ -23,7 +23,13 @@
  *           of the DILATED database map; largest count, ties -> first in (dy, dx) row-major order;
  *   result  the rotation candidate with the largest count (ties -> the earlier one) if it has more
  *           than 1.2 x the identity's count, else the identity; ok iff n_query >= 16 and
- *           count >= min_overlap * n_query (fp32 comparison).
+ *           count >= min_overlap * n_query (fp32 comparison);
+ *   scale   (round 3: the `scale` of the reference's match and its acceptance |1 - scale| < 0.1,
+ *           loop_detector.cpp:262-272) under the chosen rotation the overlap search is repeated with the query's cells
+ *           scaled about the sensor by 0.88, 0.92 .. 1.12 (rounded after scaling), each over the shifts within
+ *           `refine` of the chosen one; scale = the factor with the largest overlap (ties: nearest 1, then the smaller),
+ *           refined by the parabola through its neighbours' overlaps unless it is an end of the range; no overlap at
+ *           all -> 0; ok is withdrawn unless |1 - scale| < 0.1 (fp32).
  */
 #include "gloc_oracle.h"
 
@@ -134,10 +140,70 @@ static uint32_t overlap_at(const oracle_coarse_grid* q, const oracle_coarse_grid
   return cnt;
 }
 
+#define N_SCALES 7
+static float scale_factor(int j) { return 0.88f + 0.04f * (float)j; }
+
+static uint32_t overlap_scaled(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float c, float s, float f, int cell,
+                               int tx, int ty) {
+  uint32_t cnt = 0;
+  for (uint32_t i = 0; i < q->n; ++i) {
+    const uint32_t uv = q->cells[i];
+    const float x = cell_centre_px((int)(uv & 0xFFFF), cell), y = cell_centre_px((int)(uv >> 16), cell);
+    const float a0 = c * x, a1 = s * y, b0 = s * x, b1 = c * y;
+    const float rx = a0 - a1, ry = b0 + b1;
+    int u = cell_of_px(round_half_away_f(rx * f), cell), v = cell_of_px(round_half_away_f(ry * f), cell);
+    if (u < 0 || v < 0) continue;
+    u += tx;
+    v += ty;
+    if (u < 0 || u >= CG || v < 0 || v >= CG) continue;
+    cnt += (uint32_t)get_bit(d->dil, u, v);
+  }
+  return cnt;
+}
+
+/* the overlap search repeated with the query scaled about the sensor by 0.88 .. 1.12, each over the shifts within
+ * `refine` of the chosen one; the factor with the largest overlap (ties: nearest 1, then the smaller), refined by the
+ * parabola through its neighbours when it is not an end of the range */
+static float estimate_scale(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float c, float s, int cell, int tx,
+                            int ty, int W, uint32_t* n_matched) {
+  uint32_t o[N_SCALES];
+  for (int j = 0; j < N_SCALES; ++j) {
+    uint32_t best = 0;
+    for (int dy = -W; dy <= W; ++dy)
+      for (int dx = -W; dx <= W; ++dx) {
+        const uint32_t v = overlap_scaled(q, d, c, s, scale_factor(j), cell, tx + dx, ty + dy);
+        if (v > best) best = v;
+      }
+    o[j] = best;
+  }
+  if (n_matched) *n_matched = o[N_SCALES / 2];
+  int best = N_SCALES / 2;
+  for (int dd = 1; dd <= N_SCALES / 2; ++dd) {
+    if (o[N_SCALES / 2 - dd] > o[best]) best = N_SCALES / 2 - dd;
+    if (o[N_SCALES / 2 + dd] > o[best]) best = N_SCALES / 2 + dd;
+  }
+  if (o[best] == 0u) return 0.f;
+  double est = (double)scale_factor(best);
+  if (best > 0 && best < N_SCALES - 1) {
+    const double a = (double)o[best - 1], b0 = (double)o[best], cc = (double)o[best + 1];
+    const double den = a - 2.0 * b0 + cc;
+    if (den < 0.0) est += 0.5 * 0.04 * (a - cc) / den;
+  }
+  return (float)est;
+}
+
 void oracle_coarse_match(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float res, uint32_t cell_px,
                          uint32_t n_yaw, uint32_t max_shift, uint32_t top_yaw, uint32_t refine, float min_overlap,
                          float* out_xy_yaw, float* out_ratio, int* out_ok, uint32_t* out_overlap,
                          uint32_t* out_k) {
+  oracle_coarse_match_scale(q, d, res, cell_px, n_yaw, max_shift, top_yaw, refine, min_overlap, out_xy_yaw, out_ratio,
+                            out_ok, out_overlap, out_k, NULL, NULL);
+}
+
+void oracle_coarse_match_scale(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float res, uint32_t cell_px,
+                               uint32_t n_yaw, uint32_t max_shift, uint32_t top_yaw, uint32_t refine, float min_overlap,
+                               float* out_xy_yaw, float* out_ratio, int* out_ok, uint32_t* out_overlap,
+                               uint32_t* out_k, float* out_scale, uint32_t* out_matched) {
   const int T = (int)max_shift, W = (int)refine, cell = (int)cell_px;
   const float cell_m = (float)cell_px * res;
   float* cs = (float*)malloc(sizeof(float) * 2 * n_yaw);
@@ -229,8 +295,12 @@ void oracle_coarse_match(const oracle_coarse_grid* q, const oracle_coarse_grid* 
   out_xy_yaw[0] = (float)best_tx * cell_m;
   out_xy_yaw[1] = (float)best_ty * cell_m;
   out_xy_yaw[2] = (float)(a > M_PI ? a - 2.0 * M_PI : a);
+  const double ab = 2.0 * M_PI * (double)best_k / (double)n_yaw;
+  const float scale = estimate_scale(q, d, (float)cos(ab), (float)sin(ab), cell, best_tx, best_ty, W, out_matched);
+  if (out_scale) *out_scale = scale;
   if (out_ratio) *out_ratio = q->n ? (float)best_over / (float)q->n : 0.f;
-  if (out_ok) *out_ok = (q->n >= 16 && (float)best_over >= min_overlap * (float)q->n) ? 1 : 0;
+  if (out_ok)
+    *out_ok = (q->n >= 16 && (float)best_over >= min_overlap * (float)q->n && fabsf(1.f - scale) < 0.1f) ? 1 : 0;
   if (out_overlap) *out_overlap = best_over;
   if (out_k) *out_k = best_k;
   free(cs);

@@ -160,6 +160,12 @@ void oracle_coarse_match(const oracle_coarse_grid* q, const oracle_coarse_grid* 
                          uint32_t n_yaw, uint32_t max_shift, uint32_t top_yaw, uint32_t refine, float min_overlap,
                          float* out_xy_yaw, float* out_ratio, int* out_ok, uint32_t* out_overlap,
                          uint32_t* out_k);
+/* the same plus the scale estimate (round 3): *out_scale = least-squares scale of the matched cells (0: fewer than 16),
+ * *out_matched = pairs; out_ok includes the reference's |1 - scale| < 0.1 (loop_detector.cpp:268-272) */
+void oracle_coarse_match_scale(const oracle_coarse_grid* q, const oracle_coarse_grid* d, float res, uint32_t cell_px,
+                               uint32_t n_yaw, uint32_t max_shift, uint32_t top_yaw, uint32_t refine, float min_overlap,
+                               float* out_xy_yaw, float* out_ratio, int* out_ok, uint32_t* out_overlap,
+                               uint32_t* out_k, float* out_scale, uint32_t* out_matched);
 
 /* ---- BEV occupancy projection ("next" row N1; bev_oracle.c) --------------------------------- */
 

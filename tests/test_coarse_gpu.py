@@ -43,6 +43,10 @@ def test_grids_and_matches_equal_the_oracle(capi, oracle_mod, scans):
             o = oracle_mod.coarse_match(og[q], og[d])
             assert (bits(xyyaw[j]) == bits(o["xy_yaw"])).all(), (q, d, xyyaw[j], o)
             assert bits(np.float32(ratio[j])) == bits(np.float32(o["ratio"])) and bool(ok[j]) == o["ok"], (q, d)
+            # the scale estimate (the reference's `scale` output and its |1 - scale| < 0.1 acceptance): the same bits
+            assert bits(np.float32(cm.last_scale[j])) == bits(np.float32(o["scale"])), (q, d, cm.last_scale[j], o["scale"])
+            if d == "A" and q != "other":
+                assert ok[j] and abs(cm.last_scale[j] - 1.0) < 0.05
     # from a scan resident in a scan store (bench.py --coarse): the same grid; pairs in one launch sequence
     store = capi.ScanStore()
     sid = store.add(scans["A"])

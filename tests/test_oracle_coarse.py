@@ -27,6 +27,30 @@ def test_known_pose_is_recovered(oracle_mod, grids, case):
     assert abs(d) <= 2.0
 
 
+def test_scale_estimate_and_its_acceptance(oracle_mod, grids):
+    """The reference's match returns a scale and accepts only |1 - scale| < 0.1 (loop_detector.cpp:262-272).  Here the
+    factor by which the query, scaled about the sensor, overlaps the database grid most: ~1 for true revisits; a query
+    whose coordinates are stretched by 6 % comes back as 1 / 1.06, one stretched by 30 % is not accepted."""
+    from gloc3d_amd import synth
+    for case in CASES:
+        r = oracle_mod.coarse_match(grids[case], grids["A"])
+        assert r["ok"] and abs(r["scale"] - 1.0) < 0.02 and r["matched"] == r["overlap"]
+    w = synth.make_world(1001)
+    base = synth.lidar_scan(w, synth.se3(30.0, (6.0, -4.0, 0.0)), seed=2, n_az=1000)
+    scales = {}
+    for f in (1.0, 1.06, 1.3):
+        sc = base.copy()
+        sc[:, :2] *= np.float32(f)
+        img, info = oracle_mod.bev_project(sc)
+        r = oracle_mod.coarse_match(oracle_mod.CoarseGrid(img, info["ox"], info["oy"], info["resolution"]), grids["A"])
+        scales[f] = r
+    assert scales[1.0]["ok"] and abs(scales[1.0]["scale"] - 1.0) < 0.02
+    assert abs(scales[1.06]["scale"] - 1.0 / 1.06) < 0.02, scales[1.06]  # the database is SMALLER than the stretched query
+    assert not scales[1.3]["ok"]
+    e = oracle_mod.CoarseGrid(np.full((10, 10), 255, np.uint8), -1.0, -1.0, 0.2)
+    assert oracle_mod.coarse_match(e, grids["A"])["scale"] == 0.0       # no overlap at all
+
+
 def test_grid_and_rejection(oracle_mod, grids):
     from gloc3d_amd import synth
     cells = grids["A"].cells()

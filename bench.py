@@ -377,7 +377,7 @@ def main():
                     help="rehearsal: all ranks on GPU 0 (use with --backend gloo)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each step's queries inline")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="N = 1: wait for a step's registration before the next step's is enqueued (round 2's loop)")
+                    help="wait for a step's registration before the next step's is enqueued (round 2's loop)")
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
     ap.add_argument("--coarse", action="store_true",
                     help="also run the reference's 2-D step: the coarse (x, y, yaw) match of every (query, candidate) "
@@ -515,10 +515,11 @@ def main():
     if args.ransac_confidence is not None:
         params.ransac_confidence = args.ransac_confidence
     cur = {"params": params}       # (legs swap the parameters / the mode)
-    # Registration pipeline (N = 1): two handles with their own workspaces on ONE stream; batch i + 1 is enqueued
+    # Registration pipeline: two handles with their own workspaces on ONE stream; batch i + 1 is enqueued
     # (gloc_reg_batch_multi_begin) before batch i's results are waited for (gloc_reg_batch_multi_end), so the device runs
-    # batch after batch while the host unpacks, selects, releases and looks the next scans up
-    pipeline = world == 1 and args.mode == "throughput" and not args.no_pipeline
+    # batch after batch while the host unpacks, selects, releases and looks the next scans up.  One host thread: at
+    # N > 1 every rank issues its collectives in the same order (search i + 1, tables i, search i + 2, tables i + 1 ...)
+    pipeline = args.mode == "throughput" and not args.no_pipeline
     regs = [reg]
     if pipeline:
         reg_b = capi.Registrar(device=local_rank, store=store)
@@ -738,7 +739,10 @@ def main():
             t_a = time.time()
             r = h_.batch_multi_end()                       # waits for THAT batch; the next one is already queued behind it
             t_b = time.time()
-            tables = sharded.pack_results(r, cand_.shape)
+            nb_ = len(ids_)
+            tables = qreg.gather_tables(sharded.pack_results(r, (nb_, cand_.shape[1])), dev, capi_knn)   # all ranks' rows
+            if not isinstance(tables, np.ndarray):
+                tables = tables.detach().cpu().numpy()
             sels_.extend(sharded.ShardedRegistrar.select_first_ok(t) for t in tables)
             for sid in ids_:
                 store.release(sid)                         # (its batch has completed; no stream to wait for)
@@ -751,8 +755,8 @@ def main():
             if record:
                 stage["register"] += t_b - t_a
                 a_, _ = my_slice(i_, Bq)
-                for k in range(cand_.shape[0]):
-                    work_pairs.append((q_scan_host[a_ + k].shape[0], int(np.count_nonzero(cand_[k] >= 0))))
+                for k in range(nb_):
+                    work_pairs.append((q_scan_host[a_ + k].shape[0], int(np.count_nonzero(cand_[rank * nb_ + k] >= 0))))
 
         for i in range(first, first + count):
             t_a = time.time()
@@ -764,9 +768,10 @@ def main():
             idx, d2 = knn.search(qd, TOP_K)
             cand = idx.cpu().numpy()
             t_c = time.time()
-            init = coarse_init(ids, cand) if cm is not None else None
+            mine = cand[rank * len(ids):(rank + 1) * len(ids)]          # this rank's queries of the step
+            init = coarse_init(ids, mine) if cm is not None else None
             h = regs[i % 2]
-            h.batch_multi_begin(ids, scans_of(cand), params=cur["params"], init_T=init)
+            h.batch_multi_begin(ids, scans_of(mine), params=cur["params"], init_T=init)
             if record:
                 stage["prep_wait"] += t_b - t_a
                 stage["h2d_index"] += t_prep

@@ -196,9 +196,15 @@ class QueryParallelRegistrar:
         assert cand.shape[0] == self.world * K
         tables = np.ascontiguousarray(register_multi(my_queries, cand[self.rank * K:(self.rank + 1) * K]),
                                       np.float32)
+        return self.gather_tables(tables.reshape(K, n, RESULT_COLS), device, capi_knn)
+
+    def gather_tables(self, tables, device, capi_knn=None):
+        """This rank's [K, n, RESULT_COLS] result tables (numpy) -> all ranks' [G*K, n, RESULT_COLS], rank-major: ONE
+        all-gather (through the C ABI's communicator when `capi_knn` is given).  Collective."""
+        K, n = tables.shape[0], tables.shape[1]
         if self.world == 1:
-            return tables.reshape(K, n, RESULT_COLS)   # (host memory: the results already are there, nothing to exchange)
-        t = torch.from_numpy(tables.reshape(K * n, RESULT_COLS))
+            return tables   # (host memory: the results already are there, nothing to exchange)
+        t = torch.from_numpy(np.ascontiguousarray(tables, np.float32).reshape(K * n, RESULT_COLS))
         if capi_knn is not None:   # the all-gather through the C ABI's communicator
             return capi_knn.all_gather_tables(t.to(device).view(K, n, RESULT_COLS))
         t = t.to(self.comm_device or device)

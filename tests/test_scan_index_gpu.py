@@ -56,8 +56,10 @@ def clouds():
     dup = rng.uniform(-20, 20, (3000, 3)).astype(np.float32)
     dup[1000:2000] = dup[:1000]                           # exact duplicates: equal keys, equal coordinates
     dup[2500:] = np.float32(1.25)                         # 500 identical points
+    big = np.concatenate([full, full[:20000] + np.float32(0.013)])   # 143 929 points: 71 sort tiles (> 64: the scan
+                                                                      # kernel's carry over tile blocks), 14 kd levels
     return [full, np.ascontiguousarray(full[::7]), dup, rng.normal(0, 8, (2049, 3)).astype(np.float32),
-            rng.uniform(-5, 5, (17, 3)).astype(np.float32), rng.uniform(-5, 5, (1, 3)).astype(np.float32)]
+            rng.uniform(-5, 5, (17, 3)).astype(np.float32), rng.uniform(-5, 5, (1, 3)).astype(np.float32), big]
 
 
 def test_curve_order_is_sorted_stable_and_a_permutation(capi, clouds):

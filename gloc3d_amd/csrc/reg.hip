@@ -342,13 +342,32 @@ struct TempScans {
   gloc_scan_store* st;
   std::vector<DevScan> scans;
   explicit TempScans(gloc_scan_store* s) : st(s) {}
-  int add(const float* pts, size_t n, int cs, bool target_index = false) {
+  // Scan 0 = the source (launch order for `cs` sources per lane), scans 1.. = targets: uploaded and indexed in ONE
+  // launch sequence (round 2: one sequence of ~25 launches per scan, 21 scans for a top-20 registration)
+  int add_all(const float* src, size_t n_src, int cs, const float* const* tgt, const size_t* n_tgt, size_t n_tgts,
+              bool target_index) {
     std::lock_guard<std::mutex> lk(st->mu);
-    DevScan s;
-    GLOC_TRY(store_make_scan(st, pts, n, 3, false, &s));
-    scans.push_back(s);  // (owned from here on: freed by the destructor whatever happens below)
-    if (target_index) GLOC_TRY(store_build_target_index(st, scans.back()));
-    GLOC_TRY(store_build_order(st, scans.back(), cs));  // (cs = 0: a target, no order)
+    std::vector<const float*> p(1 + n_tgts);
+    std::vector<size_t> n(1 + n_tgts);
+    p[0] = src;
+    n[0] = n_src;
+    for (size_t c = 0; c < n_tgts; ++c) {
+      p[1 + c] = tgt[c];
+      n[1 + c] = n_tgt[c];
+    }
+    scans.resize(1 + n_tgts);
+    const int rc = store_make_scans(st, 1 + n_tgts, p.data(), n.data(), 3, false, scans.data());
+    if (rc != GLOC_OK) {
+      scans.clear();  // (store_make_scans released what it had allocated)
+      return rc;
+    }
+    if (target_index && n_tgts) {
+      std::vector<DevScan*> ps(n_tgts);
+      for (size_t c = 0; c < n_tgts; ++c) ps[c] = &scans[1 + c];
+      GLOC_TRY(store_build_target_indices(st, ps.data(), n_tgts));
+    }
+    GLOC_TRY(store_build_order(st, scans[0], cs));
+    for (size_t c = 0; c < n_tgts; ++c) scans[1 + c].order = nullptr;  // a target's launch order is never read
     return GLOC_OK;
   }
   ~TempScans() {
@@ -528,8 +547,7 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   }
   GLOC_TRY(ensure_store(h));
   TempScans tmp(h->store);  // released on return
-  GLOC_TRY(tmp.add(q_xyz, nq_pts, h->nn_src_per_lane));
-  for (size_t c = 0; c < n_cand; ++c) GLOC_TRY(tmp.add(cand_xyz[c], cand_npts[c], 0, h->temp_target_index));
+  GLOC_TRY(tmp.add_all(q_xyz, nq_pts, h->nn_src_per_lane, cand_xyz, cand_npts, n_cand, h->temp_target_index));
   std::vector<JobHost> jh(n_cand);
   for (size_t c = 0; c < n_cand; ++c)
     jh[c] = JobHost{tmp.scans[0], tmp.scans[c + 1], cand_stream_ids ? cand_stream_ids[c] : (uint32_t)c,
@@ -721,8 +739,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   GLOC_TRY(ensure_store(h));
   hipStream_t s = h->stream;
   TempScans tmp(h->store);
-  GLOC_TRY(tmp.add(src_xyz, n_src, h->nn_src_per_lane));
-  GLOC_TRY(tmp.add(tgt_xyz, n_tgt, 0, h->temp_target_index));
+  GLOC_TRY(tmp.add_all(src_xyz, n_src, h->nn_src_per_lane, &tgt_xyz, &n_tgt, 1, h->temp_target_index));
   const int cs = h->nn_src_per_lane;
   const uint32_t ng = (uint32_t)((n_src + 64 * cs - 1) / (64 * cs));
   BatchDims bd{1, (uint32_t)n_src, ng, std::max<uint32_t>(ng, 1), ((size_t)n_src + 127) & ~(size_t)127};

@@ -580,6 +580,8 @@ def main():
 
     # optional: the coarse 2-D match (one grid per place, made on the device from the resident scans)
     cm, place_grid, cm_lock, cur_qgrids = None, None, threading.Lock(), {}
+    NO_GRID = np.uint32(0xFFFFFFFF)
+    coarse_stat = {"pairs": 0, "accepted": 0}
     if args.coarse:
         cm = capi.CoarseMatcher(local_rank)
         place_grid = np.array([cm.add_store_scan(store, int(sid)) for sid in place_scan], np.uint32)
@@ -591,14 +593,19 @@ def main():
         Bq, n = p.shape
         qg = np.repeat(np.array([cur_qgrids[int(q)] for q in q_ids], np.uint32), n)
         dg = place_grid[np.clip(p, 0, None).reshape(-1) % n_store]
+        have = dg != NO_GRID                      # (a leg makes grids only for the places its queries retrieve)
+        dg = np.where(have, dg, dg[have][0] if have.any() else 0).astype(np.uint32)
         with cm_lock:
             xy_yaw, _, ok2 = cm.match_pairs(qg, dg)
         T = np.tile(np.eye(4, dtype=np.float32), (Bq * n, 1, 1))
         c, s_ = np.cos(xy_yaw[:, 2]), np.sin(xy_yaw[:, 2])
-        use = ok2 & (p.reshape(-1) >= 0)
+        use = ok2 & have & (p.reshape(-1) >= 0)
+        coarse_stat["pairs"] += int(np.count_nonzero(have & (p.reshape(-1) >= 0)))
+        coarse_stat["accepted"] += int(np.count_nonzero(use))
         T[use, 0, 0], T[use, 0, 1], T[use, 1, 0], T[use, 1, 1] = c[use], -s_[use], s_[use], c[use]
         T[use, 0, 3], T[use, 1, 3] = xy_yaw[use, 0], xy_yaw[use, 1]
-        return T.reshape(Bq, n, 4, 4)
+        # the reference registers only what its 2-D match accepts (global_localization.cpp:519-526: `if (matched)`)
+        return T.reshape(Bq, n, 4, 4), np.where(use.reshape(Bq, n), p, -1)
 
     def scans_of(places):
         """global place ids [.., n] (-1 = none) -> resident scan ids (every rank holds all scans)."""
@@ -616,7 +623,9 @@ def main():
     fs_state = {"on": False, "jobs": 0, "queries": 0}
 
     def register_multi(q_ids, places):
-        init = coarse_init(q_ids, places) if cm is not None else None
+        init = None
+        if cm is not None:
+            init, places = coarse_init(q_ids, places)
         if fs_state["on"]:
             # the reference's loop as written: stop at the first success (gloc_reg_first_success_multi)
             f = reg.first_success_multi(q_ids, scans_of(places), params=cur["params"], init_T=init)
@@ -769,9 +778,9 @@ def main():
             cand = idx.cpu().numpy()
             t_c = time.time()
             mine = cand[rank * len(ids):(rank + 1) * len(ids)]          # this rank's queries of the step
-            init = coarse_init(ids, mine) if cm is not None else None
+            init, go = (None, mine) if cm is None else coarse_init(ids, mine)
             h = regs[i % 2]
-            h.batch_multi_begin(ids, scans_of(mine), params=cur["params"], init_T=init)
+            h.batch_multi_begin(ids, scans_of(go), params=cur["params"], init_T=init)
             if record:
                 stage["prep_wait"] += t_b - t_a
                 stage["h2d_index"] += t_prep
@@ -1018,6 +1027,42 @@ def main():
             legs["data_far_5_20m"]["what"] = (f"every same-world candidate is one of {len(far_base)} views ray-cast 5-20 m from the query "
                                               "(some turned by up to 25 deg): low overlap, loose culling bounds; identity prior, so "
                                               "registration is not expected to succeed -- the leg prices the 1-NN search on such data")
+
+        def coarse_leg(recall_defined):
+            """The reference's own order (loop_detector.cpp:192-288 then icp_match_3d): the coarse (x, y, yaw, scale) match
+            of every (query, candidate) pair on their BEV grids seeds the 3-D registration.  Grids are made for the
+            places the leg's queries retrieve, from the scans the leg registers."""
+            nonlocal cm, place_grid
+            cm = capi.CoarseMatcher(local_rank)
+            place_grid = np.full(n_store, NO_GRID, np.uint32)
+            for g in leg_places:
+                o = scan_override.get(g)
+                place_grid[g] = cm.add_store_scan(store, int(o[0] if o is not None else place_scan[g]))
+            coarse_stat["pairs"] = coarse_stat["accepted"] = 0
+            # acceptance as in the reference: the 2-D match decides which candidates are registered at all; the 3-D
+            # step keeps its inlier-ratio test but not the rmse gate the identity-prior stream needs against
+            # different-world scans (a partial-overlap pair 5-20 m apart ends at 0.8-2 m rms over ALL its points)
+            cur["params"] = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS, min_inlier_ratio=MIN_INLIER_RATIO,
+                                                    max_rmse=0.0)
+            out, _ = leg_run(L, recall_defined=recall_defined)
+            cur["params"] = params
+            out["coarse_pairs_accepted"] = coarse_stat["accepted"] / max(coarse_stat["pairs"], 1)
+            cm.close()
+            cm, place_grid = None, None
+            cur_qgrids.clear()
+            return out
+
+        if cm is None:
+            if far_base:
+                legs["coarse_seeded_far_5_20m"] = coarse_leg(False)
+                legs["coarse_seeded_far_5_20m"]["what"] = ("the data of data_far_5_20m with the reference's 2-D step in front: gloc_coarse_match_pairs "
+                                                           "on the 500 (query, candidate) pairs of a step, its (x, y, yaw) seeds RANSAC + ICP")
+                drop_override()
+            log("leg: coarse 2-D match seeds the registration")
+            legs["coarse_seeded"] = coarse_leg(True)
+            legs["coarse_seeded"]["what"] = ("the headline's data with the reference's 2-D step in front (bench.py --coarse): per-query grid "
+                                             "construction + 500 pair matches per step + seeded registration")
+        elif far_base:
             drop_override()
         for sid in far_base:
             store.release(sid)

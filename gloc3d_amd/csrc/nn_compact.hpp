@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0;
+  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0;
   unsigned long long n_items = 0;
 
   float px[CS], py[CS], pz[CS], best[CS];
@@ -284,15 +284,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     float lbw = 3.402823466e+38f;
     if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
-    while (mask) {
-      const int b = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
-      const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
-      // the chunk's box straight into scalar registers (round 3: six v_readlane from the lane that tested it before)
-      const f32x4 lo = ix.cbox_lo[c], hi = ix.cbox_hi[c];
-      bool need[CS];
-      unsigned long long nm[CS], nm_any = 0ull;  // the ballots, taken where the comparisons are made
+    // the lane-level test of one chunk box: which of the lane's sources can still use the chunk
+    auto lane_test = [&](const f32x4& lo, const f32x4& hi, bool (&need)[CS], unsigned long long (&nm)[CS]) {
+      unsigned long long nm_any = 0ull;  // the ballots, taken where the comparisons are made
       if constexpr (CS == 2) {  // box_lb() of the lane's two points per packed instruction
         const f32x2 qx = {px[0], px[1]}, qy = {py[0], py[1]}, qz = {pz[0], pz[1]};
         const f32x2 ax = f32x2{lo.x, lo.x} - qx, bx = qx - f32x2{hi.x, hi.x};
@@ -316,6 +310,38 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           nm_any |= nm[s];
         }
       }
+      return nm_any;
+    };
+    // A wave over a sparse stretch of the curve (the far field: 128 points in a box of 60 m x 130 m, each 0.2 m from
+    // its neighbour) lists hundreds of candidates here and fails nearly all of them at the lane level: it is the wave
+    // a launch of few jobs waits for, and a scalar load per candidate (a miss in the scalar cache: ~400 cycles, nothing
+    // to overlap it with) is most of its time.  A batch with many survivors is therefore thinned first, with each box
+    // taken from the lane that holds it (v_readlane: no memory): what remains goes through the loop below.
+    if (__popcll(mask) > 8) {
+      unsigned long long keep = 0ull;
+      while (mask) {
+        const int b = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); };
+        const f32x4 lo = {rl(blo.x), rl(blo.y), rl(blo.z), 0.f}, hi = {rl(bhi.x), rl(bhi.y), rl(bhi.z), 0.f};
+        bool need[CS];
+        unsigned long long nm[CS];
+        if constexpr (TRACE) n_cand++;
+        if (lane_test(lo, hi, need, nm) != 0ull) keep |= 1ull << b;
+      }
+      mask = keep;
+    }
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
+      const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
+      if constexpr (TRACE) n_cand++;
+      // the chunk's box straight into scalar registers (round 3: six v_readlane from the lane that tested it before)
+      const f32x4 lo = ix.cbox_lo[c], hi = ix.cbox_hi[c];
+      bool need[CS];
+      unsigned long long nm[CS];
+      const unsigned long long nm_any = lane_test(lo, hi, need, nm);
       if (nm_any == 0ull) continue;
       n_processed++;
       const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -501,23 +527,50 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           bpos[s] = bch * (SB / 4) + u;
         }
       }
-    } else {  // rare: every chunk that can hold a point at the minimum distance
-      for (uint32_t c = 0; c < ix.nchunks; ++c) {
-        const f32x4 clo = ix.box_lo[c], chi = ix.box_hi[c];
-        if (box_lb(px[s], py[s], pz[s], clo, chi) > best[s]) continue;
-        const uint32_t j0 = c * CH;
-        const uint32_t j1 = (j0 + CH) < ix.n ? (j0 + CH) : ix.n;
-        for (uint32_t j = j0; j < j1; ++j) {
-          const f32x4 t = ix.pts[j];
-          if (dist2(px[s], py[s], pz[s], t.x, t.y, t.z) == best[s]) {
-            const uint32_t o = __float_as_uint(t.w);
-            if (o < bj) {
-              bj = o;
-              bpos[s] = j;
+    }
+  }
+  // rare: a source with two targets at its minimum distance (tie flag).  The wave looks for it together -- lanes <->
+  // chunk boxes, then lanes <-> the targets of every chunk that can hold a point at that distance -- and keeps the
+  // smallest original index.  (Until round 3 the lane searched alone, chunk by chunk: ~400 k cycles, the longest wave
+  // of a launch whenever it happened.)
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    unsigned long long tm = __builtin_amdgcn_ballot_w64(valid[s] && ix.n && L.tie[s * 64 + lane] != 0);
+    while (tm) {
+      const int tl = __ffsll((long long)tm) - 1;
+      tm &= tm - 1;
+      auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), tl)); };
+      const float qx = rl(px[s]), qy = rl(py[s]), qz = rl(pz[s]), qb = rl(best[s]);
+      unsigned long long bk = ~0ull;  // (original index << 32) | sorted position
+      for (uint32_t c0 = 0; c0 < ix.nchunks; c0 += 64) {
+        const uint32_t cl = c0 + lane;
+        bool hit = false;
+        if (cl < ix.nchunks) {
+          const f32x4 clo = ix.box_lo[cl], chi = ix.box_hi[cl];
+          hit = !(box_lb(qx, qy, qz, clo, chi) > qb);
+        }
+        unsigned long long cm = __builtin_amdgcn_ballot_w64(hit);
+        while (cm) {
+          const uint32_t cc = c0 + (uint32_t)(__ffsll((long long)cm) - 1);
+          cm &= cm - 1;
+#pragma unroll
+          for (int u = 0; u < CH / 64; ++u) {
+            const uint32_t j = cc * CH + u * 64 + lane;
+            if (j < ix.n) {
+              const f32x4 t = ix.pts[j];
+              if (dist2(qx, qy, qz, t.x, t.y, t.z) == qb) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(t.w) << 32) | j;
+                bk = k < bk ? k : bk;
+              }
             }
           }
         }
       }
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(bk, o);
+        bk = ok < bk ? ok : bk;
+      }
+      if (lane == tl && bk != ~0ull) bpos[s] = (uint32_t)bk;
     }
   }
 
@@ -597,7 +650,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
     trace[8 * wid + 1] = (uint32_t)t_chunks;  // cycles inside chunk processing
     trace[8 * wid + 2] = n_processed;
-    trace[8 * wid + 3] = n_rounds;
+    trace[8 * wid + 3] = (n_rounds & 0xFFFFu) | (n_cand << 16);  // rounds | candidate chunks (passed the wave-level test)
     trace[8 * wid + 4] = (uint32_t)n_items;
     trace[8 * wid + 5] = (uint32_t)(t_pro - t_start);  // prologue cycles
     trace[8 * wid + 6] = job;

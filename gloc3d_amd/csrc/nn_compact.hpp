@@ -42,6 +42,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the same memory seen as constant: a load through it with a wave-uniform address is a scalar load (s_load), which
 // costs no vector instruction -- the boxes of a scan do not change while a search runs
 #define CPTR(T) const T __attribute__((address_space(4)))*
+#ifdef GLOC_NN_MARKS
+#define NN_MARK(n) asm volatile("; NN_MARK " n)
+#else
+#define NN_MARK(n)
+#endif
 #ifndef GLOC_NN_WPB
 #define GLOC_NN_WPB 1  // waves per work-group; waves never synchronise with each other, and 1 measured 4 % faster than 4
 #endif
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0;
   unsigned long long n_items = 0;
 
+  NN_MARK("load_xform_box");
   float px[CS], py[CS], pz[CS], best[CS];
   bool valid[CS];
   float wlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, whi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     whi[a] = wave_minmax<true>(whi[a]);
   }
 
+  NN_MARK("upper_bounds");
   // ---- upper bounds -> LDS state -----------------------------------------------------------------
   // warm: the previous pass's correspondence (a sorted position: one coherent 16-byte gather);
   // cold: the five curve neighbours of the point's key in the target's order
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   const unsigned long long t_pro = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_chunks = 0;
 
+  NN_MARK("sweep");
   // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
   auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
     const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     float lbw = 3.402823466e+38f;
     if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
+  NN_MARK("batch_tested");
     // the lane-level test of one chunk box: which of the lane's sources can still use the chunk
     auto lane_test = [&](const f32x4& lo, const f32x4& hi, bool (&need)[CS], unsigned long long (&nm)[CS]) {
       unsigned long long nm_any = 0ull;  // the ballots, taken where the comparisons are made
@@ -343,7 +352,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       unsigned long long nm[CS];
       const unsigned long long nm_any = lane_test(lo, hi, need, nm);
       if (nm_any == 0ull) continue;
-      n_processed++;
+      n_processed++;  NN_MARK("candidate_tested");
+
       const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
 #pragma unroll
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  NN_MARK("staged_listed");
       // sub-block tests: a lane takes one listed source and TWO sub-blocks (packed fp32: both boxes per
       // instruction), against the source's CURRENT bound; the passing pairs become the work items
       const f32x2 lox = {bA.x, bA.y}, loy = {bA.z, bA.w}, loz = {bB.x, bB.y};
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         n_items += total;
+  NN_MARK("rounds_begin");
         for (uint32_t r = 0; r < total; r += 64) {
           n_rounds++;
           const uint32_t it = r + lane;
@@ -420,8 +432,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             }
           }
         }
+  NN_MARK("rounds_end");
         total = 0;
       };
+  NN_MARK("teststeps");
       const uint32_t sb0 = (lane & 3) * 2;
       const uint16_t* list_lane = &L.list[lane >> 2];
       // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
@@ -467,6 +481,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           if constexpr (TRACE) sbmask |= (nd0 ? (1u << sb0) : 0u) | (nd1 ? (2u << sb0) : 0u);
         }
       }
+  NN_MARK("teststeps_end");
       if constexpr (TRACE) {
         uint32_t lm = 0;
         for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;
@@ -478,6 +493,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  NN_MARK("refresh");
       bool changed = false;
 #pragma unroll
       for (int s = 0; s < CS; ++s) {
@@ -490,11 +506,13 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     }
     }  // batches of this super-chunk group
   }
+  NN_MARK("sweep_end");
   // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
   // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
   const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
+  NN_MARK("recovery");
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
   uint32_t bpos[CS];
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       }
     }
   }
+  NN_MARK("tie");
   // rare: a source with two targets at its minimum distance (tie flag).  The wave looks for it together -- lanes <->
   // chunk boxes, then lanes <-> the targets of every chunk that can hold a point at that distance -- and keeps the
   // smallest original index.  (Until round 3 the lane searched alone, chunk by chunk: ~400 k cycles, the longest wave
@@ -574,6 +593,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     }
   }
 
+  NN_MARK("outputs");
   // ---- outputs: corr / d2 (sorted slots), pairs, fp64 raw moments of the wave -------------------
   double v[ACC_NV];
 #pragma unroll
@@ -608,6 +628,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       pairs[o * 2 + 1] = q;
     }
   }
+  NN_MARK("reduce");
   if (partials) {
     // Sum over the 64 lanes in the order of the xor butterfly (o = 32, 16, ..., 1), but as a
     // reduce-scatter: at every step a lane keeps half of its values and hands the other half to its
@@ -645,6 +666,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     if ((lane & 3) == 0) out[(lane >> 2) & 15] = x;
     if (lane == 0) out[16] = y;
   }
+  NN_MARK("end");
   if (TRACE && trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
     trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);

@@ -584,7 +584,7 @@ def main():
     coarse_stat = {"pairs": 0, "accepted": 0}
     if args.coarse:
         cm = capi.CoarseMatcher(local_rank)
-        place_grid = np.array([cm.add_store_scan(store, int(sid)) for sid in place_scan], np.uint32)
+        place_grid = np.concatenate([cm.add_store_scans(store, place_scan[i:i + 256]) for i in range(0, len(place_scan), 256)])
         log(f"coarse grids: {n_store} places")
 
     def coarse_init(q_ids, places):
@@ -666,8 +666,8 @@ def main():
         ids = store.add_batch([q_scan_host[j].numpy() for j in range(a, b)])   # one launch sequence for all of them
         if cm is not None:
             with cm_lock:
-                for sid in ids:
-                    cur_qgrids[sid] = cm.add_store_scan(store, sid)
+                for sid, gid_ in zip(ids, cm.add_store_scans(store, ids)):   # the step's query grids in one launch sequence
+                    cur_qgrids[sid] = int(gid_)
         q0 = i * per_step
         n_q = per_step if Bq is None else Bq * (world if args.mode == "throughput" else 1)
         qd = q_desc_host[q0:q0 + n_q].to(dev, non_blocking=True)
@@ -1035,9 +1035,9 @@ def main():
             nonlocal cm, place_grid
             cm = capi.CoarseMatcher(local_rank)
             place_grid = np.full(n_store, NO_GRID, np.uint32)
-            for g in leg_places:
-                o = scan_override.get(g)
-                place_grid[g] = cm.add_store_scan(store, int(o[0] if o is not None else place_scan[g]))
+            sids = [int(scan_override[g][0]) if g in scan_override else int(place_scan[g]) for g in leg_places]
+            for i in range(0, len(sids), 256):
+                place_grid[leg_places[i:i + 256]] = cm.add_store_scans(store, sids[i:i + 256])
             coarse_stat["pairs"] = coarse_stat["accepted"] = 0
             # acceptance as in the reference: the 2-D match decides which candidates are registered at all; the 3-D
             # step keeps its inlier-ratio test but not the rmse gate the identity-prior stream needs against

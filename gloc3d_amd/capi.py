@@ -187,6 +187,7 @@ _PROTOS = [
     ("gloc_coarse_add_image", _i, [_vp, _vp, _u32, _u32, C.c_float, C.c_float, C.c_float, _vp, C.POINTER(_u32)]),
     ("gloc_coarse_add_scan", _i, [_vp, _vp, _sz, _sz, _vp, C.POINTER(_u32)]),
     ("gloc_coarse_add_store_scan", _i, [_vp, _vp, _u32, _vp, C.POINTER(_u32)]),
+    ("gloc_coarse_add_store_scans", _i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     ("gloc_coarse_match_pairs", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("gloc_coarse_release", _i, [_vp, _u32]),
     ("gloc_coarse_cells", _i, [_vp, _u32, C.POINTER(_u32), _vp, _sz]),
@@ -894,6 +895,12 @@ class CoarseMatcher:
         gid = C.c_uint32()
         check(lib().gloc_coarse_add_store_scan(self._h, store._h, int(scan_id), C.byref(self.params), C.byref(gid)))
         return gid.value
+
+    def add_store_scans(self, store, scan_ids):
+        ids = np.ascontiguousarray(scan_ids, np.uint32).reshape(-1)
+        out = np.empty(ids.shape[0], np.uint32)
+        check(lib().gloc_coarse_add_store_scans(self._h, store._h, _np_ptr(ids), ids.shape[0], C.byref(self.params), _np_ptr(out)))
+        return out
 
     def match_pairs(self, q_grids, db_grids):
         qs = np.ascontiguousarray(q_grids, np.uint32).reshape(-1)

@@ -42,6 +42,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the same memory seen as constant: a load through it with a wave-uniform address is a scalar load (s_load), which
 // costs no vector instruction -- the boxes of a scan do not change while a search runs
 #define CPTR(T) const T __attribute__((address_space(4)))*
+#ifndef GLOC_NN_THIN_MIN
+#define GLOC_NN_THIN_MIN 32  // survivors of a batch of 64 chunk boxes before the batch is thinned (nn_compact_kernel)
+#endif
 #ifdef GLOC_NN_MARKS
 #define NN_MARK(n) asm volatile("; NN_MARK " n)
 #else
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     // a launch of few jobs waits for, and a scalar load per candidate (a miss in the scalar cache: ~400 cycles, nothing
     // to overlap it with) is most of its time.  A batch with many survivors is therefore thinned first, with each box
     // taken from the lane that holds it (v_readlane: no memory): what remains goes through the loop below.
-    if (__popcll(mask) > 8) {
+    if (__popcll(mask) > GLOC_NN_THIN_MIN) {
       unsigned long long keep = 0ull;
       while (mask) {
         const int b = __ffsll((long long)mask) - 1;

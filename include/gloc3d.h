@@ -470,6 +470,10 @@ int gloc_coarse_add_scan(gloc_coarse* h, const float* xyz, size_t n, size_t stri
 /* ... or from a scan resident in a scan store on the same device (no host copy of the points needed). */
 int gloc_coarse_add_store_scan(gloc_coarse* h, gloc_scan_store* store, uint32_t scan_id,
                                const gloc_coarse_params* params, uint32_t* grid_id);
+/* n scans of the store in one launch sequence (the query scans of a step, a database being loaded): two
+ * synchronisations for the whole batch instead of three per grid. */
+int gloc_coarse_add_store_scans(gloc_coarse* h, gloc_scan_store* store, const uint32_t* scan_ids, size_t n,
+                                const gloc_coarse_params* params, uint32_t* grid_ids);
 int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id);
 /* Occupied cells of a grid ((v << 16) | u, u / v in [0, 512): cell u spans the pixels
  * (u - 256) cell_px .. + cell_px - 1); out_cells may be NULL to get the count only. */

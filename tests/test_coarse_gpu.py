@@ -58,6 +58,20 @@ def test_grids_and_matches_equal_the_oracle(capi, oracle_mod, scans):
     for j in range(3):
         xy1, r1, ok1 = cm.match(qs[j], [ds[j]])
         assert (bits(xy_p[j]) == bits(xy1[0])).all() and ok_p[j] == ok1[0] and bits(np.float32(ratio_p[j])) == bits(np.float32(r1[0]))
+    # a batch of store scans in one launch sequence (the query scans of a step): the same grids as one at a time,
+    # through release and re-use of the pooled allocations, an empty scan among them
+    others = [store.add(scans[c]) for c in CASES[1:4]] + [store.add(np.full((5, 3), 500.0, np.float32))]   # (out of range: no cell)
+    for rep in range(2):
+        gb = cm.add_store_scans(store, [sid] + others)
+        singles = [cm.add_store_scan(store, i) for i in [sid] + others]
+        for a, b in zip(gb, singles):
+            assert (np.sort(cm.cells(a)) == np.sort(cm.cells(b))).all()
+        assert (np.sort(cm.cells(gb[0])) == og["A"].cells()).all() and len(cm.cells(gb[-1])) == 0
+        xa, ra, oka = cm.match_pairs(gb[:4], [gid["A"]] * 4)
+        xb, rb, okb = cm.match_pairs(singles[:4], [gid["A"]] * 4)
+        assert (bits(xa) == bits(xb)).all() and (bits(ra) == bits(rb)).all() and (oka == okb).all()
+        for g in list(gb) + singles:
+            cm.release(int(g))
     store.close()
     # an empty grid as query and as database
     e = cm.add_image(np.full((8, 8), 255, np.uint8), -0.8, -0.8, 0.2)

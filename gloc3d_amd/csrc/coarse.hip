@@ -65,7 +65,21 @@ int take_block(gloc_coarse* h, size_t words, void** blk) {
     it->second.pop_back();
     return GLOC_OK;
   }
-  GLOC_HIP(hipMalloc(blk, sizeof(uint32_t) * words));
+  hipError_t e = hipMalloc(blk, sizeof(uint32_t) * words);
+  if (e == hipErrorOutOfMemory) {  // drop what the pool holds for other size classes, then try once more
+    (void)hipGetLastError();
+    for (auto& kv : h->free_blocks) {
+      for (void* b : kv.second) (void)hipFree(b);
+      kv.second.clear();
+    }
+    e = hipMalloc(blk, sizeof(uint32_t) * words);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *blk = nullptr;
+    set_err("hipMalloc of %zu bytes for a coarse grid failed: %s", sizeof(uint32_t) * words, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? GLOC_ERR_NOMEM : GLOC_ERR_HIP;
+  }
   return GLOC_OK;
 }
 

@@ -364,10 +364,18 @@ class Comm:
 
     def __init__(self, device, rank, world, exchange):
         uid = (C.c_uint8 * 128)()
+        err = None
         if rank == 0:
-            check(lib().gloc_comm_unique_id(uid))
+            try:
+                check(lib().gloc_comm_unique_id(uid))
+            except Exception as e:      # the other ranks are waiting in exchange(): hand them a null id, then fail
+                err, uid = e, (C.c_uint8 * 128)()
         data = exchange(bytes(uid) if rank == 0 else None)
+        if err is not None:
+            raise err
         assert len(data) == 128
+        if not any(data):
+            raise GlocError(5, "rank 0 could not create the RCCL id")
         uid = (C.c_uint8 * 128).from_buffer_copy(data)
         self._h = C.c_void_p()
         self.rank, self.world = rank, world

@@ -571,6 +571,28 @@ def main():
             capi_knn = None
             rccl_ranks_seen = None
     if capi_knn is not None:
+        # second self-test: the sharded search below the C ABI (local top-k -> grouped RCCL all-gather -> merge)
+        # against the same search over torch.distributed collectives, bit for bit, on a few queries
+        same = False
+        try:
+            from gloc3d_amd import synth as _synth
+            ref_knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank),
+                                         comm_device=comm_dev)
+            probe_q = torch.from_numpy(_synth.queries_near(DB_SEED, np.arange(7, 7 + 8 * 1000, 1000) % max(n_places, 1), DIM)).to(dev)
+            ia, da = capi_knn.search(probe_q, TOP_K)
+            ib, db_ = ref_knn.search(probe_q, TOP_K)
+            torch.cuda.synchronize()
+            same = (bool((ia.cpu().to(torch.int64) == ib.cpu().to(torch.int64)).all())
+                    and bool((da.cpu().view(torch.int32) == db_.cpu().view(torch.int32)).all()))
+        except Exception as e:
+            print(f"[bench] rank {rank}: sharded-search self-test raised {e!r}", file=sys.stderr, flush=True)
+        flag = torch.tensor([1 if same else 0], device=comm_dev or dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            print(f"[bench] rank {rank}: gloc_knn_search_sharded disagrees with the torch.distributed path; using torch.distributed",
+                  file=sys.stderr, flush=True)
+            capi_knn, rccl_ranks_seen = None, None
+    if capi_knn is not None:
         knn = capi_knn
     else:
         knn = sharded.ShardedKnn(rank, world, sharded.hip_local_search(index), sharded.hip_merge(local_rank),

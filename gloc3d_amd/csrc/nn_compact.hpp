@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * 0.99999905f;  // (a bound, not a distance: fused is fine)
   };
   for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
-    float lbs = 3.402823466e+38f;
+    float lbs = __builtin_inff();  // (not FLT_MAX: a wave whose bound is still FLT_MAX -- a non-finite source point -- must not pass lanes past the end)
     if (s0 + lane < ix.nsup) {
       const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
       lbs = box_box_lb(ulo, uhi);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       if (cn < ix.nchunks) { nlo = ix.box_lo[cn]; nhi = ix.box_hi[cn]; }
     }
     if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
-    float lbw = 3.402823466e+38f;
+    float lbw = __builtin_inff();
     if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
   NN_MARK("batch_tested");

@@ -121,6 +121,30 @@ def test_nn_lattice_ties(reg, oracle_mod):
 _LATTICE = {}
 
 
+def test_nn_with_nan_points_in_source_and_target(reg, oracle_mod, scans):
+    """A scan file with a few NaN records (the reference's readers do not filter them): the search must neither
+    fault nor let them disturb the finite points -- every finite source gets the oracle's neighbour among the
+    finite targets, bit for bit, in every search mode; a NaN source gets none."""
+    src = np.ascontiguousarray(scans["B"][::6]).copy()
+    tgt = np.ascontiguousarray(scans["A"][::3]).copy()
+    bad_s, bad_t = np.array([0, 77, 4097, len(src) - 1]), np.array([5, 1000, 1001, len(tgt) - 2])
+    src[bad_s, 1] = np.nan
+    tgt[bad_t] = np.nan
+    idx, d2 = reg.nn(src, tgt)
+    fin_s = np.ones(len(src), bool)
+    fin_s[bad_s] = False
+    fin_t = np.ones(len(tgt), bool)
+    fin_t[bad_t] = False
+    oi, od = oracle_mod.nn3(src[fin_s], tgt[fin_t])
+    back = np.flatnonzero(fin_t)          # positions in tgt of the finite targets
+    assert (idx[fin_s] == back[oi]).all() and (bits(d2[fin_s]) == bits(od)).all()
+    # and through a registration: finite pose, same inlier count in every mode
+    from gloc3d_amd import capi as c
+    r = reg.batch(src, [tgt], params=c.default_reg_params(ransac_iters=64, icp_iters=3))
+    first = _LATTICE.setdefault("nan", (r["inliers"].copy(), r["T"].copy()))
+    assert (first[0] == r["inliers"]).all() and np.isfinite(r["T"]).all() and r["inliers"][0] > 1000
+
+
 def test_nn_full_size_properties(reg, scans):
     A = scans["A"]
     idx, d2 = reg.nn(A, A)                      # idempotence: every point is its own neighbour

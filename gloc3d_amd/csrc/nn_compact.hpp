@@ -612,8 +612,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       q = ix.pts[bpos[s]];  // just loaded above: an L1 hit
       q.w = 0.f;
       const float d2 = best[s];
-      v[16] += (double)d2;
-      if (!(gate2 > 0.f) || d2 < gate2) {
+      if constexpr (!PAIRS) v[16] += (double)d2;
+      if (!PAIRS && (!(gate2 > 0.f) || d2 < gate2)) {  // (the pass that writes the pairs is refitted from them: no moments)
         const double P[3] = {(double)px[s], (double)py[s], (double)pz[s]};
         const double Q[3] = {(double)q.x, (double)q.y, (double)q.z};
         v[0] += 1.0;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     }
   }
   NN_MARK("reduce");
-  if (partials) {
+  if (!PAIRS && partials) {
     // Sum over the 64 lanes in the order of the xor butterfly (o = 32, 16, ..., 1), but as a
     // reduce-scatter: at every step a lane keeps half of its values and hands the other half to its
     // partner, so 16 values cost 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6.  value[l] + value[l ^ o]

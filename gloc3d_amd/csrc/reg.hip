@@ -86,8 +86,8 @@ struct BatchDims {
   size_t ld;
 };
 
-// S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: also
-// write the (moved source, matched target) pairs.  The culled search leaves the wave partials of the
+// S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: write the (moved
+// source, matched target) pairs INSTEAD of the moments (the RANSAC stage refits from the pairs: accum_kernel<1>).  The culled search leaves the wave partials of the
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
 int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, float gate2) {
   ProfScope ps(h->prof, "nn", h->stream);
@@ -118,7 +118,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
   hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, (uint32_t)h->nn_job_group, n_wg, h->states.as<CandState>(),              \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
-                     h->d2.as<float>(), h->pairs.as<f32x4>(), h->partials.as<double>(), bd.n_part, bd.ld, \
+                     h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
                      gate2,                                                                              \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)

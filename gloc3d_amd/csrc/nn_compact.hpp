@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "lane_ops.hpp"
 #include "reg_kernels.hpp"
 
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0;
+  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0, round_hist = 0;
   unsigned long long n_items = 0;
 
   NN_MARK("load_xform_box");
@@ -396,30 +398,52 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         n_items += total;
   NN_MARK("rounds_begin");
-        for (uint32_t r = 0; r < total; r += 64) {
-          n_rounds++;
-          const uint32_t it = r + lane;
+        // One round = up to 64 items.  A full round gives every lane one item: its sub-block's 16 staged targets, the
+        // minimum of each quarter (the key records the winning quarter, so the index recovery re-reads 4 targets; a
+        // minimum attained in two quarters -- two targets at the minimum distance -- takes the tie path).  A chunk queues
+        // 55 items on average, so 37 % of the rounds are the tail of a chunk with at most 32 items (traced: 23 % have at
+        // most 16): those give an item to TWO or FOUR lanes, each walking half / a quarter of the targets, and hand the
+        // quarter minima round inside the quad (four DPP moves); lane 0 of the group commits.  Same values, same key.
+        auto round_body = [&](uint32_t r, auto np_tag) {
+          constexpr int NP = decltype(np_tag)::value;  // lanes per item: 1, 2 or 4
+          const uint32_t it = r + (uint32_t)lane / NP;
+          const int part = lane & (NP - 1);
           const bool act = it < total;
           const uint32_t item = L.queue[act ? it : r];
           const uint32_t slot = item >> 3, bi = item & 7;
           const f32x4 p = L.src[slot];
-          const float* sb = &L.stage[bi * SB_STRIDE];
+          const float* sb = &L.stage[bi * SB_STRIDE] + part * ((SB / 2 / NP) * 8);
           const f32x2 ppx = {p.x, p.x}, ppy = {p.y, p.y}, ppz = {p.z, p.z};
-          // the minimum of each QUARTER of the sub-block: the key records which quarter holds the minimum, so the index
-          // recovery re-reads 4 targets instead of 16 (round 2: halves, 8); a minimum attained in two quarters -- two
-          // targets at the minimum distance -- takes the tie path
-          float mq[4] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
-  #pragma unroll
-          for (int i = 0; i < SB / 2; ++i) {
+          constexpr int QL = 4 / NP;  // quarters this lane walks
+          float ml[QL];
+#pragma unroll
+          for (int j = 0; j < QL; ++j) ml[j] = 3.402823466e+38f;
+#pragma unroll
+          for (int i = 0; i < SB / 2 / NP; ++i) {
             const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
             const f32x2 zz = *reinterpret_cast<const f32x2*>(sb + i * 8 + 4);
             // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
             const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
             const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-            mq[i / (SB / 8)] = fminf(fminf(mq[i / (SB / 8)], d2.x), d2.y);
+            ml[i / (SB / 8)] = fminf(fminf(ml[i / (SB / 8)], d2.x), d2.y);
+          }
+          float mq[4];
+          if constexpr (NP == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mq[j] = ml[j];
+          } else if constexpr (NP == 2) {  // lanes (2k, 2k + 1) hold quarters (0, 1) and (2, 3)
+            mq[0] = dpp_f32<0xA0>(ml[0]);  // quad_perm [0,0,2,2]
+            mq[1] = dpp_f32<0xA0>(ml[1]);
+            mq[2] = dpp_f32<0xF5>(ml[0]);  // quad_perm [1,1,3,3]
+            mq[3] = dpp_f32<0xF5>(ml[1]);
+          } else {  // the quad's lane j holds quarter j
+            mq[0] = dpp_f32<0x00>(ml[0]);
+            mq[1] = dpp_f32<0x55>(ml[0]);
+            mq[2] = dpp_f32<0xAA>(ml[0]);
+            mq[3] = dpp_f32<0xFF>(ml[0]);
           }
           const float m = fminf(fminf(fminf(mq[0], mq[1]), mq[2]), mq[3]);
-          if (act) {
+          if (act && part == 0) {
             const uint32_t blk = c * NSB + bi;
             const bool e0 = mq[0] == m, e1 = mq[1] == m, e2 = mq[2] == m, e3 = mq[3] == m;
             const uint32_t quarter = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
@@ -434,6 +458,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
               if ((od == md && ((uint32_t)old >> 2) != blk) || (md <= od && twice)) L.tie[slot] = 1;
             }
           }
+        };
+        for (uint32_t r = 0; r < total; r += 64) {
+          n_rounds++;
+          const uint32_t left = total - r;
+          if constexpr (TRACE) round_hist += 1u << (8 * (left >= 64 ? 3u : (left - 1) / 16));  // occupancy, in quarters
+          if (left <= 16) round_body(r, std::integral_constant<int, 4>{});
+          else if (left <= 32) round_body(r, std::integral_constant<int, 2>{});
+          else round_body(r, std::integral_constant<int, 1>{});
         }
   NN_MARK("rounds_end");
         total = 0;
@@ -673,7 +705,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   if (TRACE && trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
     trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
-    trace[8 * wid + 1] = (uint32_t)t_chunks;  // cycles inside chunk processing
+    trace[8 * wid + 1] = round_hist;  // rounds with <= 16 / 32 / 48 / 64 items, a byte each (was: cycles inside chunk processing)
+    (void)t_chunks;
     trace[8 * wid + 2] = n_processed;
     trace[8 * wid + 3] = (n_rounds & 0xFFFFu) | (n_cand << 16);  // rounds | candidate chunks (passed the wave-level test)
     trace[8 * wid + 4] = (uint32_t)n_items;

@@ -24,6 +24,8 @@ n = C.c_size_t(); f(reg._h, 1, None, 0, C.byref(n))
 tr = np.zeros((n.value, 8), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
 job = tr[:, 6]
 n_cand = tr[:, 3] >> 16
+rh = tr[:, 1].copy()
+tr[:, 1] = 0
 tr[:, 3] &= 0xFFFF
 ok = tr[:, 0] > 0
 print("ok", r["ok"], "rmse", np.round(r["rmse"], 2))
@@ -69,3 +71,6 @@ for jb in (0, 11, 5):
         dd = np.sort(d[g * 128:(g + 1) * 128])[::-1]
         pts = moved[g * 128:(g + 1) * 128]
         print(f"job {jb} rank {rk} group {g}: box {np.round(pts.max(0) - pts.min(0), 1)} nn dist top {np.round(dd[:6], 2)} median {np.median(dd):.2f}; above 1 m: {(dd > 1).sum()}, above 4x median: {(dd > 4 * np.median(dd)).sum()}")
+
+h = np.stack([(rh >> (8 * q)) & 255 for q in range(4)], 1)[ok]
+print("rounds by occupancy (<=16, <=32, <=48, <=64 items):", h.sum(0), "per wave", np.round(h.mean(0), 2))

@@ -17,8 +17,9 @@ reg = capi.Registrar(store=store)
 prm = capi.default_reg_params(ransac_iters=bench.RANSAC_ITERS, icp_iters=bench.ICP_ITERS, min_inlier_ratio=bench.MIN_INLIER_RATIO,
                               max_rmse=bench.MAX_RMSE)
 cid = np.array([cands], np.uint32)
-for prof in (1, 0):
+for prof, cs in ((1, 2), (0, 2), (0, 1), (0, 4)):
     reg.set_option(capi.REG_OPT_PROFILE, prof)
+    reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, cs)
     ts = []
     for j in range(12):
         if j == 4:
@@ -31,7 +32,7 @@ for prof in (1, 0):
         store.release(sid)
         ts.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
     a = np.median(np.array(ts[4:]), axis=0) * 1e3
-    print(f"profiling {prof}: add {a[0]:.3f} ms, batch_multi {a[1]:.3f} ms, release {a[2]:.3f} ms")
+    print(f"profiling {prof}, sources per lane {cs}: add {a[0]:.3f} ms, batch_multi {a[1]:.3f} ms, release {a[2]:.3f} ms")
     if prof:
         for n in ("nn", "ransac_score", "ransac_hyp", "accum", "solve"):
             ms, cnt = reg.profile(n)

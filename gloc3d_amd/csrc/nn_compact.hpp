@@ -44,6 +44,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the same memory seen as constant: a load through it with a wave-uniform address is a scalar load (s_load), which
 // costs no vector instruction -- the boxes of a scan do not change while a search runs
 #define CPTR(T) const T __attribute__((address_space(4)))*
+// relative window inside which two FUSED distances count as contested (nn_compact_kernel: NEAR); fused and un-fused
+// (dx dx + dy dy) + dz dz differ by < 2e-7
+constexpr float NN_NEAR = 1.0e-6f;
+// a box's lower bound is scaled down by this before it is compared with a point's bound: covers the rounding of the
+// bound itself (a few 2^-24) AND the bound being a fused distance, up to 2e-7 below the un-fused one (0.99999905 until
+// the evaluation was fused)
+constexpr float NN_LB_SCALE = 0.999998f;
 #ifndef GLOC_NN_THIN_MIN
 #define GLOC_NN_THIN_MIN 32  // survivors of a batch of 64 chunk boxes before the batch is thinned (nn_compact_kernel)
 #endif
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
     const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
     const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
-    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * 0.99999905f;  // (a bound, not a distance: fused is fine)
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * NN_LB_SCALE;  // (a bound, not a distance: fused is fine)
   };
   for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
     float lbs = __builtin_inff();  // (not FLT_MAX: a wave whose bound is still FLT_MAX -- a non-finite source point -- must not pass lanes past the end)
@@ -309,8 +316,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
         const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
         const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-        const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * 0.99999905f,
-                          __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
+        const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * NN_LB_SCALE,
+                          __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * NN_LB_SCALE};
         need[0] = lb.x <= best[0];  // (a lane without a point carries the bound -1: nothing passes)
         need[1] = lb.y <= best[1];
         nm[0] = __builtin_amdgcn_ballot_w64(need[0]);
@@ -422,9 +429,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           for (int i = 0; i < SB / 2 / NP; ++i) {
             const f32x4 xy = *reinterpret_cast<const f32x4*>(sb + i * 8);
             const f32x2 zz = *reinterpret_cast<const f32x2*>(sb + i * 8 + 4);
-            // dist2() on two targets at once: d = p - q per axis, (dx*dx + dy*dy) + dz*dz, un-fused
+            // two targets at once, FUSED (one multiply and two fma instead of three multiplies and two adds): within
+            // 2e-7 of dist2()'s un-fused value, which is all the search needs -- see NEAR below; the distance that is
+            // stored is computed by the index recovery, un-fused
             const f32x2 dx = ppx - f32x2{xy.x, xy.y}, dy = ppy - f32x2{xy.z, xy.w}, dz = ppz - zz;
-            const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+            const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
             ml[i / (SB / 8)] = fminf(fminf(ml[i / (SB / 8)], d2.x), d2.y);
           }
           float mq[4];
@@ -445,17 +454,22 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           const float m = fminf(fminf(fminf(mq[0], mq[1]), mq[2]), mq[3]);
           if (act && part == 0) {
             const uint32_t blk = c * NSB + bi;
-            const bool e0 = mq[0] == m, e1 = mq[1] == m, e2 = mq[2] == m, e3 = mq[3] == m;
+            const bool e0 = mq[0] == m, e1 = mq[1] == m, e2 = mq[2] == m;
             const uint32_t quarter = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
-            const bool twice = (e0 && (e1 || e2 || e3)) || (e1 && (e2 || e3)) || (e2 && e3);
+            // NEAR: the evaluated distances are fused, the reference's are not; the two differ by < 2e-7 relative, so
+            // the un-fused minimum lies among the targets whose fused distance is within NN_NEAR = 1e-6 of the fused
+            // minimum.  Normally that is one quarter of one sub-block (the recovery re-reads its 4 targets and takes the
+            // un-fused minimum); when a second quarter or another sub-block comes that close -- an exact tie included --
+            // the source is flagged and the wave looks at every target that close, un-fused (the tie path).
+            const float near_m = m * (1.0f + NN_NEAR);
+            const bool twice = ((mq[0] <= near_m) + (mq[1] <= near_m) + (mq[2] <= near_m) + (mq[3] <= near_m)) > 1;
             const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (blk * 4u + quarter);
             const unsigned long long old = atomicMin(&L.key[slot], key);
-            // a tie: the minimum so far (or one equal to it) also lies in another sub-block, or in two quarters of this
-            // one.  Both need an exact equality first: the rest is looked at only when some lane has one (rare).
-            const uint32_t od = (uint32_t)(old >> 32), md = __float_as_uint(m);
-            const bool maybe = od == md || twice;
+            const float od = __uint_as_float((uint32_t)(old >> 32));
+            const bool close = od <= near_m && m <= od * (1.0f + NN_NEAR);  // (od = FLT_MAX: the product is +inf, the first test fails)
+            const bool maybe = close || twice;
             if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
-              if ((od == md && ((uint32_t)old >> 2) != blk) || (md <= od && twice)) L.tie[slot] = 1;
+              if ((close && ((uint32_t)old >> 2) != blk) || (twice && m <= od * (1.0f + NN_NEAR))) L.tie[slot] = 1;
             }
           }
         };
@@ -501,8 +515,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
           const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
           // sums of squares with scalar fma (2.7 cycles each; the packed forms are 4.4): a bound, not a distance
-          const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * 0.99999905f,
-                            __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * 0.99999905f};
+          const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * NN_LB_SCALE,
+                            __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * NN_LB_SCALE};
           const bool nd0 = act[u] && lb.x <= bst[u], nd1 = act[u] && lb.y <= bst[u];
           const unsigned long long m0 = __builtin_amdgcn_ballot_w64(nd0), m1 = __builtin_amdgcn_ballot_w64(nd1);
           const uint32_t c0n = (uint32_t)__popcll(m0);
@@ -559,6 +573,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const uint32_t bch = (uint32_t)L.key[slot];  // (sub-block << 2) | quarter: 4 targets
     const bool tie = L.tie[slot] != 0;
     uint32_t bj = 0xFFFFFFFFu;
+    float bd = __builtin_inff();
     if (!tie) {
       // (the store pads the scan to whole chunks, so the loads are unconditional)
       GPTR(f32x4) tp = ix.pts + (size_t)bch * (SB / 4);
@@ -575,18 +590,22 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const float dz = pz[s] - t[u].z;
         const float d2 = (sxy.x + sxy.y) + dz * dz;
         const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
-        if (d2 == best[s] && o < bj) {
+        // the un-fused minimum of the quarter (the search compared fused distances), smallest original index first
+        if (d2 < bd || (d2 == bd && o < bj)) {
+          bd = d2;
           bj = o;
           bpos[s] = bch * (SB / 4) + u;
         }
       }
+      if (bpos[s] != 0xFFFFFFFFu) best[s] = bd;
     }
   }
   NN_MARK("tie");
-  // rare: a source with two targets at its minimum distance (tie flag).  The wave looks for it together -- lanes <->
-  // chunk boxes, then lanes <-> the targets of every chunk that can hold a point at that distance -- and keeps the
-  // smallest original index.  (Until round 3 the lane searched alone, chunk by chunk: ~400 k cycles, the longest wave
-  // of a launch whenever it happened.)
+  // rare: a source whose minimum is contested -- two targets at the same distance, or fused distances within NN_NEAR
+  // of each other (tie flag).  The wave looks for it together: lanes <-> chunk boxes, then lanes <-> the targets of every
+  // chunk that can hold a point that close, with dist2() itself; the smallest un-fused distance wins, the smallest
+  // original index among equals.  (Until round 3 the lane searched alone, chunk by chunk: ~400 k cycles, the longest
+  // wave of a launch whenever it happened.)
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
     unsigned long long tm = __builtin_amdgcn_ballot_w64(valid[s] && ix.n && L.tie[s * 64 + lane] != 0);
@@ -594,8 +613,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const int tl = __ffsll((long long)tm) - 1;
       tm &= tm - 1;
       auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), tl)); };
-      const float qx = rl(px[s]), qy = rl(py[s]), qz = rl(pz[s]), qb = rl(best[s]);
-      unsigned long long bk = ~0ull;  // (original index << 32) | sorted position
+      const float qx = rl(px[s]), qy = rl(py[s]), qz = rl(pz[s]);
+      const float qb = rl(best[s]) * (1.0f + 2.0f * NN_NEAR);  // (the fused minimum: everything this close is looked at)
+      unsigned long long bk = ~0ull;  // (bits of the un-fused distance << 32) | original index
+      uint32_t bp = 0xFFFFFFFFu;      // its sorted position
       for (uint32_t c0 = 0; c0 < ix.nchunks; c0 += 64) {
         const uint32_t cl = c0 + lane;
         bool hit = false;
@@ -612,19 +633,29 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             const uint32_t j = cc * CH + u * 64 + lane;
             if (j < ix.n) {
               const f32x4 t = ix.pts[j];
-              if (dist2(qx, qy, qz, t.x, t.y, t.z) == qb) {
-                const unsigned long long k = ((unsigned long long)__float_as_uint(t.w) << 32) | j;
-                bk = k < bk ? k : bk;
+              const float d2 = dist2(qx, qy, qz, t.x, t.y, t.z);
+              const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(t.w);
+              if (d2 == d2 && k < bk) {  // (non-negative floats order like their bits; a NaN target never wins)
+                bk = k;
+                bp = j;
               }
             }
           }
         }
       }
+      unsigned long long wk = bk;
       for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long ok = __shfl_xor(bk, o);
-        bk = ok < bk ? ok : bk;
+        const unsigned long long ok = __shfl_xor(wk, o);
+        wk = ok < wk ? ok : wk;
       }
-      if (lane == tl && bk != ~0ull) bpos[s] = (uint32_t)bk;
+      if (wk != ~0ull) {
+        const int owner = __ffsll((long long)__builtin_amdgcn_ballot_w64(bk == wk)) - 1;  // (original indices are unique)
+        const uint32_t wp = (uint32_t)__builtin_amdgcn_readlane((int)bp, owner);
+        if (lane == tl) {
+          bpos[s] = wp;
+          best[s] = __uint_as_float((uint32_t)(wk >> 32));
+        }
+      }
     }
   }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 
   const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
   const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0, round_hist = 0;
+  uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0, round_hist = 0, n_ties = 0;
   unsigned long long n_items = 0;
 
   NN_MARK("load_xform_box");
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
     unsigned long long tm = __builtin_amdgcn_ballot_w64(valid[s] && ix.n && L.tie[s * 64 + lane] != 0);
+    if constexpr (TRACE) n_ties += (uint32_t)__popcll(tm);
     while (tm) {
       const int tl = __ffsll((long long)tm) - 1;
       tm &= tm - 1;
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     trace[8 * wid + 2] = n_processed;
     trace[8 * wid + 3] = (n_rounds & 0xFFFFu) | (n_cand << 16);  // rounds | candidate chunks (passed the wave-level test)
     trace[8 * wid + 4] = (uint32_t)n_items;
-    trace[8 * wid + 5] = (uint32_t)(t_pro - t_start);  // prologue cycles
+    trace[8 * wid + 5] = ((uint32_t)(t_pro - t_start) & 0xFFFFFFu) | (n_ties << 24);  // prologue cycles | contested sources
     trace[8 * wid + 6] = job;
     trace[8 * wid + 7] = (n_live_sb << 20) | (n_live_pairs << 10) | n_steps;  // per wave: live sub-blocks, live pairs, test steps
     (void)t_sweep;

@@ -24,6 +24,8 @@ n = C.c_size_t(); f(reg._h, 1, None, 0, C.byref(n))
 tr = np.zeros((n.value, 8), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
 job = tr[:, 6]
 n_cand = tr[:, 3] >> 16
+n_ties = tr[:, 5] >> 24
+tr[:, 5] &= 0xFFFFFF
 rh = tr[:, 1].copy()
 tr[:, 1] = 0
 tr[:, 3] &= 0xFFFF
@@ -74,3 +76,4 @@ for jb in (0, 11, 5):
 
 h = np.stack([(rh >> (8 * q)) & 255 for q in range(4)], 1)[ok]
 print("rounds by occupancy (<=16, <=32, <=48, <=64 items):", h.sum(0), "per wave", np.round(h.mean(0), 2))
+print("contested sources (tie path) per wave:", n_ties[ok].mean(), "; waves with any:", (n_ties[ok] > 0).mean(), "; per source:", n_ties[ok].sum() / (128.0 * ok.sum()))

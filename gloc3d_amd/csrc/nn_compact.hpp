@@ -1,8 +1,9 @@
 // nn_compact.hpp -- exact 1-NN with spatial culling and compacted evaluation (K4, default mode).
 //
-// Same result, bit for bit, as the exhaustive nn_kernel (and the oracle): the distance of every
-// evaluated pair is the un-fused fp32 ((dx dx + dy dy) + dz dz), ties go to the smallest ORIGINAL
-// target index.  What changes is which pairs are evaluated:
+// Same result, bit for bit, as the exhaustive nn_kernel (and the oracle): the distance that is returned
+// is the un-fused fp32 ((dx dx + dy dy) + dz dz), ties go to the smallest ORIGINAL target index.  (The
+// search itself compares FUSED distances, 2e-7 away at most, and re-decides contested minima un-fused:
+// NN_NEAR.)  What changes is which pairs are evaluated:
 //   * every scan is Hilbert-sorted once (scan_store.hip) and cut into chunks of 128 points, sub-blocks
 //     of 16 and super-chunks of 64 chunks, each with an axis-aligned bounding box; a scan that serves as a
 //     target (a database place) is re-sorted into kd order, whose chunks and sub-blocks are disjoint cells

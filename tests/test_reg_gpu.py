@@ -121,6 +121,32 @@ def test_nn_lattice_ties(reg, oracle_mod):
 _LATTICE = {}
 
 
+def test_nn_contested_minima_are_decided_unfused(reg, oracle_mod):
+    """The culled search compares FUSED distances (within 2e-7 of the reference's un-fused ones) and re-decides, with
+    dist2() itself, every minimum that another target comes within 1e-6 of.  Adversarial input: every source has a
+    ring of 6 targets whose distances differ by a few ulps -- in different directions, so fused and un-fused
+    arithmetic order them differently -- scattered over different sub-blocks and chunks.  The returned neighbour and
+    distance must be the oracle's (un-fused, smallest index among equals), bit for bit, in every search mode."""
+    rng = np.random.default_rng(11)
+    g = np.arange(-30, 31, dtype=np.float64)
+    src = np.stack(np.meshgrid(g, g, [0.0], indexing="ij"), -1).reshape(-1, 3)            # 3721 sources, 1 m apart (exact)
+    r, e = 0.3125, 2.0 ** -13                                                             # exact offsets at |x| <= 31
+    ring = []
+    for s_ in src:
+        k = rng.permutation(4)                     # squared distances r^2 + (k e)^2: relative gaps 1.5e-7, 6e-7, 1.4e-6
+        ring += [s_ + [r, k[0] * e, 0], s_ + [-r, k[1] * e, 0], s_ + [k[2] * e, r, 0], s_ + [k[3] * e, -r, 0]]
+    far = rng.uniform(-45, 45, (20000, 3)) * np.array([1, 1, 0.05]) + np.array([90.0, 0, 0])    # clutter, elsewhere
+    tgt = np.concatenate([np.array(ring), far]).astype(np.float32)
+    tgt = tgt[rng.permutation(len(tgt))]
+    src = src.astype(np.float32)
+    idx, d2 = reg.nn(src, tgt)
+    oi, od = oracle_mod.nn3(src, tgt)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    # the construction does what it says: the runner-up is within 1e-6 of the minimum for every source
+    dd = np.sort(((src[:300, None, :].astype(np.float64) - tgt[None, :, :].astype(np.float64)) ** 2).sum(-1), axis=1)
+    assert (dd[:, 1] / dd[:, 0] - 1.0 < 1e-6).all() and (dd[:, 1] > dd[:, 0]).all()
+
+
 def test_nn_with_nan_points_in_source_and_target(reg, oracle_mod, scans):
     """A scan file with a few NaN records (the reference's readers do not filter them): the search must neither
     fault nor let them disturb the finite points -- every finite source gets the oracle's neighbour among the

@@ -314,22 +314,34 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                                                            const CandState* __restrict__ states,
                                                            uint32_t* __restrict__ inliers) {
   // staged pairs, two correspondences per entry, structure-of-arrays: (px0 px1 py0 py1)(pz0 pz1 qx0 qx1)(qy0 qy1 qz0 qz1)
-  // so that one packed fp32 instruction moves / measures two correspondences (v_pk_mul / v_pk_add round each
-  // half like the scalar forms: same bits as xform() + dist2())
+  // so that one packed fp32 instruction moves / measures two correspondences.
+  //
+  // The count must be the oracle's: residual = dist2(xform(T, p), q), every product and sum rounded, inlier iff < thr2.
+  // Round 3: the residual is first computed FUSED (three packed fma per coordinate, one multiply and two fma for the
+  // square: 15 packed instructions per two pairs instead of 26), which differs from the un-fused value by a bounded
+  // amount: a coordinate of xform() by at most 9 roundings of partial sums no larger than B = max_row |T| x M + |t|
+  // (M: the largest coordinate of the staged tile, found while it is staged), the difference to q by two more of
+  // B + M, the squares and sums by 3e-7 relative.  A fused residual outside thr2 -+ band is decided as it stands; inside
+  // the band (a few pairs in ten thousand) the un-fused form is computed and decides.  Same counts, bit for bit.
   __shared__ f32x4 sp[3 * (SC_STAGE / 2)];
+  __shared__ float tile_max[4];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int cand = blockIdx.z;
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
   const uint32_t n = jobs[cand].n_src;
   if (blockIdx.y * SC_CHUNK >= n) return;
-  // hyp_per_block = 256: thread <-> hypothesis.  64: four waves share 64 hypotheses, each taking a
-  // quarter of every staged tile (the first phase of the adaptive RANSAC needs few hypotheses).
+  // hyp_per_block = 256: thread <-> hypothesis.  64 / 16: the four waves share that many hypotheses, each thread taking
+  // a quarter / a sixteenth of every staged tile (the first phases of the adaptive RANSAC need few hypotheses).
   const uint32_t sub = threadIdx.x / hyp_per_block, nsub = 256 / hyp_per_block;
   const uint32_t h = h_begin + blockIdx.x * hyp_per_block + threadIdx.x % hyp_per_block;
   const bool hv = h < n_hyp && h < h_begin + (blockIdx.x + 1) * hyp_per_block && valid[(size_t)cand * n_hyp + h];
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = hv ? Rt[((size_t)cand * n_hyp + h) * 12 + i] : 0.f;
+  const float row = fmaxf(fmaxf(fabsf(T[0]) + fabsf(T[1]) + fabsf(T[2]), fabsf(T[3]) + fabsf(T[4]) + fabsf(T[5])),
+                          fabsf(T[6]) + fabsf(T[7]) + fabsf(T[8]));
+  const float tmax = fmaxf(fmaxf(fabsf(T[9]), fabsf(T[10])), fabsf(T[11]));
+  const float thr = sqrtf(thr2);
   const uint32_t i0 = blockIdx.y * SC_CHUNK;
   const uint32_t i1 = (i0 + SC_CHUNK) < n ? (i0 + SC_CHUNK) : n;
   uint32_t cnt = 0;
@@ -341,26 +353,47 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
       pv = pairs[((size_t)cand * ld + i) * 2 + 0];
       qv = pairs[((size_t)cand * ld + i) * 2 + 1];
     }
+    // the tile's largest coordinate (pairs without a target carry NN_FAR: they are decided by magnitude alone)
+    float mx = fmaxf(fmaxf(fabsf(pv.x), fabsf(pv.y)), fabsf(pv.z));
+    if (qv.x < 0.5f * NN_FAR) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fabsf(qv.z)));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     __syncthreads();
+    if ((threadIdx.x & 63) == 0) tile_max[threadIdx.x >> 6] = mx;
     {
       float* d = spf + (threadIdx.x >> 1) * 12 + (threadIdx.x & 1);
       d[0] = pv.x; d[2] = pv.y; d[4] = pv.z; d[6] = qv.x; d[8] = qv.y; d[10] = qv.z;
     }
     __syncthreads();
+    const float M = fmaxf(fmaxf(tile_max[0], tile_max[1]), fmaxf(tile_max[2], tile_max[3]));
+    const float B = row * M + tmax;
+    const float dd = 1.7321f * 8.5e-7f * (B + M);            // |fused - un-fused| of the residual's length, at most
+    const float band = (2.f * thr * dd + dd * dd) + 2.0e-6f * thr2;
+    const float lo2 = thr2 - band, hi2 = thr2 + band;        // (a NaN or infinite bound sends every pair to the exact form)
     const int t_begin = (int)(sub * (SC_STAGE / 2 / nsub)), t_end = (int)((sub + 1) * (SC_STAGE / 2 / nsub));
 #pragma unroll 4
     for (int t = t_begin; t < t_end; ++t) {
       const f32x4 a = sp[3 * t], bq = sp[3 * t + 1], c = sp[3 * t + 2];
       const f32x2 px = {a.x, a.y}, py = {a.z, a.w}, pz = {bq.x, bq.y}, qx = {bq.z, bq.w}, qy = {c.x, c.y}, qz = {c.z, c.w};
-      // xform(): ((r0 x + r1 y) + r2 z) + t, two points at once
-      const f32x2 x = ((f32x2{T[0], T[0]} * px + f32x2{T[1], T[1]} * py) + f32x2{T[2], T[2]} * pz) + f32x2{T[9], T[9]};
-      const f32x2 y = ((f32x2{T[3], T[3]} * px + f32x2{T[4], T[4]} * py) + f32x2{T[5], T[5]} * pz) + f32x2{T[10], T[10]};
-      const f32x2 z = ((f32x2{T[6], T[6]} * px + f32x2{T[7], T[7]} * py) + f32x2{T[8], T[8]} * pz) + f32x2{T[11], T[11]};
-      // dist2(): (dx dx + dy dy) + dz dz
-      const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
-      const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-      cnt += (d2.x < thr2) ? 1u : 0u;
-      cnt += (d2.y < thr2) ? 1u : 0u;
+      auto fma2 = [](f32x2 u, f32x2 v, f32x2 w) { return __builtin_elementwise_fma(u, v, w); };
+      const f32x2 xf = fma2(f32x2{T[0], T[0]}, px, fma2(f32x2{T[1], T[1]}, py, fma2(f32x2{T[2], T[2]}, pz, f32x2{T[9], T[9]})));
+      const f32x2 yf = fma2(f32x2{T[3], T[3]}, px, fma2(f32x2{T[4], T[4]}, py, fma2(f32x2{T[5], T[5]}, pz, f32x2{T[10], T[10]})));
+      const f32x2 zf = fma2(f32x2{T[6], T[6]}, px, fma2(f32x2{T[7], T[7]}, py, fma2(f32x2{T[8], T[8]}, pz, f32x2{T[11], T[11]})));
+      const f32x2 ex = xf - qx, ey = yf - qy, ez = zf - qz;
+      const f32x2 df = fma2(ez, ez, fma2(ey, ey, ex * ex));
+      const bool in0 = df.x < lo2, in1 = df.y < lo2;
+      cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+      // neither clearly inside nor clearly outside (written so that a NaN bound or residual lands here too)
+      const bool un0 = !in0 && !(df.x >= hi2), un1 = !in1 && !(df.y >= hi2);
+      if (__builtin_amdgcn_ballot_w64(un0 || un1) != 0ull) {
+        // xform(): ((r0 x + r1 y) + r2 z) + t, then dist2(): (dx dx + dy dy) + dz dz -- the oracle's roundings
+        const f32x2 x = ((f32x2{T[0], T[0]} * px + f32x2{T[1], T[1]} * py) + f32x2{T[2], T[2]} * pz) + f32x2{T[9], T[9]};
+        const f32x2 y = ((f32x2{T[3], T[3]} * px + f32x2{T[4], T[4]} * py) + f32x2{T[5], T[5]} * pz) + f32x2{T[10], T[10]};
+        const f32x2 z = ((f32x2{T[6], T[6]} * px + f32x2{T[7], T[7]} * py) + f32x2{T[8], T[8]} * pz) + f32x2{T[11], T[11]};
+        const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+        const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+        cnt += (un0 && d2.x < thr2) ? 1u : 0u;
+        cnt += (un1 && d2.y < thr2) ? 1u : 0u;
+      }
     }
   }
   if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);

@@ -55,6 +55,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_test_variant(force=False, verbose=False):
+    """lib/libgloc3d_smallq.so: the same library with the culled 1-NN kernel's work queue cut to 128 entries
+    (-DGLOC_NN_QCAP=128), so that the early evaluation -- the queue flushed in the middle of a chunk's test steps, rare
+    at the shipped 512 -- runs on nearly every chunk.  Test infrastructure (tests/test_reg_variant_gpu.py runs the
+    bit-identity tests through it via GLOC3D_LIB_PATH); only reg.hip is compiled again."""
+    build(force=force, verbose=verbose)
+    out = os.path.join(LIBDIR, "libgloc3d_smallq.so")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    src = os.path.join(CSRC, "reg.hip")
+    obj = os.path.join(LIBDIR, "reg_smallq.o")
+    if force or _stale(obj, [src] + headers):
+        cmd = [HIPCC] + FLAGS + ["-DGLOC_NN_QCAP=128", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    objs = [os.path.join(LIBDIR, s_.replace(".hip", ".o")) for s_ in SOURCES if s_ != "reg.hip"] + [obj]
+    if force or _stale(out, objs):
+        cmd = ["g++", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_cli(force=False, verbose=False):
     """The drop-in command lines (registration/global_localization, global_registration)."""
     build(force=force, verbose=verbose)
@@ -82,4 +106,5 @@ def build_cli(force=False, verbose=False):
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_cli(force="--force" in sys.argv, verbose=True)
+    build_test_variant(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -86,22 +86,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const Seg* __restric
   const Seg sg = segs[blockIdx.x];
   const uint32_t nt = (sg.n + TILE - 1) / TILE;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int d = w; d < RADIX; d += SCAN_THREADS / 64) {
-    uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + d) * max_tiles;
-    uint32_t run = 0;
+  // four digits of the wave at a time: their loads are in flight together (one digit after the other was a chain of
+  // sixteen load -> scan -> store round trips per wave: 13 us of a 27-us pass on one 124 k-element segment)
+  constexpr int DW = SCAN_THREADS / 64, U = 4;
+  static_assert(RADIX % (DW * U) == 0, "digits per wave a multiple of the unroll");
+  for (int d0 = w; d0 < RADIX; d0 += DW * U) {
+    uint32_t run[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) run[u] = 0;
     for (uint32_t t0 = 0; t0 < nt; t0 += 64) {
       const uint32_t t = t0 + lane;
-      const uint32_t v = t < nt ? h[t] : 0u;
-      uint32_t inc = v;  // inclusive prefix over the lanes
+      uint32_t v[U], inc[U];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(inc, o);
-        if (lane >= o) inc += up;
+      for (int u = 0; u < U; ++u) {
+        const uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + (d0 + u * DW)) * max_tiles;
+        v[u] = t < nt ? h[t] : 0u;
       }
-      if (t < nt) h[t] = run + inc - v;
-      run += __shfl(inc, 63);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        inc[u] = v[u];  // inclusive prefix over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = __shfl_up(inc[u], o);
+          if (lane >= o) inc[u] += up;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t* h = hist + ((size_t)blockIdx.x * RADIX + (d0 + u * DW)) * max_tiles;
+        if (t < nt) h[t] = run[u] + inc[u] - v[u];
+        run[u] += __shfl(inc[u], 63);
+      }
     }
-    if (lane == 0) tot[d] = run;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (lane == 0) tot[d0 + u * DW] = run[u];
   }
   __syncthreads();
   // exclusive prefix of the digit totals (RADIX values: every thread sums what lies before its digits)

@@ -111,6 +111,16 @@ __device__ __forceinline__ double exchange_add(double x, double y) {
   return nx + ny;
 }
 
+template <int O>
+__device__ __forceinline__ float exchange_add(float x, float y) {
+  static_assert(O == 32 || O == 16, "whole rows");
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 r;
+  if (O == 32) r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  else r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 // grid = n_wg * n_jobs work-groups of 4 independent waves.  Jobs are taken `job_group` at a time; within
 // a group the job index runs fastest (every job's widest source groups -- `order` lists them widest
 // first -- start together and finish under cover of the bulk), so that at any time the work-groups in
@@ -266,6 +276,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   unsigned long long t_chunks = 0;
 
   NN_MARK("sweep");
+#if defined(GLOC_NN_RET) && GLOC_NN_RET == 1  // dev (timing only, wrong results): stop after the prologue
+  if (wmax > -2.f) return;
+#endif
   // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
   auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
     const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
@@ -273,7 +286,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * NN_LB_SCALE;  // (a bound, not a distance: fused is fine)
   };
+#if defined(GLOC_NN_RET) && GLOC_NN_RET == 6  // dev (timing only): no sweep at all -- prologue + epilogue
+  for (uint32_t s0 = 0; s0 < (wmax > -2.f ? 0u : ix.nsup); s0 += 64) {
+#else
   for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
+#endif
     float lbs = __builtin_inff();  // (not FLT_MAX: a wave whose bound is still FLT_MAX -- a non-finite source point -- must not pass lanes past the end)
     if (s0 + lane < ix.nsup) {
       const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
@@ -363,8 +380,21 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const f32x4 lo = ix.cbox_lo[c], hi = ix.cbox_hi[c];
       bool need[CS];
       unsigned long long nm[CS];
+#ifdef GLOC_NN_DUP_CAND  // dev: the lane-level test of a candidate chunk twice
+      {
+        bool need2[CS];
+        unsigned long long nm2[CS];
+        f32x4 lo2 = lo;
+        asm volatile("" : "+s"(lo2.x));
+        unsigned long long sink_ = lane_test(lo2, hi, need2, nm2);
+        asm volatile("" : : "s"(sink_));
+      }
+#endif
       const unsigned long long nm_any = lane_test(lo, hi, need, nm);
       if (nm_any == 0ull) continue;
+#if defined(GLOC_NN_RET) && GLOC_NN_RET == 2  // dev (timing only): candidates are tested, none is processed
+      if (nm_any != 0x12345ull) continue;
+#endif
       n_processed++;  NN_MARK("candidate_tested");
 
       const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -474,6 +504,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
             }
           }
         };
+#ifdef GLOC_NN_DUP_ROUNDS  // dev: every evaluation round twice (idempotent: the same keys again) -- what the rounds cost
+        for (uint32_t r = 0; r < total; r += 64) {
+          const uint32_t left = total - r;
+          if (left <= 16) round_body(r, std::integral_constant<int, 4>{});
+          else if (left <= 32) round_body(r, std::integral_constant<int, 2>{});
+          else round_body(r, std::integral_constant<int, 1>{});
+        }
+#endif
         for (uint32_t r = 0; r < total; r += 64) {
           n_rounds++;
           const uint32_t left = total - r;
@@ -491,6 +529,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
       // 6 % slower -- a processed chunk lists 58 sources on average, many far fewer
       constexpr int TU = 1;
+#ifdef GLOC_NN_DUP_TESTS  // dev: the chunk's test steps twice (the second pass rewrites the same queue entries)
+      for (int rep_ = 0; rep_ < 2; ++rep_) {
+      if (rep_ == 1) total = 0;
+#endif
       for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
         if (total + 128 * TU > (uint32_t)QCAP) run_rounds();  // rare: this step's items might not fit
         uint32_t si[TU];
@@ -532,6 +574,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         }
       }
   NN_MARK("teststeps_end");
+#ifdef GLOC_NN_DUP_TESTS
+      }
+#endif
       if constexpr (TRACE) {
         uint32_t lm = 0;
         for (int b = 0; b < 8; ++b) lm |= __builtin_amdgcn_ballot_w64((sbmask >> b) & 1u) ? (1u << b) : 0u;
@@ -562,6 +607,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
   const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
+#if defined(GLOC_NN_RET) && GLOC_NN_RET == 3  // dev (timing only): no index recovery, no outputs
+  if (wmax > -2.f) return;
+#endif
   NN_MARK("recovery");
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
@@ -662,10 +710,17 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   }
 
   NN_MARK("outputs");
-  // ---- outputs: corr / d2 (sorted slots), pairs, fp64 raw moments of the wave -------------------
-  double v[ACC_NV];
+  // ---- outputs: corr / d2 (sorted slots), pairs, the wave's moments ------------------------------
+  // Moments about the WAVE'S OWN centre, in fp32 (round 3; fp64 raw moments until then: 11 % of the launch).  The ICP
+  // step needs n, sum p, sum q, sum p q^T to ~1e-9 of their size, which for raw coordinates (100 m, 124 k points) takes
+  // fp64; about the centre c of the wave's box the 128 points are a metre or two out, their products of order one,
+  // and a 24-bit sum of 128 of them is exact to 1e-7 of that -- 1e-11 of the raw sum.  solve_kernel puts the raw
+  // moments back together in fp64 (sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T: exact products of
+  // fp32 values), in the fixed order of the partials.
+  float mv[ACC_NV];
 #pragma unroll
-  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+  for (int k = 0; k < ACC_NV; ++k) mv[k] = 0.f;
+  const float cen[3] = {0.5f * (wlo[0] + whi[0]), 0.5f * (wlo[1] + whi[1]), 0.5f * (wlo[2] + whi[2])};
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
     if (!valid[s]) continue;
@@ -677,17 +732,17 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       q = ix.pts[bpos[s]];  // just loaded above: an L1 hit
       q.w = 0.f;
       const float d2 = best[s];
-      if constexpr (!PAIRS) v[16] += (double)d2;
+      if constexpr (!PAIRS) mv[16] += d2;
       if (!PAIRS && (!(gate2 > 0.f) || d2 < gate2)) {  // (the pass that writes the pairs is refitted from them: no moments)
-        const double P[3] = {(double)px[s], (double)py[s], (double)pz[s]};
-        const double Q[3] = {(double)q.x, (double)q.y, (double)q.z};
-        v[0] += 1.0;
+        const float P[3] = {px[s] - cen[0], py[s] - cen[1], pz[s] - cen[2]};
+        const float Q[3] = {q.x - cen[0], q.y - cen[1], q.z - cen[2]};
+        mv[0] += 1.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          v[1 + a] += P[a];
-          v[4 + a] += Q[a];
+          mv[1 + a] += P[a];
+          mv[4 + a] += Q[a];
 #pragma unroll
-          for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = __builtin_fma(P[a], Q[b], v[7 + 3 * a + b]);  // (fp64 sums: fused is fine)
+          for (int b = 0; b < 3; ++b) mv[7 + 3 * a + b] = __builtin_fmaf(P[a], Q[b], mv[7 + 3 * a + b]);
         }
       }
     }
@@ -700,29 +755,29 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   if (!PAIRS && partials) {
     // Sum over the 64 lanes in the order of the xor butterfly (o = 32, 16, ..., 1), but as a
     // reduce-scatter: at every step a lane keeps half of its values and hands the other half to its
-    // partner, so 16 values cost 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6.  value[l] + value[l ^ o]
-    // is what both forms compute at every node of the tree: the results are bit-identical to the
-    // plain butterfly of rounds 1-2.  Lane l ends with moment (l >> 2) & 15 (all four lanes of a quad).
+    // partner, so 16 values cost 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6.  Lane l ends with moment
+    // (l >> 2) & 15 (all four lanes of a quad).  The partial: 17 floats + the centre (WavePartial).
     static_assert(ACC_NV == 17, "16 scattered moments + the d2 sum");
-    double* out = partials + ((size_t)job * n_part + gi) * ACC_NV;
+    static_assert(sizeof(double) * ACC_NV >= sizeof(float) * WAVE_PARTIAL_FLOATS, "a wave partial fits a partial's slot");
+    float* out = reinterpret_cast<float*>(partials + ((size_t)job * n_part + gi) * ACC_NV);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = exchange_add<32>(v[k], v[k + 8]);
+    for (int k = 0; k < 8; ++k) mv[k] = exchange_add<32>(mv[k], mv[k + 8]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = exchange_add<16>(v[k], v[k + 4]);
+    for (int k = 0; k < 4; ++k) mv[k] = exchange_add<16>(mv[k], mv[k + 4]);
     {
       const bool up = (lane & 8) != 0;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const double keep = up ? v[k + 2] : v[k], send = up ? v[k] : v[k + 2];
-        v[k] = keep + xor_lane<8>(send);
+        const float keep = up ? mv[k + 2] : mv[k], send = up ? mv[k] : mv[k + 2];
+        mv[k] = keep + xor_lane<8>(send);
       }
     }
     {
       const bool up = (lane & 4) != 0;
-      const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-      v[0] = keep + xor_lane<4>(send);
+      const float keep = up ? mv[1] : mv[0], send = up ? mv[0] : mv[1];
+      mv[0] = keep + xor_lane<4>(send);
     }
-    double x = v[0], y = v[16];
+    float x = mv[0], y = mv[16];
     x += xor_lane<2>(x);
     x += xor_lane<1>(x);
     y = exchange_add<32>(y, y);
@@ -732,7 +787,12 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     y += xor_lane<2>(y);
     y += xor_lane<1>(y);
     if ((lane & 3) == 0) out[(lane >> 2) & 15] = x;
-    if (lane == 0) out[16] = y;
+    if (lane == 0) {
+      out[16] = y;
+      out[17] = cen[0];
+      out[18] = cen[1];
+      out[19] = cen[2];
+    }
   }
   NN_MARK("end");
   if (TRACE && trace && lane == 0) {

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "math3.hpp"          // f32x4, xform, dist2, jacobi_eig3, cross3, mulhi_idx, NN_FAR
+#include "lane_ops.hpp"
 #include "scan_index.hpp"     // ScanIndexDev, CH, SB
 #include "synth_kernels.hpp"  // mix64 / rng_key / rng_draw
 
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
 // thread 0 solves Kabsch and composes.
 // MODE 0 (ICP step): T <- dT * T.   MODE 1 (RANSAC refit): T <- T_r * T0, falling back to the
 // un-refitted best hypothesis when fewer than 3 inliers, or to T0 when no hypothesis was valid.
+constexpr int WAVE_PARTIAL_FLOATS = 20;  // the culled search's partial: 17 fp32 moments about the wave's centre + the centre
 constexpr int SOLVE_R = 60;
 constexpr int SOLVE_THREADS = 1024;
 
@@ -593,11 +595,59 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
   const int tid = threadIdx.x;
   const uint32_t cnt = per_group ? jobs[cand].n_groups
                                  : (jobs[cand].n_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
-  if (tid < SOLVE_R * ACC_NV) {
+  if (per_group) {
+    // The culled search's partials: fp32 moments about each wave's own centre (nn_compact.hpp) -> raw moments in
+    // fp64.  sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T, every product of two fp32 values exact in
+    // fp64.  A thread takes whole partials (one each at 124 k points: 969 waves), the work-group sums them in a
+    // fixed order: xor butterfly inside the wave, the 16 waves in order.
+    static_assert(SOLVE_THREADS / 64 <= SOLVE_R, "a row of sub[][] per wave");
+    const float* base = reinterpret_cast<const float*>(partials + (size_t)cand * n_part * ACC_NV);
+    double v[ACC_NV];
+#pragma unroll
+    for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+    for (uint32_t g = (uint32_t)tid; g < cnt; g += SOLVE_THREADS) {
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      const f32x2_* f2 = reinterpret_cast<const f32x2_*>(base + (size_t)g * (2 * ACC_NV));  // (a slot is 136 B: 8-byte aligned)
+      float f[WAVE_PARTIAL_FLOATS];
+#pragma unroll
+      for (int i = 0; i < WAVE_PARTIAL_FLOATS / 2; ++i) {
+        const f32x2_ t = f2[i];
+        f[2 * i] = t.x;
+        f[2 * i + 1] = t.y;
+      }
+      const double n = (double)f[0];
+      const double c[3] = {(double)f[17], (double)f[18], (double)f[19]};
+      v[0] += n;
+      v[16] += (double)f[16];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        v[1 + a] += (double)f[1 + a] + n * c[a];
+        v[4 + a] += (double)f[4 + a] + n * c[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          v[7 + 3 * a + b] += (((double)f[7 + 3 * a + b] + c[a] * (double)f[4 + b]) + (double)f[1 + a] * c[b]) + n * (c[a] * c[b]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ACC_NV; ++k) {  // (DPP / permlane exchanges: the LDS crossbar's __shfl_xor made this 8 us of chain)
+      double x = v[k];
+      x += xor_lane<32>(x);
+      x += xor_lane<16>(x);
+      x += xor_lane<8>(x);
+      x += xor_lane<4>(x);
+      x += xor_lane<2>(x);
+      x += xor_lane<1>(x);
+      v[k] = x;
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < ACC_NV; ++k) sub[tid >> 6][k] = v[k];
+    }
+  } else if (tid < SOLVE_R * ACC_NV) {
     const int k = tid % ACC_NV, r = tid / ACC_NV;
-    const double* pp = partials + (size_t)cand * n_part * ACC_NV + k;
     double acc = 0.0;
     uint32_t b = (uint32_t)r;
+    const double* pp = partials + (size_t)cand * n_part * ACC_NV + k;
     for (; b + 3 * SOLVE_R < cnt; b += 4 * SOLVE_R) {  // four independent loads in flight, summed in order
       const double v0 = pp[(size_t)b * ACC_NV], v1 = pp[(size_t)(b + SOLVE_R) * ACC_NV];
       const double v2 = pp[(size_t)(b + 2 * SOLVE_R) * ACC_NV], v3 = pp[(size_t)(b + 3 * SOLVE_R) * ACC_NV];
@@ -609,7 +659,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
   __syncthreads();
   if (tid < ACC_NV) {
     double acc = 0.0;
-    for (int r = 0; r < SOLVE_R; ++r) acc += sub[r][tid];
+    const int rows = per_group ? SOLVE_THREADS / 64 : SOLVE_R;  // (a row per wave / per stride class)
+    for (int r = 0; r < rows; ++r) acc += sub[r][tid];
     tot[tid] = acc;
   }
   __syncthreads();

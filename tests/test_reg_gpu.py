@@ -291,11 +291,12 @@ def test_culled_equals_exhaustive_full_size(capi, scans):
         r.close()
     ref_b, ref_nn = outs[0]
     for (b, nn), cfg in zip(outs[1:], configs[1:]):
-        # the 1-NN results are identical bit for bit; the fp64 moments are summed per wave (culled) or
-        # per 2048-slot block (exhaustive), so the poses agree to the last bits, not necessarily in them
+        # the 1-NN results are identical bit for bit; the moments are summed per wave about the wave's centre in fp32
+        # and recombined in fp64 (culled) or per 2048-slot block in fp64 (exhaustive): 1e-10 apart per ICP step, which
+        # the discrete correspondences of 14 steps turn into micrometres (both within 1e-4 of the oracle)
         assert (nn[0] == ref_nn[0]).all() and (bits(nn[1]) == bits(ref_nn[1])).all(), cfg
         assert (b["inliers"] == ref_b["inliers"]).all() and (b["ok"] == ref_b["ok"]).all(), cfg
-        assert np.abs(b["T"] - ref_b["T"]).max() < 2e-6, cfg
+        assert np.abs(b["T"] - ref_b["T"]).max() < 1e-5, cfg
         assert np.abs(b["rmse"] - ref_b["rmse"]).max() < 1e-6, cfg
 
 
@@ -448,29 +449,38 @@ def test_target_index_changes_no_bit_of_any_result(capi, scans):
 
 
 def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
-    """After EVERY number of ICP passes the correspondences and distances of the last (warm-started) pass of
-    the culled search equal those of the exhaustive kernel, bit for bit -- full-size scans, a positive and a
-    different-scene candidate, with and without the RANSAC stage in front."""
+    """After EVERY number of ICP passes the correspondences and distances of the last (warm-started) pass of the
+    culled search equal those of the exhaustive kernel AT THE SAME POSE, bit for bit -- full-size scans, a positive
+    and a different-scene candidate, with and without the RANSAC stage in front.  The pose the k-th pass searches at
+    is the result of k - 1 passes (the run is deterministic); the exhaustive kernel searches there from cold.  (Until
+    the culled path's moments became fp32-about-the-wave's-centre both modes were simply run side by side: their
+    poses then agreed to the last bit of the fp32 result, now they are 1e-9 apart after the first step.)"""
     q, cands = scans["B"], [scans["A"], scans["C"]]
     store = capi.ScanStore()
     qid = store.add(q)
     cids = [store.add(c) for c in cands]
 
-    def run(mode, iters, ransac):
+    def run(mode, iters, ransac, init_T=None):
         r = capi.Registrar(store=store)
         r.set_option(capi.REG_OPT_NN_MODE, mode)
-        out = r.batch_ids(qid, cids, params=capi.default_reg_params(ransac_iters=ransac, icp_iters=iters))
+        out = r.batch_ids(qid, cids, init_T=init_T, params=capi.default_reg_params(ransac_iters=ransac, icp_iters=iters))
         corr = [r.debug_corr(j, len(q)) for j in range(2)]
         r.close()
         return out, corr
 
     for iters, ransac in ((1, 0), (2, 0), (3, 0), (6, 0), (12, 0), (4, 300), (9, 300)):
-        ref_out, ref_corr = run(capi.REG_NN_EXHAUSTIVE, iters, ransac)
         out, corr = run(capi.REG_NN_CULLED, iters, ransac)
+        if iters == 1 and ransac == 0:
+            T_prev = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+        else:
+            T_prev = run(capi.REG_NN_CULLED, iters - 1, ransac)[0]["T"]       # where the k-th pass searched
+        ref_out, ref_corr = run(capi.REG_NN_EXHAUSTIVE, 1, 0, init_T=T_prev)
         for j in range(2):
             assert (corr[j][0] == ref_corr[j][0]).all(), (iters, ransac, j)
             assert (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), (iters, ransac, j)
-        assert (out["inliers"] == ref_out["inliers"]).all() and np.abs(out["T"] - ref_out["T"]).max() < 2e-6
+        # and the whole exhaustive run ends where the culled one does, to micrometres
+        full_out, _ = run(capi.REG_NN_EXHAUSTIVE, iters, ransac)
+        assert (out["inliers"] == full_out["inliers"]).all() and np.abs(out["T"] - full_out["T"]).max() < 1e-5
     store.close()
 
 

@@ -427,8 +427,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   NN_MARK("staged_listed");
       // sub-block tests: a lane takes one listed source and TWO sub-blocks (packed fp32: both boxes per
       // instruction), against the source's CURRENT bound; the passing pairs become the work items
-      const f32x2 lox = {bA.x, bA.y}, loy = {bA.z, bA.w}, loz = {bB.x, bB.y};
-      const f32x2 hix = {bB.z, bB.w}, hiy = {bC.x, bC.y}, hiz = {bC.z, bC.w};
+      const f32x2 bcx = {bA.x, bA.y}, bcy = {bA.z, bA.w}, bcz = {bB.x, bB.y};   // centres of the lane's two sub-blocks
+      const f32x2 nhx = {bB.z, bB.w}, nhy = {bC.x, bC.y}, nhz = {bC.z, bC.w};   // -(half extent) / SB2_RANGE
       uint32_t total = 0, sbmask = 0;
       auto run_rounds = [&]() {  // evaluate the queued work items
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -551,16 +551,24 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-          // box_lb() for both boxes at once
+          // the distance to both boxes at once, per axis clamp(|p - c| / 64 - h / 64): one packed subtract, then one
+          // v_fma_f32 with the abs and clamp modifiers per box (2.5 cycles; max(lo - p, p - hi, 0) was two packed
+          // subtracts and a v_max3_f32 of 4.3).  Units of 64 m, saturated at one: a bound stays a bound.
           const f32x2 qx = {p[u].x, p[u].x}, qy = {p[u].y, p[u].y}, qz = {p[u].z, p[u].z};
-          const f32x2 ax = lox - qx, bx = qx - hix, ay = loy - qy, by = qy - hiy, az = loz - qz, bz = qz - hiz;
-          const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
-          const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
-          const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-          // sums of squares with scalar fma (2.7 cycles each; the packed forms are 4.4): a bound, not a distance
-          const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * NN_LB_SCALE,
-                            __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * NN_LB_SCALE};
-          const bool nd0 = act[u] && lb.x <= bst[u], nd1 = act[u] && lb.y <= bst[u];
+          const f32x2 dx = qx - bcx, dy = qy - bcy, dz = qz - bcz;
+          auto axis = [](float d, float nh) {
+            float e;
+            asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(e) : "v"(d), "v"(SB2_INV_RANGE), "v"(nh));
+            return e;
+          };
+          const f32x2 ex = {axis(dx.x, nhx.x), axis(dx.y, nhx.y)};
+          const f32x2 ey = {axis(dy.x, nhy.x), axis(dy.y, nhy.y)};
+          const f32x2 ez = {axis(dz.x, nhz.x), axis(dz.y, nhz.y)};
+          // sums of squares with scalar fma (2.6 cycles each; the packed forms are 4.4): a bound, not a distance
+          const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)),
+                            __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y))};
+          const float bs = bst[u] * (SB2_INV_RANGE * SB2_INV_RANGE / NN_LB_SCALE);  // the source's bound in those units
+          const bool nd0 = act[u] && lb.x <= bs, nd1 = act[u] && lb.y <= bs;
           const unsigned long long m0 = __builtin_amdgcn_ballot_w64(nd0), m1 = __builtin_amdgcn_ballot_w64(nd1);
           const uint32_t c0n = (uint32_t)__popcll(m0);
           if (nd0)

@@ -24,6 +24,10 @@ namespace reg {
 
 constexpr int CH = 128;  // points per chunk (256 / 32 measured: -9 % throughput with three queries in flight)
 constexpr int SB = 16;   // points per sub-block (second-level boxes, argmin bookkeeping)
+// sub-block boxes (sb2) are kept as centre c and -h / SB2_RANGE per axis (h: half extent, rounded up): the distance of a
+// point to the box along an axis, in units of SB2_RANGE metres and saturated at one unit, is then
+// clamp(|p - c| / SB2_RANGE - h / SB2_RANGE) -- one fma with free abs / clamp modifiers.  A power of two: exact.
+constexpr float SB2_RANGE = 64.f, SB2_INV_RANGE = 1.f / 64.f;
 
 // Device-resident header of a scan (first 64 bytes of its allocation): written by the indexing
 // kernels, read by the search kernels, never by the host.

@@ -230,10 +230,28 @@ __global__ void subblock_boxes_kernel(const ScanBuild* __restrict__ sbs) {
       }
     }
   }
+  // Stored as CENTRE and NEGATED HALF EXTENT / 64 (scan_index.hpp: SB2_*), two sub-blocks interleaved for packed fp32:
+  // the search's test is e = clamp(|p - c| / 64 - h / 64) per axis -- a packed subtract and one v_fma_f32 with the abs
+  // and clamp modifiers (2.5 cycles) where max(lo - p, p - hi, 0) took two subtracts and a v_max3_f32 (4.3).  The half
+  // extent is rounded up so that [c - h, c + h] contains the box whatever the rounding of c; an empty sub-block gets a
+  // half extent of -1e30 (every point is "64 m away or more").
+  float c_[2][3], nh[2][3];
+  for (int h = 0; h < 2; ++h)
+    for (int a = 0; a < 3; ++a) {
+      if (mn[h][a] <= mx[h][a]) {
+        const float c = 0.5f * mn[h][a] + 0.5f * mx[h][a];
+        const float he = fmaxf(c - mn[h][a], mx[h][a] - c) * 1.0000005f + 1.0e-30f;  // (each difference within 2^-24 of exact)
+        c_[h][a] = c;
+        nh[h][a] = -he * SB2_INV_RANGE;
+      } else {
+        c_[h][a] = 0.f;
+        nh[h][a] = 1.0e30f;
+      }
+    }
   f32x4* sb2 = sb.sb2;
-  sb2[3 * (size_t)b + 0] = f32x4{mn[0][0], mn[1][0], mn[0][1], mn[1][1]};
-  sb2[3 * (size_t)b + 1] = f32x4{mn[0][2], mn[1][2], mx[0][0], mx[1][0]};
-  sb2[3 * (size_t)b + 2] = f32x4{mx[0][1], mx[1][1], mx[0][2], mx[1][2]};
+  sb2[3 * (size_t)b + 0] = f32x4{c_[0][0], c_[1][0], c_[0][1], c_[1][1]};
+  sb2[3 * (size_t)b + 1] = f32x4{c_[0][2], c_[1][2], nh[0][0], nh[1][0]};
+  sb2[3 * (size_t)b + 2] = f32x4{nh[0][1], nh[1][1], nh[0][2], nh[1][2]};
 }
 
 // Spatial extent of every group of `group` consecutive sorted points: the squared diagonal of its bounding

@@ -32,6 +32,8 @@
 #define B_MAX32(x) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(c));
 #define B_MAX3(x) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
 #define B_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define B_FMACLAMP(x) asm volatile("v_fma_f32 %0, |%0|, %1, %2 clamp" : "+v"(x) : "v"(c), "v"(d));
+#define B_SUBABS(x) asm volatile("v_sub_f32 %0, |%0|, %1 clamp" : "+v"(x) : "v"(c));
 #define B_PKADD(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(c));
 #define B_PKMUL(x) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
 #define B_PKFMA(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
@@ -40,6 +42,7 @@
 KERNEL32(pkadd16, B_PKADD16) KERNEL32(pkmul16, B_PKMUL16) KERNEL32(pkmax16, B_PKMAX16) KERNEL32(pkfma16, B_PKFMA16)
 KERNEL32(cvtpk, B_CVTPK) KERNEL32(cvt16, B_CVT16) KERNEL32(add32, B_ADD32) KERNEL32(sub32, B_SUB32) KERNEL32(mul32, B_MUL32)
 KERNEL32(max32, B_MAX32) KERNEL32(max3, B_MAX3) KERNEL32(fma, B_FMA) KERNEL32(cmp16, B_CMP16) KERNEL32(max3_16, B_MAX3_16)
+KERNEL32(fmaclamp, B_FMACLAMP) KERNEL32(subabs, B_SUBABS)
 KERNEL64(pkadd, B_PKADD) KERNEL64(pkmul, B_PKMUL) KERNEL64(pkfma, B_PKFMA)
 
 template <class K>
@@ -61,6 +64,7 @@ int main() {
   run("v_cvt_pkrtz_f16_f32", k_cvtpk, w); run("v_cvt_f16_f32", k_cvt16, w); run("v_cmp_lt_f16", k_cmp16, w); run("v_max3_f16", k_max3_16, w);
   run("v_add_f32", k_add32, w); run("v_sub_f32", k_sub32, w); run("v_mul_f32", k_mul32, w); run("v_max_f32", k_max32, w);
   run("v_max3_f32", k_max3, w); run("v_fma_f32", k_fma, w);
+  run("v_fma_f32 |a| clamp", k_fmaclamp, w); run("v_sub_f32 |a| clamp", k_subabs, w);
   run("v_pk_add_f32", k_pkadd, w); run("v_pk_mul_f32", k_pkmul, w); run("v_pk_fma_f32", k_pkfma, w);
   return 0;
 }

@@ -391,6 +391,9 @@ def main():
     ap.add_argument("--views-cache", default=None, help="npz cache of the ray-cast base views (profiling runs)")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-job-group", type=int, default=0, help="culled 1-NN tuning: jobs interleaved in the launch order")
+    ap.add_argument("--nn-split-helpers", type=int, default=None, help="culled 1-NN tuning: wave slots per job for planned (split / early) source groups (0: off)")
+    ap.add_argument("--nn-split-thresh", type=int, default=None, help="culled 1-NN tuning: work estimate (cycles) above which a source group is split")
+    ap.add_argument("--nn-sub-jobs", type=int, default=None, help="culled 1-NN tuning: shares of a job's work-groups with their own slot in the launch order")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
                     help="1-NN search of the registration (identical results)")
     ap.add_argument("--ransac-confidence", type=float, default=None,
@@ -506,10 +509,16 @@ def main():
     reg = capi.Registrar(device=local_rank, store=store)
     reg.set_option(capi.REG_OPT_PROFILE, 1)
     reg.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
-    if args.nn_src_per_lane:
-        reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
-    if args.nn_job_group:
-        reg.set_option(capi.REG_OPT_NN_JOB_GROUP, args.nn_job_group)
+    def tune(r):
+        if args.nn_src_per_lane:
+            r.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
+        if args.nn_job_group:
+            r.set_option(capi.REG_OPT_NN_JOB_GROUP, args.nn_job_group)
+        for opt, v in ((capi.REG_OPT_NN_SPLIT_HELPERS, args.nn_split_helpers), (capi.REG_OPT_NN_SPLIT_THRESH, args.nn_split_thresh),
+                       (capi.REG_OPT_NN_SUB_JOBS, args.nn_sub_jobs)):
+            if v is not None:
+                r.set_option(opt, v)
+    tune(reg)
     params = capi.default_reg_params(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS,
                                      min_inlier_ratio=MIN_INLIER_RATIO, max_rmse=MAX_RMSE)
     if args.ransac_confidence is not None:
@@ -525,10 +534,7 @@ def main():
         reg_b = capi.Registrar(device=local_rank, store=store)
         reg_b.set_option(capi.REG_OPT_PROFILE, 1)
         reg_b.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)
-        if args.nn_src_per_lane:
-            reg_b.set_option(capi.REG_OPT_NN_SRC_PER_LANE, args.nn_src_per_lane)
-        if args.nn_job_group:
-            reg_b.set_option(capi.REG_OPT_NN_JOB_GROUP, args.nn_job_group)
+        tune(reg_b)
         reg_stream = torch.cuda.Stream(device=dev)
         reg.set_stream(reg_stream.cuda_stream)
         reg_b.set_stream(reg_stream.cuda_stream)

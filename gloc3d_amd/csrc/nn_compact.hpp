@@ -65,6 +65,7 @@ constexpr float NN_LB_SCALE = 0.999998f;
 #endif
 constexpr int NN_WPB = GLOC_NN_WPB;
 constexpr uint32_t NN_STAT_SLOTS = 4096;  // partial counters of the pairs-evaluated statistic
+constexpr uint32_t NN_TRACE_WORDS = 32;   // dev trace: words per wave
 
 // Wave-wide min / max without the LDS crossbar: four DPP steps inside every row of 16 lanes (quad
 // swaps, then the half-row and row mirrors: after each step the lanes already paired hold one value,
@@ -128,14 +129,14 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // so with job_group a multiple of 8 all work-groups of a job run on ONE XCD and its candidate scan (2 MB of
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
-template <int CS, bool PAIRS, bool TRACE = false>
+template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */>
 __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
-    const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg,
+    const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg /* per slot */, uint32_t subs,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
-    size_t ld, float gate2, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
-    uint32_t* __restrict__ trace /* dev only: [wave][8] = cycles, cycles in chunks, chunks, rounds, items, prologue cycles, job, live sub-blocks | pairs | steps */) {
+    size_t ld, float gate2, NnSplit sp, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
+    uint32_t* __restrict__ trace /* dev only: [wave][NN_TRACE_WORDS]: counts in words 0-7, cycles per region in 8-19 (tools/dev_nn_trace3.py) */) {
   constexpr int S = 64 * CS;        // sources per wave
   constexpr int NSB = CH / SB;      // sub-blocks per chunk
   // The staged chunk is kept as PAIRS of targets, structure-of-arrays: pair i of a sub-block is
@@ -166,16 +167,49 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   __shared__ WaveLds lds_all[NN_WPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   WaveLds& L = lds_all[w];
+  // blockIdx -> (job, work-group of the job).  The launch order walks `job_group` SLOTS at a time, slot fastest, and
+  // work-groups go to the XCDs round-robin (XCD = blockIdx % 8, every XCD working through its own share independently):
+  // with job_group a multiple of 8 a slot stays on one XCD.  A slot holds one job -- or, with `subs` > 1 (few jobs:
+  // fewer than the XCDs can balance), one of `subs` interleaved shares of a job's work-groups.  Which job a slot holds
+  // rotates: within a row of 8 slots by the row number, and from one group of slots to the next -- any regular pattern
+  // in the jobs' costs (bench.py: every fourth candidate is from a different world, 22 % dearer) would otherwise
+  // load the same XCDs in every group: measured, XCDs 1 and 5 of 8 carried every such job and the launch waited for them.
   const uint32_t per = n_wg * job_group, grp = blockIdx.x / per, rem = blockIdx.x % per;
-  const uint32_t left_jobs = n_jobs - grp * job_group, gsize = left_jobs < job_group ? left_jobs : job_group;
-  const uint32_t job = grp * job_group + rem % gsize, wg = rem / gsize;
+  const uint32_t slot = rem % job_group, wgv = rem / job_group;
+  uint32_t vin = slot;  // the virtual job of the slot, within the group
+  if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
+  const uint32_t vjob = grp * job_group + vin;
+  if (vjob >= n_jobs * subs) return;
+  const uint32_t job = vjob / subs, wg = wgv * subs + vjob % subs;
   const Job& J = jobs[job];
-  const uint32_t gi = wg * NN_WPB + w;
   const uint32_t n_src = J.n_src;
-  if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
+  // the first sp.hx waves of a job are helpers (they start with the job's widest groups); then one wave per group
+  uint32_t gi, part = 0, parts = 1, hid = 0, plan_word = 0;
+  bool own_wave = true;  // the group's own wave at its rank (not a helper)
+  {
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(wg * NN_WPB + w);
+    if (SPLIT && wv < sp.hx) {
+      const uint32_t hw = ((CPTR(uint32_t))sp.helper)[(size_t)job * sp.hx + wv];  // (wave-uniform: scalar loads)
+      if (hw == NN_NO_HELPER) return;
+      gi = hw & 0xFFFFFu;
+      part = (hw >> 20) & 15u;
+      parts = hw >> 24;
+      own_wave = false;
+    } else {
+      gi = wv - (SPLIT ? sp.hx : 0u);
+    }
+    if (gi >= J.n_groups) return;  // whole wave idle (no work-group barriers are used below)
+    // (looked at below, once the wave's other loads are in flight: a dependent round trip at the head of every wave
+    // -- 1 us of its 19 -- otherwise)
+    if constexpr (SPLIT) plan_word = ((CPTR(uint32_t))sp.plan)[(size_t)job * n_part + gi];
+  }
+  // candidate chunks of this part: bit b of a batch of 64 chunk boxes (the batch starts at a multiple of 64)
+  const unsigned long long pmask =
+      !SPLIT || parts == 1 ? ~0ull : ((parts == 2 ? 0x5555555555555555ull : (parts == 4 ? 0x1111111111111111ull : 0x0101010101010101ull)) << part);
+  uint32_t w_cand = 0;
   struct IndexView {
     GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb2;
-    GPTR(uint32_t) keys; GPTR(uint32_t) kpos; GPTR(ScanHeader) hdr;
+    GPTR(uint32_t) keys; GPTR(uint32_t) kpos; GPTR(uint32_t) inv; GPTR(ScanHeader) hdr;
     uint32_t n, nchunks;
     GPTR(f32x4) sup_lo; GPTR(f32x4) sup_hi;
     uint32_t nsup;
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   const ScanIndexDev ixg = J.tgt;
   const IndexView ix{(GPTR(f32x4))ixg.pts, (GPTR(f32x4))ixg.box_lo, (GPTR(f32x4))ixg.box_hi,
                      (GPTR(f32x4))ixg.sb2, (GPTR(uint32_t))ixg.keys, (GPTR(uint32_t))ixg.kpos,
-                     (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
+                     (GPTR(uint32_t))ixg.inv, (GPTR(ScanHeader))ixg.hdr, ixg.n, ixg.nchunks,
                      (GPTR(f32x4))ixg.sup_lo, (GPTR(f32x4))ixg.sup_hi, ixg.nsup,
                      (CPTR(f32x4))ixg.box_lo, (CPTR(f32x4))ixg.box_hi};
   GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
@@ -194,20 +228,49 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
 
-  const uint32_t wave_base = ((GPTR(uint32_t))J.src_order)[gi] * S;
+  const uint32_t wave_base = ((CPTR(uint32_t))J.src_order)[gi] * S;
+  if constexpr (SPLIT) {
+    if (own_wave && (plan_word & 0xFFu) != 0u) return;  // the helpers have this group, all its parts
+    hid = plan_word >> 8;
+  }
   const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   uint32_t n_processed = 0, n_rounds = 0, n_live_sb = 0, n_live_pairs = 0, n_steps = 0, n_cand = 0, round_hist = 0, n_ties = 0;
   unsigned long long n_items = 0;
+  // dev trace: cycles per region (s_memtime; a wave's wall clock among the other waves of its SIMD)
+  auto now = [&]() { return TRACE ? __builtin_amdgcn_s_memtime() : 0ull; };
+  unsigned long long a_cand = 0, a_thin = 0, a_stage = 0, a_tests = 0, a_rounds = 0, a_refresh = 0, a_batch = 0;
 
   NN_MARK("load_xform_box");
   float px[CS], py[CS], pz[CS], best[CS];
   bool valid[CS];
   float wlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, whi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  // The wave's loads in as few dependent round trips as there are: the previous pass's correspondences (warm start) go
+  // out with the source points, the gather of the matched targets as soon as they are back -- before the wave's box is
+  // reduced (48 DPP instructions that need no memory).  (Until round 4: points, box, THEN correspondences, THEN the
+  // gather -- two more exposed round trips at the head of every wave, 1 - 2 us of its 19.)
+  uint32_t pj[CS];
+  f32x4 pt[CS];
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    pj[s] = 0xFFFFFFFFu;
+    if (prev_corr && ix.n) pj[s] = prev_corr[(size_t)job * ld + (wave_base + s * 64 + lane < n_src ? wave_base + s * 64 + lane : 0)];
+  }
+  f32x4 psrc[CS];
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
     const uint32_t i = wave_base + s * 64 + lane;
     valid[s] = i < n_src;
-    const f32x4 p = src4[valid[s] ? i : (n_src - 1)];
+    psrc[s] = src4[valid[s] ? i : (n_src - 1)];
+  }
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    pt[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pj[s] < ix.n) pt[s] = ix.pts[pj[s]];
+  }
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    const f32x4 p = psrc[s];
     xform(T, p.x, p.y, p.z, px[s], py[s], pz[s]);
     wlo[0] = fminf(wlo[0], px[s]); whi[0] = fmaxf(whi[0], px[s]);
     wlo[1] = fminf(wlo[1], py[s]); whi[1] = fmaxf(whi[1], py[s]);
@@ -220,6 +283,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     whi[a] = wave_minmax<true>(whi[a]);
   }
 
+  const unsigned long long t_box = now();
   NN_MARK("upper_bounds");
   // ---- upper bounds -> LDS state -----------------------------------------------------------------
   // warm: the previous pass's correspondence (a sorted position: one coherent 16-byte gather);
@@ -228,10 +292,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   for (int s = 0; s < CS; ++s) {
     uint32_t b0 = 0;
     if (ix.n) {
-      uint32_t j = 0xFFFFFFFFu;
-      if (prev_corr) j = prev_corr[(size_t)job * ld + (valid[s] ? wave_base + s * 64 + lane : 0)];
+      const uint32_t j = pj[s];
       if (j < ix.n) {
-        const f32x4 t = ix.pts[j];
+        const f32x4 t = pt[s];
         best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
         b0 = j / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
       } else {
@@ -307,6 +370,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       if (cl < ix.nchunks) { nlo = ix.box_lo[cl]; nhi = ix.box_hi[cl]; }
     }
     while (cur >= 0) {
+    const unsigned long long t_b0 = now();
     const uint32_t c0 = (s0 + cur) * 64;
     const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax;
     const uint32_t cl = c0 + lane;
@@ -322,6 +386,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     float lbw = __builtin_inff();
     if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
+    if constexpr (SPLIT) {
+      mask &= pmask;
+      w_cand += (uint32_t)__popcll(mask);
+    }
+    if constexpr (TRACE) a_batch += now() - t_b0;
   NN_MARK("batch_tested");
     // the lane-level test of one chunk box: which of the lane's sources can still use the chunk
     auto lane_test = [&](const f32x4& lo, const f32x4& hi, bool (&need)[CS], unsigned long long (&nm)[CS]) {
@@ -357,6 +426,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     // to overlap it with) is most of its time.  A batch with many survivors is therefore thinned first, with each box
     // taken from the lane that holds it (v_readlane: no memory): what remains goes through the loop below.
     if (__popcll(mask) > GLOC_NN_THIN_MIN) {
+      const unsigned long long t_t0 = now();
       unsigned long long keep = 0ull;
       while (mask) {
         const int b = __ffsll((long long)mask) - 1;
@@ -369,10 +439,12 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         if (lane_test(lo, hi, need, nm) != 0ull) keep |= 1ull << b;
       }
       mask = keep;
+      if constexpr (TRACE) a_thin += now() - t_t0;
     }
     while (mask) {
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
+      const unsigned long long t_k0 = now();
       if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
       const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
       if constexpr (TRACE) n_cand++;
@@ -391,13 +463,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       }
 #endif
       const unsigned long long nm_any = lane_test(lo, hi, need, nm);
+      if constexpr (TRACE) a_cand += now() - t_k0;
       if (nm_any == 0ull) continue;
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 2  // dev (timing only): candidates are tested, none is processed
       if (nm_any != 0x12345ull) continue;
 #endif
       n_processed++;  NN_MARK("candidate_tested");
 
-      const unsigned long long t_c0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+      const unsigned long long t_c0 = now();
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
 #pragma unroll
       for (int u = 0; u < CH / 64; ++u) {
@@ -424,6 +497,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if constexpr (TRACE) a_stage += now() - t_c0;
   NN_MARK("staged_listed");
       // sub-block tests: a lane takes one listed source and TWO sub-blocks (packed fp32: both boxes per
       // instruction), against the source's CURRENT bound; the passing pairs become the work items
@@ -431,6 +505,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const f32x2 nhx = {bB.z, bB.w}, nhy = {bC.x, bC.y}, nhz = {bC.z, bC.w};   // -(half extent) / SB2_RANGE
       uint32_t total = 0, sbmask = 0;
       auto run_rounds = [&]() {  // evaluate the queued work items
+        const unsigned long long t_r0 = now();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -522,8 +597,10 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         }
   NN_MARK("rounds_end");
         total = 0;
+        if constexpr (TRACE) a_rounds += now() - t_r0;
       };
   NN_MARK("teststeps");
+      const unsigned long long t_s0 = now(), a_r_before = a_rounds;
       const uint32_t sb0 = (lane & 3) * 2;
       const uint16_t* list_lane = &L.list[lane >> 2];
       // one step of 16 listed sources (x 4 sub-block pairs) at a time: four steps unrolled together measured
@@ -592,7 +669,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         n_live_pairs += (uint32_t)__popc((lm | (lm >> 1)) & 0x55u);
         n_steps += (k + 15) / 16;
       }
+      if constexpr (TRACE) a_tests += (now() - t_s0) - (a_rounds - a_r_before);
       run_rounds();
+      const unsigned long long t_f0 = now();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -605,7 +684,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         best[s] = nb;
       }
       if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax = wave_max_best();
-      if constexpr (TRACE) t_chunks += __builtin_amdgcn_s_memtime() - t_c0;
+      if constexpr (TRACE) {
+        const unsigned long long t_e = now();
+        a_refresh += t_e - t_f0;
+        t_chunks += t_e - t_c0;
+      }
     }
     }  // batches of this super-chunk group
   }
@@ -613,6 +696,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
   // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
+  if (SPLIT && lane == 0) {
+    const uint32_t wk = (part == 0 ? NN_W_FIXED : 0u) + NN_W_CAND * w_cand + NN_W_CHUNK * n_processed + NN_W_ITEM * (uint32_t)n_items;
+    uint32_t* wp = sp.work + (size_t)job * n_part + gi;
+    if (parts == 1) *wp = wk; else atomicAdd(wp, wk);  // (the planner left a zero)
+  }
   const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 3  // dev (timing only): no index recovery, no outputs
@@ -657,6 +745,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       if (bpos[s] != 0xFFFFFFFFu) best[s] = bd;
     }
   }
+  const unsigned long long t_rec = now();
   NN_MARK("tie");
   // rare: a source whose minimum is contested -- two targets at the same distance, or fused distances within NN_NEAR
   // of each other (tie flag).  The wave looks for it together: lanes <-> chunk boxes, then lanes <-> the targets of every
@@ -717,6 +806,38 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     }
   }
 
+  // ---- a group searched by several waves: fold the parts, the last one to arrive goes on ---------------------
+  if (SPLIT && parts > 1) {
+    unsigned long long* sk = sp.skey + ((size_t)job * sp.hx + hid) * S;
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      if (bpos[s] == 0xFFFFFFFFu) continue;
+      const uint32_t o = __float_as_uint(ix.pts[bpos[s]].w);  // (just read: an L1 hit)
+      __hip_atomic_fetch_min(sk + s * 64 + lane, ((unsigned long long)__float_as_uint(best[s]) << 32) | o, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The keys before the ticket.  Only atomics carry data between the parts (device-scope read-modify-writes and loads,
+    // performed where all XCDs see them), so it is enough that this wave's have been acknowledged before its ticket is
+    // drawn: no cache write-back or invalidate (__threadfence() here -- a write-back of the XCD's whole L2 per part --
+    // made a launch with 2 500 parts take twice as long).
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt = expcnt = lgkmcnt = 0
+    asm volatile("" ::: "memory");
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add(sp.ticket + (size_t)job * sp.hx + hid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != parts - 1) return;  // (all lanes: no barrier below)
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      const unsigned long long k = __hip_atomic_load(sk + s * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sk[s * 64 + lane] = ~0ull;  // as the next pass expects it
+      if (k != ~0ull) {
+        best[s] = __uint_as_float((uint32_t)(k >> 32));
+        bpos[s] = ix.inv[(uint32_t)k];
+      }
+    }
+    if (lane == 0) sp.ticket[(size_t)job * sp.hx + hid] = 0u;
+  }
+  const unsigned long long t_tie = now();
   NN_MARK("outputs");
   // ---- outputs: corr / d2 (sorted slots), pairs, the wave's moments ------------------------------
   // Moments about the WAVE'S OWN centre, in fp32 (round 3; fp64 raw moments until then: 11 % of the launch).  The ICP
@@ -759,6 +880,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       pairs[o * 2 + 1] = q;
     }
   }
+  const unsigned long long t_out = now();
   NN_MARK("reduce");
   if (!PAIRS && partials) {
     // Sum over the 64 lanes in the order of the xor butterfly (o = 32, 16, ..., 1), but as a
@@ -805,16 +927,37 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   NN_MARK("end");
   if (TRACE && trace && lane == 0) {
     const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
-    trace[8 * wid + 0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
-    trace[8 * wid + 1] = round_hist;  // rounds with <= 16 / 32 / 48 / 64 items, a byte each (was: cycles inside chunk processing)
+    uint32_t* tw = trace + NN_TRACE_WORDS * wid;
+    const unsigned long long t_end = now();
+    tw[0] = (uint32_t)(t_end - t_start);
+    tw[1] = round_hist;  // rounds with <= 16 / 32 / 48 / 64 items, a byte each
+    tw[2] = n_processed;
+    tw[3] = (n_rounds & 0xFFFFu) | (n_cand << 16);  // rounds | candidate chunks (passed the wave-level test)
+    tw[4] = (uint32_t)n_items;
+    tw[5] = ((uint32_t)(t_pro - t_start) & 0xFFFFFFu) | (n_ties << 24);  // prologue cycles | contested sources
+    tw[6] = job;
+    tw[7] = (n_live_sb << 20) | (n_live_pairs << 10) | n_steps;  // per wave: live sub-blocks, live pairs, test steps
+    // cycles per region
+    tw[8] = (uint32_t)(t_box - t_start);   // load + transform + wave box
+    tw[9] = (uint32_t)(t_pro - t_box);     // upper bounds -> LDS state
+    tw[10] = (uint32_t)a_batch;            // batches of 64 chunk boxes (wave level), incl. the wait for their loads
+    tw[11] = (uint32_t)a_thin;             // thinning of many-survivor batches
+    tw[12] = (uint32_t)a_cand;             // lane-level tests of candidate chunks
+    tw[13] = (uint32_t)a_stage;            // staging + listing
+    tw[14] = (uint32_t)a_tests;            // sub-block test steps
+    tw[15] = (uint32_t)a_rounds;           // evaluation rounds
+    tw[16] = (uint32_t)a_refresh;          // bound refresh
+    tw[17] = (uint32_t)(t_sweep - t_pro);  // the whole sweep
+    tw[18] = (uint32_t)(t_rec - t_sweep);  // index recovery
+    tw[19] = (uint32_t)(t_tie - t_rec);    // contested minima
+    tw[20] = (uint32_t)(t_out - t_tie);    // outputs + moments
+    tw[21] = (uint32_t)(t_end - t_out);    // reduction of the moments
+    tw[22] = gi | (part << 20) | (parts << 24);
+    tw[23] = (uint32_t)rt_start;  // the constant 100 MHz clock all XCDs share (the shader clock above is not synchronised)
+    tw[24] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    tw[25] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    tw[26] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave, simd, cu, sh, se
     (void)t_chunks;
-    trace[8 * wid + 2] = n_processed;
-    trace[8 * wid + 3] = (n_rounds & 0xFFFFu) | (n_cand << 16);  // rounds | candidate chunks (passed the wave-level test)
-    trace[8 * wid + 4] = (uint32_t)n_items;
-    trace[8 * wid + 5] = ((uint32_t)(t_pro - t_start) & 0xFFFFFFu) | (n_ties << 24);  // prologue cycles | contested sources
-    trace[8 * wid + 6] = job;
-    trace[8 * wid + 7] = (n_live_sb << 20) | (n_live_pairs << 10) | n_steps;  // per wave: live sub-blocks, live pairs, test steps
-    (void)t_sweep;
   }
 }
 

@@ -50,7 +50,14 @@ struct gloc_reg {
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
   int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
+  int nn_sub_jobs = 0;      // culled kernel: interleaved shares of a job's work-groups that get their own slot (0: by batch size)
   bool temp_target_index = false;  // kd-ordered target index for the temporary scans of the host-buffer calls
+  // heavy source groups over several waves (nn_compact.hpp, NnSplit): helper waves per job (-1: by batch size, 0: off)
+  // and the work estimate (cycles) above which a group is split
+  int nn_split_helpers = -1;
+  uint32_t nn_split_thresh = 60000;
+  DevBuf split_zero, split_ff;     // [work | plan | ticket] and [skey | helper] of the batch
+  NnSplit split{};                 // views into them for the batch being enqueued (hx = 0: off)
   uint64_t nn_launches = 0;
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
@@ -86,6 +93,34 @@ struct BatchDims {
   size_t ld;
 };
 
+// The split plan's buffers for a batch (NnSplit): everything starts as "no group is split"; the first pass of a batch
+// therefore runs one wave per group and leaves the estimates the first plan is made from.
+int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
+  h->split = NnSplit{};
+  if (h->nn_mode == 1 || h->nn_split_helpers == 0 || h->nn_split_thresh == 0) return GLOC_OK;
+  // one query alone (20 jobs) is the case that needs it: its launch is as long as its longest wave; a launch of hundreds
+  // of jobs only loses its tail
+  uint32_t hx = h->nn_split_helpers > 0 ? (uint32_t)h->nn_split_helpers : (bd.n_jobs <= 64 ? 128u : (bd.n_jobs <= 256 ? 64u : 32u));
+  hx = std::min<uint32_t>((hx + NN_WPB - 1) / NN_WPB * NN_WPB, 1u << 12);
+  const size_t S = 64 * (size_t)cs, nj = bd.n_jobs, np = bd.n_part;
+  const size_t zero_words = nj * np * 2 + nj * hx;
+  const size_t ff_bytes = nj * hx * S * 8 + nj * hx * 4;
+  hipStream_t s = h->stream;
+  GLOC_TRY(h->split_zero.ensure(zero_words * 4, s));
+  GLOC_TRY(h->split_ff.ensure(ff_bytes, s));
+  GLOC_HIP(hipMemsetAsync(h->split_zero.p, 0, zero_words * 4, s));
+  GLOC_HIP(hipMemsetAsync(h->split_ff.p, 0xFF, ff_bytes, s));
+  NnSplit& sp = h->split;
+  sp.work = h->split_zero.as<uint32_t>();
+  sp.plan = sp.work + nj * np;
+  sp.ticket = sp.plan + nj * np;
+  sp.skey = h->split_ff.as<unsigned long long>();
+  sp.helper = reinterpret_cast<uint32_t*>(sp.skey + nj * hx * S);
+  sp.hx = hx;
+  sp.thresh = h->nn_split_thresh;
+  return GLOC_OK;
+}
+
 // S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: write the (moved
 // source, matched target) pairs INSTEAD of the moments (the RANSAC stage refits from the pairs: accum_kernel<1>).  The culled search leaves the wave partials of the
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
@@ -102,24 +137,35 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
                          h->pairs.as<f32x4>());
   } else {
     const int cs = h->nn_src_per_lane;
-    const uint32_t n_wg = (bd.max_groups + NN_WPB - 1) / NN_WPB;
-    const unsigned grid = n_wg * bd.n_jobs;
+    const uint32_t n_wg_job = (bd.max_groups + h->split.hx + NN_WPB - 1) / NN_WPB;  // helper waves first, then one per group
+    // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
+    // that the 8 XCDs get equal numbers of slots
+    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 4u : 1u);
+    const uint32_t jg = (uint32_t)h->nn_job_group, n_slots = bd.n_jobs * subs;
+    const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
+    const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
     if (h->trace_on) {
       h->trace_waves = (size_t)grid * NN_WPB;
-      if (h->trace.ensure(h->trace_waves * 32, h->stream)) return GLOC_ERR_NOMEM;
-      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 32, h->stream));
+      if (h->trace.ensure(h->trace_waves * 4 * NN_TRACE_WORDS, h->stream)) return GLOC_ERR_NOMEM;
+      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 4 * NN_TRACE_WORDS, h->stream));
     }
 #define LAUNCH_COMPACT(CS_, P_)                                                                          \
   do {                                                                                                  \
-    if (h->trace_on) LAUNCH_COMPACT_T(CS_, P_, true);                                                   \
-    else LAUNCH_COMPACT_T(CS_, P_, false);                                                              \
+    if (h->trace_on) {                                                                                  \
+      if (h->split.hx) LAUNCH_COMPACT_T(CS_, P_, true, true);                                           \
+      else LAUNCH_COMPACT_T(CS_, P_, true, false);                                                      \
+    } else if (h->split.hx) {                                                                           \
+      LAUNCH_COMPACT_T(CS_, P_, false, true);                                                           \
+    } else {                                                                                            \
+      LAUNCH_COMPACT_T(CS_, P_, false, false);                                                          \
+    }                                                                                                   \
   } while (0)
-#define LAUNCH_COMPACT_T(CS_, P_, T_)                                                                    \
-  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
-                     bd.n_jobs, (uint32_t)h->nn_job_group, n_wg, h->states.as<CandState>(),              \
+#define LAUNCH_COMPACT_T(CS_, P_, T_, S_)                                                                \
+  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_, S_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
+                     bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
-                     gate2,                                                                              \
+                     gate2, h->split,                                                                    \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
     if (grid) {
@@ -195,6 +241,7 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
   GLOC_TRY(h->partials.ensure(sizeof(double) * ACC_NV * (size_t)bd.n_part * n_jobs, s));
   GLOC_HIP(hipMemcpyAsync(h->jobs.p, jd, sizeof(Job) * n_jobs, hipMemcpyHostToDevice, s));
   GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states, sizeof(CandState) * n_jobs, hipMemcpyHostToDevice, s));
+  GLOC_TRY(setup_split(h, bd, cs));
   const bool culled = h->nn_mode != 1;
   const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
   bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
@@ -257,7 +304,7 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
     {
       ProfScope ps(h->prof, "solve", s);
       hipLaunchKernelGGL(solve_kernel<1>, dim3(n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, false, h->jobs.as<Job>(), h->states.as<CandState>());
+                         bd.n_part, false, h->jobs.as<Job>(), h->states.as<CandState>(), h->split);
       GLOC_HIP(hipGetLastError());
     }
   }
@@ -274,7 +321,7 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
     {
       ProfScope ps(h->prof, "solve", s);
       hipLaunchKernelGGL(solve_kernel<0>, dim3(n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, culled, h->jobs.as<Job>(), h->states.as<CandState>());
+                         bd.n_part, culled, h->jobs.as<Job>(), h->states.as<CandState>(), h->split);
       GLOC_HIP(hipGetLastError());
     }
   }
@@ -313,6 +360,12 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   for (size_t c = 0; c < jh.size(); ++c) n_src[c] = jh[c].src.n;
   return collect_jobs(h, (uint32_t)jh.size(), n_src.data(), prm->max_rmse, out_T, out_rmse, out_inliers, out_ok);
 }
+
+// Every entry point that runs jobs on the handle's workspaces (enqueue_jobs / launch_nn: pinned staging, job table,
+// states, corr, partials, the done event) is refused while a batch is between gloc_reg_batch_multi_begin and _end:
+// it would overwrite what that batch's D2H copy and unpacking still read.
+#define GLOC_NOT_PENDING(h) \
+  GLOC_REQUIRE(!(h)->pending.active, GLOC_ERR_STATE, "a batch is in flight on this handle: call gloc_reg_batch_multi_end first")
 
 int check_params(const gloc_reg_params* p) {
   GLOC_REQUIRE(p, GLOC_ERR_INVALID, "params is null");
@@ -440,7 +493,7 @@ int gloc_reg_destroy(gloc_reg* h) {
   if (h->own_store) (void)gloc_scan_store_destroy(h->own_store);
   h->prof.destroy();
   for (DevBuf* b : {&h->jobs, &h->states, &h->corr, &h->d2, &h->pairs, &h->Rt, &h->valid, &h->inliers,
-                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace})
+                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff})
     b->release();
   if (h->done_ev) (void)hipEventDestroy(h->done_ev);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -483,6 +536,21 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   }
   if (option == GLOC_REG_OPT_TEMP_TARGET_INDEX) {
     h->temp_target_index = value != 0;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_SUB_JOBS) {
+    GLOC_REQUIRE(value >= 0 && value <= 64, GLOC_ERR_INVALID, "must be in [0, 64]");
+    h->nn_sub_jobs = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_SPLIT_HELPERS) {
+    GLOC_REQUIRE(value >= -1 && value <= 4096, GLOC_ERR_INVALID, "must be in [-1, 4096]");
+    h->nn_split_helpers = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_SPLIT_THRESH) {
+    GLOC_REQUIRE(value >= 0 && value <= 0x3FFFFFFF, GLOC_ERR_INVALID, "must be in [0, 2^30)");
+    h->nn_split_thresh = (uint32_t)value;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {
@@ -533,6 +601,7 @@ int gloc_reg_batch(gloc_reg* h, const float* q_xyz, size_t nq_pts, const float* 
   GLOC_REQUIRE(n_cand >= 1 && n_cand <= 4096 && cand_xyz && cand_npts, GLOC_ERR_INVALID,
                "n_cand = %zu outside [1,4096] or null candidate arrays", n_cand);
   GLOC_REQUIRE(nq_pts < (1ull << 31), GLOC_ERR_INVALID, "query scan too large");
+  GLOC_NOT_PENDING(h);
   GLOC_TRY(check_params(params));
   GLOC_HIP(hipSetDevice(h->device));
   for (size_t c = 0; c < n_cand; ++c) {
@@ -635,6 +704,7 @@ int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* 
                                  const gloc_reg_params* params, int* out_rank, float* out_T, float* out_rmse,
                                  uint32_t* out_inliers, uint64_t* out_jobs_run) {
   GLOC_REQUIRE(h && q_scan_ids && cand_scan_ids && out_rank && out_T, GLOC_ERR_INVALID, "null argument");
+  GLOC_NOT_PENDING(h);
   GLOC_REQUIRE(n_queries >= 1 && n_cand >= 1 && n_queries * n_cand <= 65536, GLOC_ERR_INVALID,
                "n_queries x n_cand = %zu x %zu outside [1, 65536]", n_queries, n_cand);
   GLOC_REQUIRE(h->store, GLOC_ERR_INVALID, "no scan store: upload scans or attach a store first");
@@ -728,6 +798,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   GLOC_REQUIRE(h && out_idx && out_d2 && (src_xyz || !n_src) && (tgt_xyz || !n_tgt),
                GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n_src < (1ull << 31) && n_tgt < (1ull << 31), GLOC_ERR_INVALID, "scan too large");
+  GLOC_NOT_PENDING(h);
   if (n_src == 0) return GLOC_OK;
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_TRY(ensure_store(h));
@@ -753,6 +824,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
   if (hipMemcpyAsync(h->jobs.p, &jd, sizeof(jd), hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(h->states.p, &st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess)
     return done(GLOC_ERR_HIP);
+  h->split = NnSplit{};  // (one cold pass: there is no estimate to plan from)
   int rc = launch_nn(h, bd, false, false, 0.f);
   if (rc != GLOC_OK) return done(rc);
   hipLaunchKernelGGL(export_corr_kernel, dim3((unsigned)((n_src + 255) / 256), 1), dim3(256), 0, s,
@@ -775,6 +847,7 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
                GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(n >= 3 && n < (1ull << 31) && n_hyp >= 1 && n_hyp <= (1u << 20), GLOC_ERR_INVALID,
                "bad sizes");
+  GLOC_NOT_PENDING(h);
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const size_t ld = (n + 127) & ~(size_t)127;
@@ -840,6 +913,7 @@ int gloc_reg_debug_corr(gloc_reg* h, uint32_t job, uint32_t n_src, uint32_t* out
   GLOC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const size_t ld = h->last_ld;
+  GLOC_NOT_PENDING(h);
   GLOC_REQUIRE(job < h->last_jobs && n_src <= ld, GLOC_ERR_INVALID, "no such job in the last batch");
   GLOC_TRY(h->export_idx.ensure(sizeof(uint32_t) * ld * h->last_jobs, s));
   GLOC_TRY(h->export_d2.ensure(sizeof(float) * ld * h->last_jobs, s));
@@ -863,7 +937,7 @@ int gloc_reg_debug_trace(gloc_reg* h, int enable, uint32_t* out, size_t cap_wave
   if (n_waves) *n_waves = h->trace_waves;
   if (out && h->trace.p) {
     const size_t n = std::min(cap_waves, h->trace_waves);
-    GLOC_HIP(hipMemcpyAsync(out, h->trace.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    GLOC_HIP(hipMemcpyAsync(out, h->trace.p, n * 4 * NN_TRACE_WORDS, hipMemcpyDeviceToHost, h->stream));
     GLOC_HIP(hipStreamSynchronize(h->stream));
   }
   return GLOC_OK;

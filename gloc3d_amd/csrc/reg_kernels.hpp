@@ -39,6 +39,43 @@ struct Job {
   uint32_t pad_;
 };
 
+// ---- heavy source groups over several waves (round 4) -------------------------------------------------------------
+// A launch cannot end before its longest wave does, and a few waves are 3 - 6 x the mean: the far-field groups of every
+// scan (128 points in a box of 60 m x 130 m: ~880 of the 969 chunk boxes pass the wave-level test and are rejected lane
+// by lane) and, against a different scene, groups whose points are metres from everything (40+ processed chunks).  With
+// few jobs per launch (one query alone: 20) that wave IS the launch time.  Such a group is searched by P = 2, 4 or 8
+// waves: part p takes the candidate chunks c with c % P == p (the wave-level ballot is masked), runs the unchanged
+// search over them -- every part starts from the same upper bounds, so no part can cull the true neighbour -- and folds
+// its (un-fused distance, original index) per source into a 64-bit key in global memory (atomicMin: the smallest
+// distance, the smallest original index among equals: the reference's rule); the part that arrives last (a ticket)
+// reads the keys back and writes the outputs and the moments the single wave would have written, bit for bit.
+// Which groups: a work estimate per (job, group) written by every pass (candidate chunks, processed chunks, items, in
+// units of the cycles they cost), turned into next pass's plan by solve_kernel, which runs between two passes anyway.
+// The waves of a planned group ("helpers", all its parts) are the first sp.hx work-groups of a job in the launch order,
+// the heaviest class first: a heavy wave that starts late outlasts the launch however it is split.  The group's own
+// wave, at its rank in the launch order, then exits at once.
+struct NnSplit {
+  uint32_t* work;             // [job][n_part]: the estimate, accumulated by the parts, consumed + zeroed by the planner
+  uint32_t* plan;             // [job][n_part]: (ordinal among the job's split groups << 8) | parts; 0: not planned (its own wave)
+  uint32_t* helper;           // [job][hx]: rank | part << 20 | parts << 24, or NN_NO_HELPER
+  unsigned long long* skey;   // [job][hx][64 * CS]: (bits(d2) << 32) | original index; ~0 between passes
+  uint32_t* ticket;           // [job][hx]: parts arrived; 0 between passes
+  uint32_t hx;                // helper slots per job (0: no plan, the pointers are null)
+  uint32_t thresh;            // estimate above which a group is split (cycles)
+};
+constexpr uint32_t NN_NO_HELPER = 0xFFFFFFFFu;
+constexpr uint32_t NN_MAX_PARTS = 8;
+// the estimate, from the trace's regression of wave cycles on its counts (tools/dev_nn_trace3.py)
+constexpr uint32_t NN_W_FIXED = 21000, NN_W_CAND = 300, NN_W_CHUNK = 2800, NN_W_ITEM = 37;
+
+// waves for an estimate: 0 = the group's own wave at its rank in the launch order; 1 = one wave, but started with the
+// helpers (a wave of half the threshold that starts late still outlasts the launch); 2, 4, 8 = that many parts
+__host__ __device__ __forceinline__ uint32_t nn_parts_for(uint32_t w, uint32_t thresh) {
+  if (thresh == 0 || 2ull * w <= thresh) return 0;
+  if (w <= thresh) return 1;
+  return w > 4 * (unsigned long long)thresh ? 8u : (w > 2 * (unsigned long long)thresh ? 4u : 2u);
+}
+
 // per-candidate state, device resident
 struct CandState {
   double Td[12];      // current absolute transform (R row-major 9, t 3), fp64
@@ -588,11 +625,77 @@ template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,
                                                               uint32_t n_part, bool per_group,
                                                               const Job* __restrict__ jobs,
-                                                              CandState* __restrict__ states) {
+                                                              CandState* __restrict__ states, NnSplit sp) {
   __shared__ double sub[SOLVE_R][ACC_NV];
   __shared__ double tot[ACC_NV];
+  __shared__ uint32_t plan_helpers, plan_groups;
   const int cand = blockIdx.x;
   const int tid = threadIdx.x;
+  // The plan of the NEXT culled 1-NN pass (nn_compact.hpp, NnSplit): groups whose work estimate of the pass just done
+  // exceeds the threshold get 2, 4 or 8 waves, in launch order (widest group first) until the helper slots run out.
+  // A plan moves time, never a result.  The estimates are consumed.
+  if (sp.hx) {
+    if (tid == 0) {
+      plan_helpers = 0;
+      plan_groups = 0;
+    }
+    __syncthreads();
+    const uint32_t ng = jobs[cand].n_groups;
+    uint32_t* work = sp.work + (size_t)cand * n_part;
+    uint32_t* plan = sp.plan + (size_t)cand * n_part;
+    uint32_t* helper = sp.helper + (size_t)cand * sp.hx;
+    // helper slots in RANK order (the widest groups first) by a prefix sum over the work-group: deterministic, and no
+    // atomics (a compare-and-swap per split group made this kernel 3 x slower at 128 slots)
+    __shared__ uint32_t wave_sum[2][SOLVE_THREADS / 64];
+    for (uint32_t e = (uint32_t)tid; e < sp.hx; e += SOLVE_THREADS) helper[e] = NN_NO_HELPER;  // (slots nobody takes below)
+    __syncthreads();
+    // two rounds over the groups: first those that get 4 or 8 waves, then those that get 2 or 1 (one wave, started early)
+    for (int round = 0; round < 2; ++round) {
+      for (uint32_t g0 = 0; g0 < ng; g0 += SOLVE_THREADS) {
+        const uint32_t g = g0 + (uint32_t)tid;
+        uint32_t parts = 0;
+        if (g < ng) parts = nn_parts_for(work[g], sp.thresh);
+        if ((round == 0) != (parts >= 4)) parts = 0;
+        uint32_t need = parts, isg = parts > 1 ? 1u : 0u;  // inclusive scans of both over the wave
+        uint32_t sn = need, sg = isg;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t a = __shfl_up(sn, o), b = __shfl_up(sg, o);
+          if ((tid & 63) >= o) {
+            sn += a;
+            sg += b;
+          }
+        }
+        if ((tid & 63) == 63) {
+          wave_sum[0][tid >> 6] = sn;
+          wave_sum[1][tid >> 6] = sg;
+        }
+        __syncthreads();
+        uint32_t base_n = plan_helpers, base_g = plan_groups, tot_n = 0, tot_g = 0;
+        for (int w_ = 0; w_ < SOLVE_THREADS / 64; ++w_) {
+          if (w_ < (tid >> 6)) {
+            base_n += wave_sum[0][w_];
+            base_g += wave_sum[1][w_];
+          }
+          tot_n += wave_sum[0][w_];
+          tot_g += wave_sum[1][w_];
+        }
+        const uint32_t first = base_n + sn - need, hid = base_g + sg - isg;
+        if (parts >= 1 && first + need <= sp.hx) {  // (groups past the last slot keep their one wave at their own rank)
+          for (uint32_t p = 0; p < parts; ++p) helper[first + p] = g | (p << 20) | (parts << 24);
+          plan[g] = (hid << 8) | parts;
+        } else if (g < ng && round == 0) {
+          plan[g] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          plan_helpers += tot_n;
+          plan_groups += tot_g;
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t g = (uint32_t)tid; g < ng; g += SOLVE_THREADS) work[g] = 0;  // consumed
+  }
   const uint32_t cnt = per_group ? jobs[cand].n_groups
                                  : (jobs[cand].n_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
   if (per_group) {

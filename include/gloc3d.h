@@ -210,9 +210,19 @@ enum {
   GLOC_REG_OPT_NN_JOB_GROUP = 4,    /* culled search tuning: jobs whose work-groups are interleaved in the
                                        launch order (their scans share the caches); default 24.  A multiple of
                                        8 keeps each job's work-groups on one XCD, i.e. its scans in one L2 */
-  GLOC_REG_OPT_TEMP_TARGET_INDEX = 5 /* 1: the host-buffer calls (gloc_reg_batch, gloc_reg_nn) build the kd-ordered
+  GLOC_REG_OPT_TEMP_TARGET_INDEX = 5, /* 1: the host-buffer calls (gloc_reg_batch, gloc_reg_nn) build the kd-ordered
                                        target index for their temporary candidate scans too (default 0: a
                                        millisecond per candidate is more than one registration saves) */
+  GLOC_REG_OPT_NN_SPLIT_HELPERS = 6, /* culled search: wave slots per job at the head of the launch order for the
+                                       heaviest source groups (a group whose work estimate of the previous pass
+                                       exceeds the threshold is searched by 2, 4 or 8 waves, one above half of it
+                                       starts early; identical results).  -1 (default): by batch size (128 up to
+                                       64 jobs, 64 up to 256, else 32); 0: off */
+  GLOC_REG_OPT_NN_SPLIT_THRESH = 7,  /* the estimate (cycles of one wave) above which a group is split; default
+                                       60000; 0: off */
+  GLOC_REG_OPT_NN_SUB_JOBS = 8       /* culled search tuning: interleaved shares of a job's work-groups that take a
+                                       slot of the launch order each (a slot stays on one XCD); 0 (default): 4 for
+                                       batches under 48 jobs, which 8 XCDs cannot balance job by job, else 1 */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

@@ -484,6 +484,68 @@ def test_every_pass_bit_identical_to_the_brute_force_kernel(capi, scans):
     store.close()
 
 
+def test_split_groups_change_no_bit_of_any_result(capi, scans):
+    """Heavy source groups searched by several waves (nn_compact.hpp, NnSplit: parts take disjoint candidate chunks,
+    fold (distance, original index) keys in global memory, the last part to arrive writes the outputs): whatever the
+    plan -- off, the default, every group split as far as the helper slots go, too few slots, other sources per
+    lane -- poses, rmse, inlier counts and the last pass's correspondences and distances keep their bits.  Full-size
+    scans, a positive and a different-scene candidate (the one whose groups are heavy), RANSAC + ICP."""
+    store = capi.ScanStore()
+    qid = store.add(scans["B"])
+    cids = [store.add(scans["A"]), store.add(scans["C"])]
+    store.build_target_index_batch(cids[:1])                    # one kd-ordered target, one in curve order
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=5)
+
+    def run(helpers, thresh, cs=2):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_SRC_PER_LANE, cs)
+        r.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, helpers)
+        r.set_option(capi.REG_OPT_NN_SPLIT_THRESH, thresh)
+        out = r.batch_ids(qid, cids, params=prm)
+        corr = [r.debug_corr(j, len(scans["B"])) for j in range(2)]
+        r.close()
+        return out, corr
+
+    ref, ref_corr = run(0, 60000)
+    for helpers, thresh, cs in ((-1, 60000, 2), (700, 1, 2), (37, 20000, 2), (8, 1, 2), (300, 1, 1), (300, 1000, 4)):
+        out, corr = run(helpers, thresh, cs)
+        what = (helpers, thresh, cs)
+        if cs == 2:
+            assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all(), what
+        else:                                                   # (other wave partials: the moments' rounding differs)
+            assert np.abs(out["T"] - ref["T"]).max() < 1e-5, what
+        assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all(), what
+        if cs == 2:
+            for j in range(2):
+                assert (corr[j][0] == ref_corr[j][0]).all() and (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), what
+    store.close()
+
+
+def test_split_groups_decide_ties_by_the_original_index(capi, oracle_mod):
+    """Equidistant targets in DIFFERENT parts of a split group: the parts' keys are (distance, original index), so the
+    smallest original index wins as in the single wave.  Lattice targets in shuffled order, sources on cell centres /
+    edges / faces; max_corr_dist rejects every pair, so the pose stays the identity and the second (warm, split) pass
+    searches the same configuration the oracle does."""
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(12), indexing="ij"), -1).reshape(-1, 3)
+    tgt = (g[rng.permutation(len(g))] * 0.5).astype(np.float32)
+    cells = g[(g[:, 0] < 23) & (g[:, 1] < 23) & (g[:, 2] < 11)].astype(np.float32) * 0.5
+    src = np.concatenate([cells + np.float32(0.25), cells + np.array([0.25, 0, 0], np.float32),
+                          cells + np.array([0.25, 0.25, 0], np.float32)]).astype(np.float32)   # (no exact hits: no pair survives the gate)
+    src = src[rng.permutation(len(src))]
+    oi, od = oracle_mod.nn3(src, tgt)
+    for kd in (0, 1):
+        r = capi.Registrar()
+        r.set_option(capi.REG_OPT_TEMP_TARGET_INDEX, kd)
+        r.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, 600)
+        r.set_option(capi.REG_OPT_NN_SPLIT_THRESH, 1)
+        out = r.batch(src, [tgt], params=capi.default_reg_params(ransac_iters=0, icp_iters=3, max_corr_dist=1e-4))
+        assert (out["T"][0] == np.eye(4, dtype=np.float32)).all()
+        idx, d2 = r.debug_corr(0, len(src))
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+        r.close()
+
+
 def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
     """gloc_reg_batch_multi_begin / _end: two handles with their own workspaces on ONE stream, batch i + 1 enqueued
     before batch i's results are waited for (bench.py's registration pipeline).  Every batch equals the blocking call
@@ -513,6 +575,21 @@ def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
             assert (g["inliers"] == w["inliers"]).all() and (g["ok"] == w["ok"]).all()
     with pytest.raises(capi.GlocError):
         h[0].batch_multi_end()
+    # every other entry point that runs jobs on the handle's workspaces is refused (GLOC_ERR_STATE) while a batch
+    # is in flight, and the batch in flight is not disturbed by the refused calls
+    h[0].batch_multi_begin(qs[0:2], cand, params=prm)
+    small = np.ascontiguousarray(A[::50])
+    for call in (lambda: h[0].batch(small, [small], params=prm),
+                 lambda: h[0].batch_ids(qs[0], cs, params=prm),
+                 lambda: h[0].first_success_multi(qs[0:2], cand, params=prm),
+                 lambda: h[0].nn(small, small),
+                 lambda: h[0].ransac_hypotheses(small, small, np.arange(len(small), dtype=np.uint32), 1, 0, 16, 0.6),
+                 lambda: h[0].debug_corr(0, 16)):
+        with pytest.raises(capi.GlocError) as ei:
+            call()
+        assert ei.value.code == 5, ei.value                # GLOC_ERR_STATE
+    g = h[0].batch_multi_end()
+    assert (bits(g["T"]) == bits(want[0]["T"])).all() and (g["inliers"] == want[0]["inliers"]).all()
     for r in h + [ref]:
         r.close()
     store.close()

@@ -1,79 +1,87 @@
-"""dev: per-wave trace of the culled 1-NN kernel on a bench-like query (15 positives + 5 negatives), last ICP pass."""
+"""dev: per-wave trace of the culled 1-NN kernel on bench-like queries (15 positives + 5 negatives each), last ICP pass.
+usage: dev_nn_trace3.py [icp_iters [n_queries]]   (n_queries x 20 jobs in ONE launch; 8 fill the chip like the bench)"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from gloc3d_amd import capi, synth
+W = 32  # NN_TRACE_WORDS
+icp = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 wa, wb = synth.make_world(1001), synth.make_world(2002)
 store = capi.ScanStore()
 base_a = [store.add(np.ascontiguousarray(synth.lidar_scan(wa, bench.pool_pose(s), seed=3000 + s)[:, :3])) for s in range(0, 20)]
 base_b = [store.add(np.ascontiguousarray(synth.lidar_scan(wb, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), seed=5000 + s)[:, :3])) for s in range(2)]
-qv = np.ascontiguousarray(synth.lidar_scan(wa, bench.pool_pose(10) @ synth.se3(1.5, (0.3, -0.2, 0.02)), seed=9000)[:, :3])
-qid = store.add(qv)
+qvs, qids = [], []
+for q in range(nq):
+    qv = np.ascontiguousarray(synth.lidar_scan(wa, bench.pool_pose(10) @ synth.se3(1.5 + 0.4 * q, (0.3 - 0.1 * q, -0.2 + 0.05 * q, 0.02)), seed=9000 + q)[:, :3])
+    qvs.append(qv)
+    qids.append(store.add(qv))
+qv, qid = qvs[0], qids[0]
 cands = []
 for c in range(20):
     g = c
     cands.append(store.add_variant(base_b[(g // 4) % 2] if g % 4 == 1 else base_a[g], bench.place_perturbation(g), 0.01, 7000 + g))
+store.build_target_index_batch(cands)
 reg = capi.Registrar(store=store)
 L = capi.lib(); f = L.gloc_reg_debug_trace; f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 f(reg._h, 1, None, 0, None)
-prm = capi.default_reg_params(ransac_iters=3000, icp_iters=int(sys.argv[1]) if len(sys.argv) > 1 else 20, max_rmse=1.0)
-r = reg.batch_ids(qid, cands, params=prm)
+prm = capi.default_reg_params(ransac_iters=3000, icp_iters=icp, max_rmse=1.0)
+r = reg.batch_multi(qids, [cands] * nq, params=prm)
 n = C.c_size_t(); f(reg._h, 1, None, 0, C.byref(n))
-tr = np.zeros((n.value, 8), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+tr = np.zeros((n.value, W), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
 job = tr[:, 6]
 n_cand = tr[:, 3] >> 16
 n_ties = tr[:, 5] >> 24
 tr[:, 5] &= 0xFFFFFF
 rh = tr[:, 1].copy()
-tr[:, 1] = 0
 tr[:, 3] &= 0xFFFF
 ok = tr[:, 0] > 0
-print("ok", r["ok"], "rmse", np.round(r["rmse"], 2))
-for name, sel in (("positives", np.isin(job, [c for c in range(20) if c % 4 != 1])), ("negatives", np.isin(job, [c for c in range(20) if c % 4 == 1]))):
+print("queries", nq, "jobs", nq * 20, "waves traced", int(ok.sum()))
+print("ok", np.asarray(r["ok"]).reshape(nq, 20)[0], "rmse", np.round(np.asarray(r["rmse"]).reshape(nq, 20)[0], 2))
+cand_of = job % 20
+names = ["load+xform+box", "upper bounds", "chunk-box batches", "thinning", "candidate lane tests", "staging+listing",
+         "sub-block tests", "evaluation rounds", "bound refresh", "(whole sweep)", "index recovery", "contested minima",
+         "outputs+moments", "moment reduction"]
+for name, sel in (("all", np.ones_like(ok)), ("positives", cand_of % 4 != 1), ("negatives", cand_of % 4 == 1)):
     t = tr[ok & sel].astype(np.float64)
-    tot, chunks, pro = t[:, 0], t[:, 1], t[:, 5]
+    tot = t[:, 0]
     w7 = tr[ok & sel][:, 7]
     live_sb, live_pairs, steps = (w7 >> 20), (w7 >> 10) & 1023, w7 & 1023
-    epi = 0 * tot
-    sweep = tot - chunks - pro
     print(f"{name}: waves {len(t)} cycles mean {tot.mean():.0f} p50 {np.percentile(tot,50):.0f} p99 {np.percentile(tot,99):.0f} max {tot.max():.0f}")
-    print(f"   prologue {pro.mean():.0f}  sweep outside chunks {sweep.mean():.0f}  chunk processing {chunks.mean():.0f} ({t[:,2].mean():.1f} chunks, {t[:,3].mean():.1f} rounds, {t[:,4].mean():.0f} items)  ")
-    print(f"   per processed chunk: listed {t[:,5].sum() and 0 or 0} live sub-blocks {live_sb.sum()/t[:,2].sum():.2f} of 8, live pairs {live_pairs.sum()/t[:,2].sum():.2f} of 4, test steps {steps.sum()/t[:,2].sum():.2f}, items {t[:,4].sum()/t[:,2].sum():.1f}")
+    print(f"   per wave: candidate chunks {n_cand[ok & sel].mean():.1f}, processed {t[:,2].mean():.2f}, rounds {t[:,3].mean():.2f}, items {t[:,4].mean():.0f}, test steps {steps.mean():.2f}")
+    print(f"   per processed chunk: live sub-blocks {live_sb.sum()/t[:,2].sum():.2f} of 8, live pairs {live_pairs.sum()/t[:,2].sum():.2f} of 4, test steps {steps.sum()/t[:,2].sum():.2f}, items {t[:,4].sum()/t[:,2].sum():.1f}")
+    reg_c = t[:, 8:22]
+    inner = reg_c[:, 2:9].sum(1)
+    other_sweep = reg_c[:, 9] - inner
+    acc = reg_c[:, [0, 1]].sum(1) + reg_c[:, 9] + reg_c[:, 10:14].sum(1)
+    print("   share of the wave's cycles per region (sum over waves / sum of totals):")
+    for k, nm in enumerate(names):
+        if k == 9:
+            print(f"      {'sweep: loops, ballots, waits':28s} {100 * other_sweep.sum() / tot.sum():5.1f} %   mean {other_sweep.mean():7.0f} cycles")
+            continue
+        print(f"      {nm:28s} {100 * reg_c[:, k].sum() / tot.sum():5.1f} %   mean {reg_c[:, k].mean():7.0f} cycles")
+    print(f"      {'(stamps cover)':28s} {100 * acc.sum() / tot.sum():5.1f} %")
 # cycles against the wave's rank in the launch order (rank 0 = the widest source group of its job): what a split of
 # the widest groups would have to cover
-n_wg = int(tr.shape[0] // 20)
-per = n_wg * 20     # one job group (20 < job_group): blockIdx = wg * 20 + job
-wid = np.arange(tr.shape[0])
-rank = (wid % per) // 20
 t_all = tr[:, 0].astype(np.float64)
+rank_of_group = {}
 print(f"all waves: mean {t_all[ok].mean():.0f} p50 {np.percentile(t_all[ok], 50):.0f} p90 {np.percentile(t_all[ok], 90):.0f} "
       f"p99 {np.percentile(t_all[ok], 99):.0f} p99.9 {np.percentile(t_all[ok], 99.9):.0f} max {t_all[ok].max():.0f}")
-for lo, hi in ((0, 4), (4, 16), (16, 64), (64, 256), (256, n_wg)):
-    s = ok & (rank >= lo) & (rank < hi)
-    if s.any():
-        print(f"   ranks [{lo}, {hi}): waves {s.sum()} cycles mean {t_all[s].mean():.0f} max {t_all[s].max():.0f} chunks {tr[s, 2].mean():.1f} items {tr[s, 4].mean():.0f}")
 top = np.argsort(-t_all)[:12]
-print("slowest waves (cycles, rank, job, candidate chunks, chunks, items):", [(int(t_all[i]), int(rank[i]), int(job[i]), int(n_cand[i]), int(tr[i, 2]), int(tr[i, 4])) for i in top])
-print("candidate chunks per wave: mean", n_cand[ok].mean(), "p99", np.percentile(n_cand[ok], 99), "max", n_cand[ok].max(), "; share of waves with > 32:", (n_cand[ok] > 32).mean())
+print("slowest waves (cycles, group, job, candidate chunks, chunks, items):", [(int(t_all[i]), int(tr[i, 22]), int(job[i]), int(n_cand[i]), int(tr[i, 2]), int(tr[i, 4])) for i in top])
+# how concentrated the work is: share of all cycles in the heaviest x % of the waves; what a split by work would cover
+srt = np.sort(t_all[ok])[::-1]
+cs = np.cumsum(srt) / srt.sum()
+for pc in (0.1, 0.5, 1, 2, 5, 10):
+    k = max(1, int(len(srt) * pc / 100))
+    print(f"   heaviest {pc:4.1f} % of waves ({k}): {100 * cs[k - 1]:.1f} % of the cycles, lightest of them {srt[k - 1]:.0f} cycles")
+# items as a predictor of cycles (what a split decision could use): items of the same (job, group) -> cycles
 A = np.stack([n_cand[ok], tr[ok, 2], tr[ok, 4], np.ones(ok.sum())], 1).astype(np.float64)
 coef = np.linalg.lstsq(A, t_all[ok], rcond=None)[0]
 print("cycles ~ %.0f x candidate + %.0f x processed + %.1f x item + %.0f" % tuple(coef))
-# what the widest groups look like: nearest-neighbour distances (at the final pose) of their 128 sources
-from scipy.spatial import cKDTree
-ix = store.debug_index(qid)
-qs = qv[ix["perm"]]
-for jb in (0, 11, 5):
-    T = r["T"][jb].astype(np.float64)
-    moved = qs @ T[:3, :3].T + T[:3, 3]
-    d, _ = cKDTree(store.download(cands[jb])).query(moved)
-    for rk in (0, 5, 100, 506):
-        g = int(ix["order2"][rk])
-        dd = np.sort(d[g * 128:(g + 1) * 128])[::-1]
-        pts = moved[g * 128:(g + 1) * 128]
-        print(f"job {jb} rank {rk} group {g}: box {np.round(pts.max(0) - pts.min(0), 1)} nn dist top {np.round(dd[:6], 2)} median {np.median(dd):.2f}; above 1 m: {(dd > 1).sum()}, above 4x median: {(dd > 4 * np.median(dd)).sum()}")
-
+print("candidate chunks per wave: mean", n_cand[ok].mean(), "p99", np.percentile(n_cand[ok], 99), "max", n_cand[ok].max(), "; share of waves with > 32:", (n_cand[ok] > 32).mean())
 h = np.stack([(rh >> (8 * q)) & 255 for q in range(4)], 1)[ok]
 print("rounds by occupancy (<=16, <=32, <=48, <=64 items):", h.sum(0), "per wave", np.round(h.mean(0), 2))
 print("contested sources (tie path) per wave:", n_ties[ok].mean(), "; waves with any:", (n_ties[ok] > 0).mean(), "; per source:", n_ties[ok].sum() / (128.0 * ok.sum()))

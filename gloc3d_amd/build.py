@@ -56,17 +56,18 @@ def build(force=False, verbose=False):
 
 
 def build_test_variant(force=False, verbose=False):
-    """lib/libgloc3d_smallq.so: the same library with the culled 1-NN kernel's work queue cut to 128 entries
-    (-DGLOC_NN_QCAP=128), so that the early evaluation -- the queue flushed in the middle of a chunk's test steps, rare
-    at the shipped 512 -- runs on nearly every chunk.  Test infrastructure (tests/test_reg_variant_gpu.py runs the
-    bit-identity tests through it via GLOC3D_LIB_PATH); only reg.hip is compiled again."""
+    """lib/libgloc3d_smallq.so: the same library with the culled 1-NN kernel evaluating its work queue before EVERY test
+    step, incomplete rounds included (-DGLOC_NN_EAGER; the shipped kernel evaluates full rounds between steps and the
+    rest at the end of a chunk): bounds tighten between all steps of a chunk and tail rounds of every size occur.  Test
+    infrastructure (tests/test_reg_variant_gpu.py runs the bit-identity tests through it via GLOC3D_LIB_PATH); only
+    reg.hip is compiled again."""
     build(force=force, verbose=verbose)
     out = os.path.join(LIBDIR, "libgloc3d_smallq.so")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     src = os.path.join(CSRC, "reg.hip")
     obj = os.path.join(LIBDIR, "reg_smallq.o")
     if force or _stale(obj, [src] + headers):
-        cmd = [HIPCC] + FLAGS + ["-DGLOC_NN_QCAP=128", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + ["-DGLOC_NN_EAGER", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -145,18 +145,17 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // the extra 32 B shift sub-block b's pair i into bank group (i + b) % 8, so lanes that walk
   // different sub-blocks in lock step never collide.
   constexpr int SB_STRIDE = (SB / 2) * 8 + 8;  // floats per sub-block: SB/2 pairs x 8 floats + 8 of shift
-  // queue entries: a chunk queues 55 items on average; a test step adds at most 128, and the queue is evaluated
-  // early when the next step might not fit (a wave's LDS: 6.8 KB; with the 1024-entry queue of the worst case,
-  // 7.8 KB, the same kernel measured 3 % slower; six waves per SIMD -- 80 VGPRs -- spill and gain nothing)
+  // queue entries: a chunk queues 51 items on average; a test step adds at most 128 to the at most 63 that wait for a
+  // full round (below).  A wave's LDS: 6.3 KB.
 #ifndef GLOC_NN_QCAP
-#define GLOC_NN_QCAP 512
+#define GLOC_NN_QCAP 256
 #endif
-  constexpr int QCAP = GLOC_NN_QCAP;  // (tests build a 128-entry variant to drive the early evaluation on every step)
+  constexpr int QCAP = GLOC_NN_QCAP;
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
     f32x4 src[S + 1];               // moved source points; [S]: a dummy the padded tail of the list points at
     unsigned long long key[S + 1];  // (bits(best d2) << 32) | (sub-block holding it << 2) | its quarter; [S]: bound -1 (nothing passes)
-    uint8_t tie[S];                 // (CS = 2: 6.8 KB per wave; five waves per SIMD -- 88 VGPRs -- need <= 8 KB)
+    uint8_t tie[S];                 // (CS = 2: 6.3 KB per wave, 78 VGPRs: six waves per SIMD)
     uint16_t list[S + 16];          // source slots that passed the chunk-level test, padded to a multiple of 16 with S
     uint16_t queue[QCAP];           // work items: (source slot << 3) | sub-block within the chunk
 #ifdef GLOC_NN_LDS_PAD
@@ -504,11 +503,16 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const f32x2 bcx = {bA.x, bA.y}, bcy = {bA.z, bA.w}, bcz = {bB.x, bB.y};   // centres of the lane's two sub-blocks
       const f32x2 nhx = {bB.z, bB.w}, nhy = {bC.x, bC.y}, nhz = {bC.z, bC.w};   // -(half extent) / SB2_RANGE
       uint32_t total = 0, sbmask = 0;
-      auto run_rounds = [&]() {  // evaluate the queued work items
+      // evaluate the queued work items: all of them, or (between two test steps: FULL_ONLY) the full rounds only -- the
+      // items of an incomplete round stay queued (moved to the front) and wait for company
+      auto run_rounds = [&](auto full_tag) {
+        constexpr bool FULL_ONLY = decltype(full_tag)::value;
         const unsigned long long t_r0 = now();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t all_queued = total;
+        if constexpr (FULL_ONLY) total &= ~63u;
         n_items += total;
   NN_MARK("rounds_begin");
         // One round = up to 64 items.  A full round gives every lane one item: its sub-block's 16 staged targets, the
@@ -596,7 +600,18 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
           else round_body(r, std::integral_constant<int, 1>{});
         }
   NN_MARK("rounds_end");
-        total = 0;
+        if constexpr (FULL_ONLY) {
+          const uint32_t rem = all_queued - total;  // (< 64 <= total: the two ranges do not overlap)
+          uint16_t keep = 0;
+          if ((uint32_t)lane < rem) keep = L.queue[total + lane];
+          if ((uint32_t)lane < rem) L.queue[lane] = keep;
+          total = rem;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // the keys the rounds lowered are what the next test step reads
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+          total = 0;
+        }
         if constexpr (TRACE) a_rounds += now() - t_r0;
       };
   NN_MARK("teststeps");
@@ -611,7 +626,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       if (rep_ == 1) total = 0;
 #endif
       for (uint32_t t0 = 0; t0 < k * (NSB / 2); t0 += 64 * TU) {
-        if (total + 128 * TU > (uint32_t)QCAP) run_rounds();  // rare: this step's items might not fit
+        // Between two steps every FULL round that is waiting is evaluated (round 4; until then only when the queue might
+        // overflow): its lanes are as busy as they get, and the bounds it lowers save the chunk's later steps their items.
+        static_assert(QCAP >= 63 + 128 * TU, "the tail of a round and one step's items fit the queue");
+#ifdef GLOC_NN_EAGER  // test variant (lib/libgloc3d_smallq.so): everything queued is evaluated before every step
+        if (total) run_rounds(std::false_type{});
+#else
+        if (total >= 64u) run_rounds(std::true_type{});
+#endif
         uint32_t si[TU];
         bool act[TU];
 #pragma unroll
@@ -670,7 +692,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         n_steps += (k + 15) / 16;
       }
       if constexpr (TRACE) a_tests += (now() - t_s0) - (a_rounds - a_r_before);
-      run_rounds();
+      run_rounds(std::false_type{});
       const unsigned long long t_f0 = now();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible

@@ -1,10 +1,10 @@
-"""GPU: the culled 1-NN kernel with a 128-entry work queue (lib/libgloc3d_smallq.so, -DGLOC_NN_QCAP=128).
+"""GPU: the culled 1-NN kernel evaluating its work queue before every test step (lib/libgloc3d_smallq.so, -DGLOC_NN_EAGER).
 
-At the shipped queue size (512 entries) the early evaluation -- the queue flushed in the middle of a chunk's test
-steps because the next step's items might not fit -- runs for a handful of chunks per launch; with 128 entries it
-runs on nearly every chunk, bounds tighten between the steps of one chunk, tail rounds of every size occur.  The
-tests that pin the search to the brute-force kernel, the oracle and the reference's kd-tree golden are run again
-through that library (a child pytest with GLOC3D_LIB_PATH set): the results must not change in a bit."""
+The shipped kernel evaluates the FULL rounds that are waiting between two test steps of a chunk and everything at the
+chunk's end; the variant evaluates everything before every step, so bounds tighten between all steps and tail rounds
+of every size occur.  The tests that pin the search to the brute-force kernel, the oracle and the reference's kd-tree
+golden are run again through that library (a child pytest with GLOC3D_LIB_PATH set): the results must not change in a
+bit."""
 import os
 import subprocess
 import sys
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANT = os.path.join(ROOT, "gloc3d_amd", "lib", "libgloc3d_smallq.so")
 SELECT = ("every_pass_bit_identical or lattice or contested or culled_equals_exhaustive or golden or full_size_properties "
-          "or nan_points or batch_matches_oracle")
+          "or nan_points or batch_matches_oracle or split")
 
 
 def test_bit_identity_tests_through_the_small_queue_library():

@@ -4,4 +4,4 @@ python -m pytest tests/test_reg_gpu.py -x -q -m gpu -k "split or bit_identical o
 run --nn-split-helpers 0
 run --nn-split-helpers 16
 run --nn-split-helpers 0
-python tools/dev_split_sweep.py 0,0,24,1 128,60000,24,2 256,60000,24,2 256,60000,24,4
+python tools/dev_split_sweep.py 0,0,24,1 256,60000,24,4

@@ -150,6 +150,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #ifndef GLOC_NN_QCAP
 #define GLOC_NN_QCAP 256
 #endif
+#ifndef GLOC_NN_GRAN
+#define GLOC_NN_GRAN 64  // items evaluated between two test steps come in multiples of this (64: full rounds; 32, 16: also a two- / four-lane round)
+#endif
   constexpr int QCAP = GLOC_NN_QCAP;
   struct WaveLds {
     float stage[NSB * SB_STRIDE];   // the chunk being evaluated
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t all_queued = total;
-        if constexpr (FULL_ONLY) total &= ~63u;
+        if constexpr (FULL_ONLY) total &= ~(uint32_t)(GLOC_NN_GRAN - 1);
         n_items += total;
   NN_MARK("rounds_begin");
         // One round = up to 64 items.  A full round gives every lane one item: its sub-block's 16 staged targets, the
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #ifdef GLOC_NN_EAGER  // test variant (lib/libgloc3d_smallq.so): everything queued is evaluated before every step
         if (total) run_rounds(std::false_type{});
 #else
-        if (total >= 64u) run_rounds(std::true_type{});
+        if (total >= (uint32_t)GLOC_NN_GRAN) run_rounds(std::true_type{});
 #endif
         uint32_t si[TU];
         bool act[TU];

@@ -50,6 +50,7 @@ struct gloc_reg {
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
   int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
+  bool nn_job_group_set = false;  // the caller chose nn_job_group (else small batches take one group of all their slots)
   int nn_sub_jobs = 0;      // culled kernel: interleaved shares of a job's work-groups that get their own slot (0: by batch size)
   bool temp_target_index = false;  // kd-ordered target index for the temporary scans of the host-buffer calls
   // heavy source groups over several waves (nn_compact.hpp, NnSplit): helper waves per job (-1: by batch size, 0: off)
@@ -98,9 +99,11 @@ struct BatchDims {
 int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
   h->split = NnSplit{};
   if (h->nn_mode == 1 || h->nn_split_helpers == 0 || h->nn_split_thresh == 0) return GLOC_OK;
-  // one query alone (20 jobs) is the case that needs it: its launch is as long as its longest wave; a launch of hundreds
-  // of jobs only loses its tail
-  uint32_t hx = h->nn_split_helpers > 0 ? (uint32_t)h->nn_split_helpers : (bd.n_jobs <= 64 ? 128u : (bd.n_jobs <= 256 ? 64u : 32u));
+  // one query alone (20 jobs) is the case that needs it: its launch is as long as its longest wave.  A launch of hundreds
+  // of jobs only loses its tail to such waves (5 % at 500 jobs, measured per XCD) and the kernel with the plan in it is
+  // 3 % slower: off by default there
+  uint32_t hx = h->nn_split_helpers > 0 ? (uint32_t)h->nn_split_helpers : (bd.n_jobs <= 64 ? 256u : (bd.n_jobs <= 256 ? 64u : 0u));
+  if (hx == 0) return GLOC_OK;
   hx = std::min<uint32_t>((hx + NN_WPB - 1) / NN_WPB * NN_WPB, 1u << 12);
   const size_t S = 64 * (size_t)cs, nj = bd.n_jobs, np = bd.n_part;
   const size_t zero_words = nj * np * 2 + nj * hx;
@@ -141,7 +144,10 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
     const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 4u : 1u);
-    const uint32_t jg = (uint32_t)h->nn_job_group, n_slots = bd.n_jobs * subs;
+    // (few slots: ONE group of them, so that every job's helpers and widest groups start at the head of the launch --
+    // groups are dispatched one after the other)
+    const uint32_t n_slots = bd.n_jobs * subs;
+    const uint32_t jg = n_slots <= 192 && !h->nn_job_group_set ? ((n_slots + 7u) & ~7u) : (uint32_t)h->nn_job_group;
     const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
     const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
     if (h->trace_on) {
@@ -532,6 +538,7 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_JOB_GROUP) {
     GLOC_REQUIRE(value >= 1 && value <= 65536, GLOC_ERR_INVALID, "must be in [1, 65536]");
     h->nn_job_group = (int)value;
+    h->nn_job_group_set = true;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_TEMP_TARGET_INDEX) {

@@ -71,8 +71,12 @@ constexpr uint32_t NN_W_FIXED = 21000, NN_W_CAND = 300, NN_W_CHUNK = 2800, NN_W_
 // waves for an estimate: 0 = the group's own wave at its rank in the launch order; 1 = one wave, but started with the
 // helpers (a wave of half the threshold that starts late still outlasts the launch); 2, 4, 8 = that many parts
 __host__ __device__ __forceinline__ uint32_t nn_parts_for(uint32_t w, uint32_t thresh) {
+#ifdef GLOC_NN_EARLY_CLASS
   if (thresh == 0 || 2ull * w <= thresh) return 0;
   if (w <= thresh) return 1;
+#else
+  if (thresh == 0 || w <= thresh) return 0;
+#endif
   return w > 4 * (unsigned long long)thresh ? 8u : (w > 2 * (unsigned long long)thresh ? 4u : 2u);
 }
 

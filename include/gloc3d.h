@@ -215,9 +215,9 @@ enum {
                                        millisecond per candidate is more than one registration saves) */
   GLOC_REG_OPT_NN_SPLIT_HELPERS = 6, /* culled search: wave slots per job at the head of the launch order for the
                                        heaviest source groups (a group whose work estimate of the previous pass
-                                       exceeds the threshold is searched by 2, 4 or 8 waves, one above half of it
-                                       starts early; identical results).  -1 (default): by batch size (128 up to
-                                       64 jobs, 64 up to 256, else 32); 0: off */
+                                       exceeds the threshold is searched by 2, 4 or 8 waves that start first;
+                                       identical results).  -1 (default): by batch size (256 up to
+                                       64 jobs, 64 up to 256, else off); 0: off */
   GLOC_REG_OPT_NN_SPLIT_THRESH = 7,  /* the estimate (cycles of one wave) above which a group is split; default
                                        60000; 0: off */
   GLOC_REG_OPT_NN_SUB_JOBS = 8       /* culled search tuning: interleaved shares of a job's work-groups that take a

@@ -85,3 +85,15 @@ print("candidate chunks per wave: mean", n_cand[ok].mean(), "p99", np.percentile
 h = np.stack([(rh >> (8 * q)) & 255 for q in range(4)], 1)[ok]
 print("rounds by occupancy (<=16, <=32, <=48, <=64 items):", h.sum(0), "per wave", np.round(h.mean(0), 2))
 print("contested sources (tie path) per wave:", n_ties[ok].mean(), "; waves with any:", (n_ties[ok] > 0).mean(), "; per source:", n_ties[ok].sum() / (128.0 * ok.sum()))
+# per XCD: when its waves started / ended (100 MHz clock shared by the XCDs) -- is the launch waiting for one of them?
+t0 = tr[ok, 23].astype(np.int64); t1 = tr[ok, 24].astype(np.int64)
+base = t0.min()
+st = ((t0 - base) & 0xFFFFFFFF) / 100.0
+en = ((t1 - base) & 0xFFFFFFFF) / 100.0
+xcc = tr[ok, 25] & 15
+print(f"launch span {en.max():.1f} us (trace build); per XCD:")
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        jj = job[ok][m]
+        print(f"  XCD {x}: waves {m.sum():6d}  last start {st[m].max():7.1f}  last end {en[m].max():7.1f}  wave-time {(en[m] - st[m]).sum() / 1e3:7.1f} ms  jobs {len(set(jj.tolist()))}  negatives among them {len(set(j for j in jj.tolist() if (j % 20) % 4 == 1))}")

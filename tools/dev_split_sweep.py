@@ -16,7 +16,7 @@ store.build_target_index_batch(cands)
 prm = capi.default_reg_params(ransac_iters=bench.RANSAC_ITERS, icp_iters=bench.ICP_ITERS, min_inlier_ratio=bench.MIN_INLIER_RATIO,
                               max_rmse=bench.MAX_RMSE)
 cid = np.array([cands], np.uint32)
-plans = [(0, 60000)] + [(h, t) for t in (40000, 60000, 90000) for h in (32, 64, 128)] + [(256, 30000), (0, 60000)]
+plans = [(0, 60000)]
 if len(sys.argv) > 1:
     plans = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 ref = None

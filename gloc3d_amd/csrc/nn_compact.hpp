@@ -129,7 +129,11 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // so with job_group a multiple of 8 all work-groups of a job run on ONE XCD and its candidate scan (2 MB of
 // points + boxes) stays in that XCD's 4 MB L2: measured L2-miss traffic per launch of 500 jobs 3.4 GB at
 // job_group 60, 1.07 GB at 24 (FETCH_SIZE; profiles/r02_*), i.e. 1.1x the algorithmic bytes.
-template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */>
+// WARM: every pass after a batch's first -- prev_corr holds the previous correspondences, and the cold start's code (a
+// search in the target's curve keys) is not in the kernel at all: measured, its mere presence cost the warm passes
+// -- 92 % of the 1-NN time -- 3 % (registers, code layout).
+template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */,
+          bool WARM = false>
 __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg /* per slot */, uint32_t subs,
     const CandState* __restrict__ states,
@@ -299,12 +303,34 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const f32x4 t = pt[s];
         best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
         b0 = j / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
-      } else {
+      } else if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
         const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
-        uint32_t lo = 0, hi = ix.n;  // lower_bound over the sorted keys
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (ix.keys[mid] < key) lo = mid + 1; else hi = mid;
+        // lower_bound over the sorted keys, nine-way: eight independent probes per round trip, 6 rounds at 124 k keys
+        // where the binary search took 17 dependent ones -- 46 % of a cold wave's time (traced, round 4)
+        uint32_t lo = 0, hi = ix.n;  // the answer is in [lo, hi]
+        while (hi - lo > 8u) {
+          const uint32_t len = hi - lo;
+          uint32_t pos[8], kv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pos[i] = lo + (uint32_t)(((unsigned long long)len * (uint32_t)(i + 1)) / 9u);  // lo < pos < hi, ascending
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kv[i] = ix.keys[pos[i]];
+          uint32_t nlo = lo, nhi = hi;
+#pragma unroll
+          for (int i = 7; i >= 0; --i)
+            if (!(kv[i] < key)) nhi = pos[i];      // the first probe that is not below the key bounds the answer from above
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (kv[i] < key) nlo = pos[i] + 1;     // the last probe below it, from below
+          lo = nlo;
+          hi = nhi;
+        }
+        {
+          uint32_t below = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (lo + i < hi && ix.keys[lo + i] < key) below++;
+          lo += below;  // (sorted: the keys below the key are a prefix of [lo, hi))
         }
         for (int d = -2; d <= 2; ++d) {
           long long jj = (long long)lo + d;

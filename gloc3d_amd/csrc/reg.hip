@@ -155,36 +155,39 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       if (h->trace.ensure(h->trace_waves * 4 * NN_TRACE_WORDS, h->stream)) return GLOC_ERR_NOMEM;
       GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 4 * NN_TRACE_WORDS, h->stream));
     }
-#define LAUNCH_COMPACT(CS_, P_)                                                                          \
+// instantiations: sources per lane x (pairs | moments) x (first pass: cold start | later: warm) x (with the split plan);
+// the per-wave trace only at two sources per lane
+#define LAUNCH_COMPACT(CS_, P_, W_)                                                                      \
   do {                                                                                                  \
-    if (h->trace_on) {                                                                                  \
-      if (h->split.hx) LAUNCH_COMPACT_T(CS_, P_, true, true);                                           \
-      else LAUNCH_COMPACT_T(CS_, P_, true, false);                                                      \
+    if (h->trace_on && (CS_) == 2) {                                                                    \
+      if (h->split.hx) LAUNCH_COMPACT_T(2, P_, true, true, W_);                                         \
+      else LAUNCH_COMPACT_T(2, P_, true, false, W_);                                                    \
     } else if (h->split.hx) {                                                                           \
-      LAUNCH_COMPACT_T(CS_, P_, false, true);                                                           \
+      LAUNCH_COMPACT_T(CS_, P_, false, true, W_);                                                       \
     } else {                                                                                            \
-      LAUNCH_COMPACT_T(CS_, P_, false, false);                                                          \
+      LAUNCH_COMPACT_T(CS_, P_, false, false, W_);                                                      \
     }                                                                                                   \
   } while (0)
-#define LAUNCH_COMPACT_T(CS_, P_, T_, S_)                                                                \
-  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_, S_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
+#define LAUNCH_COMPACT_T(CS_, P_, T_, S_, W_)                                                            \
+  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_, S_, W_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
                      gate2, h->split,                                                                    \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
+#define LAUNCH_COMPACT_CS(P_, W_)                                                                        \
+  do {                                                                                                  \
+    if (cs == 1) LAUNCH_COMPACT(1, P_, W_);                                                             \
+    else if (cs == 2) LAUNCH_COMPACT(2, P_, W_);                                                        \
+    else LAUNCH_COMPACT(4, P_, W_);                                                                     \
+  } while (0)
     if (grid) {
-      if (want_pairs) {
-        if (cs == 1) LAUNCH_COMPACT(1, true);
-        else if (cs == 2) LAUNCH_COMPACT(2, true);
-        else LAUNCH_COMPACT(4, true);
-      } else {
-        if (cs == 1) LAUNCH_COMPACT(1, false);
-        else if (cs == 2) LAUNCH_COMPACT(2, false);
-        else LAUNCH_COMPACT(4, false);
-      }
+      if (want_pairs) LAUNCH_COMPACT_CS(true, false);  // (the pass that writes the pairs is a batch's first)
+      else if (warm) LAUNCH_COMPACT_CS(false, true);
+      else LAUNCH_COMPACT_CS(false, false);
     }
+#undef LAUNCH_COMPACT_CS
 #undef LAUNCH_COMPACT
 #undef LAUNCH_COMPACT_T
   }

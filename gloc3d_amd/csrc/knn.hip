@@ -178,6 +178,7 @@ int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_
 // ---- MFMA path -------------------------------------------------------------------------------
 struct MfmaPlan {
   int WQ, NT, KS, BQ, BN;
+  int t32 = 0;  // 1: the 32 x 32 x 2 tiles (dist_mfma32_kernel: BQ = 64, BN = 64 * NT)
 };
 
 MfmaPlan plan_mfma(int nq, int n_range, int dim) {
@@ -209,6 +210,14 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
     if (cost < best_cost) {
       best_cost = cost;
       best = MfmaPlan{WQ, NT, KS, BQ, BN};
+    }
+  }
+  // developer override: GLOC3D_MFMA_T32="NT,KS" -- the 32 x 32 x 2 tiles with NT tiles per wave and KS splits of K
+  if (const char* e = getenv("GLOC3D_MFMA_T32")) {
+    int nt = 0, ks = 0;
+    if (sscanf(e, "%d,%d", &nt, &ks) == 2 && (nt == 1 || nt == 2) && ks > 0 && nq > 32) {
+      best = MfmaPlan{4, nt, ks, 64, 64 * nt};
+      best.t32 = 1;
     }
   }
   // developer override: GLOC3D_MFMA_PLAN="NT,KS"
@@ -254,7 +263,22 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     GLOC_TRY(h->n_incomplete.ensure(sizeof(unsigned long long), h->stream));
     GLOC_HIP(hipMemsetAsync(h->n_incomplete.p, 0, sizeof(unsigned long long), h->stream));
   }
-  {
+  if (p.t32) {
+    ProfScope ps(h->prof, "dist_mfma", h->stream);
+    dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
+    const int kps32 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+    static const int bk32 = getenv("GLOC3D_MFMA_BK") ? atoi(getenv("GLOC3D_MFMA_BK")) : 64;
+#define MF32(NT_, KQ_)                                                                                             \
+  hipLaunchKernelGGL((dist_mfma32_kernel<NT_, KQ_>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), d_q,      \
+                     h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps32, ld, strideP)
+    if (bk32 == 32 || kps32 < 128) {
+      if (p.NT == 1) MF32(1, 8); else MF32(2, 8);
+    } else {
+      if (p.NT == 1) MF32(1, 16); else MF32(2, 16);
+    }
+#undef MF32
+    GLOC_HIP(hipGetLastError());
+  } else {
     ProfScope ps(h->prof, "dist_mfma", h->stream);
 #define MF(WQ_, NT_)                                                        \
   if (p.WQ == WQ_ && p.NT == NT_) {                                         \

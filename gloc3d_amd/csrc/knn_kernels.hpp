@@ -415,6 +415,156 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 (MFMA form, 32 x 32 tiles; round 4): the same partial dots with v_mfma_f32_32x32x2_f32.  A wave owns 32 queries x
+// (32 * NT) rows: one ds_read_b128 per operand row feeds FOUR MFMAs of 64 cycles each (the 16x16x4 form: four of 32),
+// so a flop costs half the LDS operand reads, and the 16 accumulator registers of a tile give the 64-cycle dependent
+// latency of this form nothing to wait for once two tiles (or two waves per SIMD) interleave.  Work-group = 4 waves,
+// 2 along the queries (64) x 2 along the rows: BN = 64 * NT.  LDS image as above: [k / 4][row][4 floats], the two
+// half-waves read planes kq and kq + 1 (K = 2 per MFMA: lane l holds row l % 32, k slot l / 32).
+// Rounding: every accumulator element is still one k-ordered fmaf chain flushed every 64 k -- the bound of the coarse
+// distance (knn.hip) does not change.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT, int KQ /* K-step = 4*KQ floats */>
+__global__ __launch_bounds__(256) void dist_mfma32_kernel(const float* __restrict__ db,
+                                                          const float* __restrict__ queries,
+                                                          float* __restrict__ P, int dim,
+                                                          size_t first_row, int n_range, int nq,
+                                                          int k_per_split, size_t ldP,
+                                                          size_t strideP) {
+  constexpr int BQ = 64;
+  constexpr int BN = 64 * NT;
+  constexpr int ROWS = BQ + BN;
+  constexpr int PLANE = ROWS + 1;  // float4 slots per kq plane
+  constexpr int BK = 4 * KQ;
+  constexpr int NL = (ROWS * KQ + 255) / 256;
+  __shared__ f32x4 lds[2 * KQ * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wq = w & 1, wn = w >> 1;
+  const int n0 = blockIdx.x * BN;
+  const int q0 = blockIdx.y * BQ;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
+
+  const float* src[NL];  // never null: rows outside the tile read row 0 and are masked to zero
+  int dst[NL], kq4[NL];
+  bool ok[NL], rowv[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int slot = tid + i * 256;
+    const int row = slot / KQ, kq = slot % KQ;
+    ok[i] = slot < ROWS * KQ;
+    dst[i] = kq * PLANE + row;
+    kq4[i] = kq * 4;
+    src[i] = db + first_row * dim;
+    rowv[i] = false;
+    if (ok[i]) {
+      if (row < BQ) {
+        const int qq = q0 + row;
+        if (qq < nq) {
+          src[i] = queries + (size_t)qq * dim;
+          rowv[i] = true;
+        }
+      } else {
+        const int jj = n0 + (row - BQ);
+        if (jj < n_range) {
+          src[i] = db + (first_row + (size_t)jj) * dim;
+          rowv[i] = true;
+        }
+      }
+    }
+  }
+  f32x4 preA[NL], preB[NL];
+  auto gload = [&](f32x4* pre, int k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int kk = k + kq4[i];
+      const int kc = kk < dim - 4 ? kk : dim - 4;
+      const f4u v = *reinterpret_cast<const f4u*>(src[i] + kc);
+      const bool use = rowv[i] && kk < kend;
+      pre[i] = use ? f32x4{v.x, v.y, v.z, v.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](const f32x4* pre, int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (ok[i]) lds[buf * KQ * PLANE + dst[i]] = pre[i];
+  };
+
+  f32x16 acc[NT], tot[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[t][r] = 0.f;
+      tot[t][r] = 0.f;
+    }
+  const int a_row = wq * 32 + (lane & 31);
+  const int b_row0 = BQ + wn * NT * 32 + (lane & 31);
+  auto compute = [&](int buf, int k) {
+    const f32x4* L = lds + buf * KQ * PLANE;
+#pragma unroll
+    for (int sub = 0; sub < KQ / 2; ++sub) {
+      const int kq = sub * 2 + (lane >> 5);
+      const f32x4 a = L[kq * PLANE + a_row];
+      f32x4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = L[kq * PLANE + b_row0 + t * 32];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+    if (BK >= 64 || ((k - kbeg) & 32) || (k + BK) >= kend) {  // every 64 k and at the end: flush
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        tot[t] += acc[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      }
+    }
+  };
+
+  gload(preA, kbeg);
+  lstore(preA, 0);
+  gload(preA, kbeg + BK);
+  gload(preB, kbeg + 2 * BK);
+  __syncthreads();
+  for (int k = kbeg; k < kend; k += 2 * BK) {
+    compute(0, k);
+    if (k + BK < kend) {
+      lstore(preA, 1);
+      gload(preA, k + 3 * BK);
+      __syncthreads();
+      compute(1, k + BK);
+      if (k + 2 * BK < kend) {
+        lstore(preB, 0);
+        gload(preB, k + 4 * BK);
+        __syncthreads();
+      }
+    }
+  }
+  // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* Pz = P + (size_t)blockIdx.z * strideP;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = n0 + (wn * NT + t) * 32 + (lane & 31);
+    if (j < n_range) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Pz[(size_t)qq * ldP + j] = tot[t][r];  // rows q >= nq land in the padded part of P
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1 (top-k part): per-query top-K of a distance row, LDS-staged, in two kernels.
 //
 // select_chunk_kernel: grid (chunks, nq), 256 threads, E elements per thread (chunk = 256 E).

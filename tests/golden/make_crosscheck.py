@@ -11,7 +11,8 @@ the single-author risk.  tests/test_oracle_crosscheck.py c
 Shared with the oracle by construction (they are part of the specification, not of the algorithm): the counter RNG
 of gloc3d_amd/synth.py that draws the three sample ids of hypothesis h of candidate c, and the inputs.
 
-    python tests/golden/make_crosscheck.py          # rewrites tests/golden/reg_crosscheck.npz
+    python tests/golden/make_crosscheck.py          # rewrites tests/golden/reg_crosscheck.npz (six small cases in
+                                                    # seconds, the full-size one in about half a minute)
 """
 import os
 import sys
@@ -159,13 +160,24 @@ def cases():
             ("all_hypotheses", q, a, dict(cand_id=5, ransac_iters=500, icp_iters=4, confidence=0.0))]
 
 
+def full_size_case():
+    """BASELINE configs[2]'s shape: ~124 k x ~124 k points, RANSAC (3000 cap, adaptive) + ICP 20 -- the two full scans of
+    tests/test_reg_gpu.py's fixture (a same-place pair 5 degrees / 0.6 m apart).  ~25 s of cKDTree queries here, so it
+    is a case of its own: the oracle (CPU suite) and the HIP path (-m gpu) are compared with the committed fixture."""
+    w = synth.make_world(1001)
+    A = synth.lidar_scan(w, None, seed=1001)[:, :3]
+    B = synth.lidar_scan(w, synth.se3(5.0, (0.5, -0.3, 0.1)), seed=1002)[:, :3]
+    return ("full_size", np.ascontiguousarray(B), np.ascontiguousarray(A),
+            dict(cand_id=0, ransac_iters=3000, icp_iters=20, max_rmse=1.0))
+
+
 def crc(a):
     return np.uint64(np.ascontiguousarray(a, F).view(np.uint32).sum(dtype=np.uint64))
 
 
 if __name__ == "__main__":
     out = {}
-    for name, s, t, kw in cases():
+    for name, s, t, kw in cases() + [full_size_case()]:
         r = register(s, t, **kw)
         print(name, "inliers", r["inliers"], "hyp", r["best_hyp"], "rmse", round(r["rmse"], 4), "ok", r["ok"])
         out[name + "_T"] = r["T"]

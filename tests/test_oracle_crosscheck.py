@@ -42,3 +42,24 @@ def test_the_fixture_is_what_the_generator_makes():
     name, s, t, kw = mc.cases()[3]
     r = mc.register(s, t, **kw)
     assert np.abs(r["T"] - g[name + "_T"]).max() < 1e-6 and r["inliers"] == int(g[name + "_meta"][1])
+
+
+def _check(o, g, name):
+    T, (rmse, inl, hyp, ok) = g[name + "_T"], g[name + "_meta"]
+    assert np.abs(np.asarray(o["T"])[:3, 3] - T[:3, 3]).max() < 1e-4, name
+    assert _rot_angle(np.asarray(o["T"])[:3, :3], T[:3, :3]) < 1e-4, name
+    assert abs(float(o["rmse"]) - rmse) < 1e-4 and bool(o["ok"]) == bool(ok), name
+    assert abs(int(o["inliers"]) - int(inl)) <= max(2, int(1e-4 * inl)), name   # (points exactly at the 0.6 m threshold)
+
+
+def test_oracle_agrees_at_full_size(oracle_mod):
+    """BASELINE configs[2]'s shape (124 k x 124 k points, RANSAC 3000 adaptive + ICP 20): the C restatement against
+    the scipy / numpy statement's committed result (tests/golden/reg_crosscheck.npz: full_size).
+    The same fixture checks the HIP path in tests/test_reg_gpu.py::test_full_size_matches_the_independent_statement."""
+    g = np.load(os.path.join(HERE, "golden", "reg_crosscheck.npz"))
+    name, s, t, kw = mc.full_size_case()
+    assert (g[name + "_crc"] == np.array([mc.crc(s), mc.crc(t)], np.uint64)).all(), "inputs are regenerated, not stored"
+    o = oracle_mod.reg_one(s, t, cand_id=kw["cand_id"], ransac_iters=kw["ransac_iters"], icp_iters=kw["icp_iters"],
+                           max_rmse=kw["max_rmse"])
+    _check(o, g, name)
+    assert (o["best_hyp"] if o["best_hyp"] != 0xFFFFFFFF else -1) == int(g[name + "_meta"][2])

@@ -73,6 +73,26 @@ def test_full_size_registration_matches_oracle(reg, capi, scans, fullsize_oracle
     assert ep < 1.0 and er < 5.0        # the reference's success criterion (global_localization.cpp:307)
 
 
+def test_full_size_matches_the_independent_statement(reg, capi, scans):
+    """The HIP path against the scipy / numpy statement of SURVEY Appendix B at BASELINE configs[2]'s shape: the
+    committed result of tests/golden/make_crosscheck.py::full_size_case (cKDTree + numpy.linalg.svd, ~124 k x 124 k
+    points, RANSAC 3000 adaptive + ICP 20), pose within 1e-4 m / 1e-4 rad, on every search mode."""
+    import importlib.util, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_crosscheck", os.path.join(here, "golden", "make_crosscheck.py"))
+    mc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mc)
+    g = np.load(os.path.join(here, "golden", "reg_crosscheck.npz"))
+    assert (g["full_size_crc"] == np.array([mc.crc(scans["B"]), mc.crc(scans["A"])], np.uint64)).all()   # the fixture's inputs
+    prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
+    out = reg.batch(scans["B"], [scans["A"]], params=prm, stream_ids=[0])
+    T, (rmse, inl, hyp, ok) = g["full_size_T"], g["full_size_meta"]
+    assert np.abs(out["T"][0][:3, 3] - T[:3, 3]).max() < POSE_TOL_M
+    assert _rot_angle(out["T"][0][:3, :3], T[:3, :3]) < POSE_TOL_RAD
+    assert abs(out["rmse"][0] - rmse) < 1e-4 and bool(out["ok"][0]) == bool(ok)
+    assert abs(int(out["inliers"][0]) - int(inl)) <= max(2, int(1e-4 * inl))
+
+
 def capi_pose_error(T_gt, T):
     from gloc3d_amd import loop_detector as ld
     return ld.pose_error(np.asarray(T_gt, np.float32), T)

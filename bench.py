@@ -388,6 +388,8 @@ def main():
     ap.add_argument("--no-legs", "--no-lone-query", dest="no_legs", action="store_true",
                     help="skip everything after the timed region but the CPU baseline: legs and sub-records (profiling runs)")
     ap.add_argument("--leg-steps", type=int, default=4, help="steps of each leg (x --batch queries)")
+    ap.add_argument("--cfge-rows", type=int, default=1_000_000,
+                    help="N > 1: rows of the sharded descriptor database of sub_records.knn_cfgE_sharded (BASELINE configs[4]: 1M; 0: skip)")
     ap.add_argument("--views-cache", default=None, help="npz cache of the ray-cast base views (profiling runs)")
     ap.add_argument("--nn-src-per-lane", type=int, default=0, help="culled 1-NN tuning (1, 2, 4)")
     ap.add_argument("--nn-job-group", type=int, default=0, help="culled 1-NN tuning: jobs interleaved in the launch order")
@@ -555,8 +557,11 @@ def main():
         a_ = [r_.nn_stats() for r_ in regs]
         return sum(x[0] for x in a_), sum(x[1] for x in a_)
 
-    capi_knn, collectives, rccl_ranks_seen = None, "none", None
-    if world > 1 and args.collectives == "capi" and args.backend == "nccl" and not args.same_device:
+    capi_knn, collectives, rccl_ranks_seen, comm = None, "none", None, None
+    # the transport the caller asked for: the C-ABI RCCL path unless --collectives torch, a gloo backend or ranks that
+    # share a device (rehearsals) say otherwise; if it was asked for and is not what ran, the run FAILS (after its line)
+    want_capi = world > 1 and args.collectives == "capi" and args.backend == "nccl" and not args.same_device
+    if want_capi:
         try:
             comm = capi.Comm(local_rank, rank, world, sharded.torch_exchange(dev))
             capi_knn = sharded.CapiShardedKnn(index, comm)
@@ -1147,6 +1152,73 @@ def main():
                                          "what": "one of the 8 shards of BASELINE configs[4] (1M x 4096): the per-rank search before the "
                                                  "all-gather of the top-k lists; roofline = max(HBM time of the shard, fp32 MFMA time)"}
 
+    # ---- N > 1: BASELINE configs[4] in the line the driver runs -- the 1 M x 4096 database row-interleaved over the
+    # ranks (1 M / N rows generated on each device), searched through gloc_knn_search_sharded (local top-k with global
+    # indices -> ONE grouped RCCL all-gather of the lists over xGMI -> K3 merge, all below the C ABI, one stream) ----
+    if world > 1 and args.cfge_rows > 0 and not args.no_legs:
+        log(f"sub-record: configs[4], {args.cfge_rows} x {DIM} over {world} ranks")
+        rows_total, per_rank = args.cfge_rows, args.cfge_rows // world
+        CFGE_SEED = 5001
+        ixe = capi.KnnIndex(DIM, device=local_rank)
+        ixe.reserve(per_rank)
+        ixe.add_synthetic(1, CFGE_SEED, rank, per_rank, row_stride=world)       # global rows rank, rank + N, ...
+        q_rows = (np.arange(64, dtype=np.int64) * 15485 + 977) % (per_rank * world)
+        qe = torch.from_numpy(synth.queries_near(CFGE_SEED, q_rows, DIM)).to(dev)
+        ref_e = sharded.ShardedKnn(rank, world, sharded.hip_local_search(ixe), sharded.hip_merge(local_rank), comm_device=comm_dev)
+        ri, rd = ref_e.search(qe[:8], TOP_K)                                    # the same search over torch.distributed
+        torch.cuda.synchronize()
+        rec = {"rows": per_rank * world, "rows_per_rank": per_rank, "dim": DIM, "ranks": world, "top_k": TOP_K,
+               "what": "BASELINE configs[4]: synthetic 1M-place x 4096-D descriptor DB row-interleaved over the ranks, "
+                       "queries replicated, per-shard top-k all-gathered over xGMI and merged on every rank"}
+        own_row_first = bool((ri[:, 0].cpu().numpy() == q_rows[:8]).all())       # a query sits next to its own row
+        if capi_knn is not None:
+            cke = sharded.CapiShardedKnn(ixe, comm)
+            ci, cd = cke.search(qe[:8], TOP_K)
+            torch.cuda.synchronize()
+            same = (bool((ci.cpu() == ri.cpu()).all()) and bool((cd.cpu().view(torch.int32) == rd.cpu().view(torch.int32)).all()))
+            flag = torch.tensor([1 if (same and own_row_first) else 0], device=comm_dev or dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rec["equal_to_torch_gathered_path_on_8_queries"] = bool(int(flag.item()))
+            search_e = cke.search
+            rec["transport"] = collectives
+        else:
+            rec["equal_to_torch_gathered_path_on_8_queries"] = None
+            search_e = ref_e.search
+            rec["transport"] = collectives
+        rec["query_finds_its_own_row_first"] = own_row_first
+        for nq_e, reps_e in ((1, 30), (64, 20)):
+            qq = qe[:nq_e].contiguous()
+            for _ in range(3):
+                search_e(qq, TOP_K)
+            fence()
+            t0 = time.time()
+            for _ in range(reps_e):
+                search_e(qq, TOP_K)
+            torch.cuda.synchronize()
+            te = torch.tensor([(time.time() - t0) / reps_e], dtype=torch.float64, device=comm_dev or dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            us_e = float(te.item()) * 1e6
+            stage_e = None
+            if capi_knn is not None:                                            # per-stage HIP events inside the C-ABI call
+                ixe.set_option(capi.KNN_OPT_PROFILE, 1)
+                ixe.profile_reset()
+                for _ in range(10):
+                    search_e(qq, TOP_K)
+                torch.cuda.synchronize()
+                stage_e = {n_: ixe.profile(n_)[0] / 10 * 1e3 for n_ in ("shard_local", "shard_gather", "shard_merge")}
+                ixe.set_option(capi.KNN_OPT_PROFILE, 0)
+            byts = 4.0 * per_rank * DIM
+            flop = 2.0 * nq_e * per_rank * DIM
+            roof = max(byts / (PEAK_HBM_GBS * 1e9), flop / (PEAK_FP32_TFLOPS * 1e12)) * 1e6
+            rec[f"q{nq_e}"] = {"us_per_search": us_e, "queries_per_s": nq_e / (us_e * 1e-6), "stage_us_rank0": stage_e,
+                               "per_rank_roofline_us": roof, "frac_of_roofline": roof / us_e,
+                               "timing": f"wall clock over {reps_e} back-to-back searches, barrier + synchronize on both sides, max over ranks"}
+        ixe.close()
+        del qe
+        torch.cuda.empty_cache()
+        if rank == 0:
+            sub_records = dict(sub_records or {}, knn_cfgE_sharded=rec)
+
     q_per_rep = n_steps * per_step
     out = {
         "metric": "localization queries/sec (kNN+top-20 reg), KITTI-00-sized DB",
@@ -1198,10 +1270,18 @@ def main():
         out["cpu_baseline"] = cpu_baseline(q_scan_host[0].numpy(), cand_scans, n_places, MIN_INLIER_RATIO, gpu_rows=rows0)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if world > 1:
+        out["per_gpu_value"] = out["value"] / world      # (to set beside the N = 1 line)
+        out["config"]["collectives_requested"] = "capi (RCCL below the C ABI)" if want_capi else f"torch.distributed ({args.backend})"
     if rank == 0:
         print(json.dumps(out), flush=True)
+    wrong_transport = want_capi and capi_knn is None
     if world > 1:
         dist.destroy_process_group()
+    if wrong_transport:
+        log("FAILED: the C-ABI RCCL transport was requested (--collectives capi) but the run fell back to torch.distributed "
+            "(its communicator or self-tests failed, see above); pass --collectives torch to accept that path")
+        sys.exit(4)
     if shared_views and os.path.exists(shared_views):
         try:
             os.remove(shared_views)

@@ -212,6 +212,15 @@ MfmaPlan plan_mfma(int nq, int n_range, int dim) {
       best = MfmaPlan{WQ, NT, KS, BQ, BN};
     }
   }
+  // Many rounds of work-groups per CU (a shard of a large database): the 32 x 32 x 2 tiles -- half the LDS operand reads
+  // per flop.  Measured at 64 x 125 000 x 4096: 794 us against 922 with the 16 x 16 x 4 tiles (BN = 128, K-step 32, three
+  // work-groups per CU).  At 64 x 10 000 the launch is ONE round of work-groups and the tile that divides 10 000 rows
+  // into 500 of them (BN = 80, split-K 4) wins: 82 us against 92 - 116 for every 32-wide plan.
+  static const bool no_t32 = getenv("GLOC3D_MFMA_NO_T32") != nullptr;
+  if (nq > 32 && !no_t32 && (long long)((n_range + 127) / 128) * ((nq + 63) / 64) >= 3 * 256) {
+    best = MfmaPlan{4, 2, 1, 64, 128};
+    best.t32 = 1;
+  }
   // developer override: GLOC3D_MFMA_T32="NT,KS" -- the 32 x 32 x 2 tiles with NT tiles per wave and KS splits of K
   if (const char* e = getenv("GLOC3D_MFMA_T32")) {
     int nt = 0, ks = 0;
@@ -267,7 +276,7 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     ProfScope ps(h->prof, "dist_mfma", h->stream);
     dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
     const int kps32 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
-    static const int bk32 = getenv("GLOC3D_MFMA_BK") ? atoi(getenv("GLOC3D_MFMA_BK")) : 64;
+    static const int bk32 = getenv("GLOC3D_MFMA_BK") ? atoi(getenv("GLOC3D_MFMA_BK")) : 32;
 #define MF32(NT_, KQ_)                                                                                             \
   hipLaunchKernelGGL((dist_mfma32_kernel<NT_, KQ_>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), d_q,      \
                      h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps32, ld, strideP)
@@ -712,21 +721,28 @@ int gloc_knn_search_sharded(gloc_knn* h, gloc_comm* comm, const float* d_queries
   uint64_t* gi = li + cnt;
   float* ld = reinterpret_cast<float*>(gi + G * cnt);
   float* gd = ld + cnt;
-  // this shard's top-k with GLOBAL row indices ...
-  GLOC_TRY(search_device_impl(h, d_queries, nq, k, 0, (size_t)-1, index_offset, li, ld, index_stride));
+  // this shard's top-k with GLOBAL row indices ...  (profile families: shard_local / shard_gather / shard_merge)
+  {
+    ProfScope ps(h->prof, "shard_local", h->stream);
+    GLOC_TRY(search_device_impl(h, d_queries, nq, k, 0, (size_t)-1, index_offset, li, ld, index_stride));
+  }
   if (G == 1) {
     GLOC_HIP(hipMemcpyAsync(d_out_idx, li, cnt * sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream));
     GLOC_HIP(hipMemcpyAsync(d_out_d2, ld, cnt * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return GLOC_OK;
   }
   // ... all-gathered over xGMI: one fused launch for the two small arrays ([shard][nq][k], what K3 reads) ...
-  GLOC_TRY(gloc::comm::group_begin());
-  int rc = gloc::comm::all_gather(comm, li, gi, cnt * sizeof(uint64_t), h->stream);
-  if (rc == GLOC_OK) rc = gloc::comm::all_gather(comm, ld, gd, cnt * sizeof(float), h->stream);
-  const int rc2 = gloc::comm::group_end();
-  GLOC_TRY(rc);
-  GLOC_TRY(rc2);
+  {
+    ProfScope ps(h->prof, "shard_gather", h->stream);
+    GLOC_TRY(gloc::comm::group_begin());
+    int rc = gloc::comm::all_gather(comm, li, gi, cnt * sizeof(uint64_t), h->stream);
+    if (rc == GLOC_OK) rc = gloc::comm::all_gather(comm, ld, gd, cnt * sizeof(float), h->stream);
+    const int rc2 = gloc::comm::group_end();
+    GLOC_TRY(rc);
+    GLOC_TRY(rc2);
+  }
   // ... and merged on every rank in the same (d2, idx) order: a replicated result, equal to the one-GPU search
+  ProfScope ps(h->prof, "shard_merge", h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(64), 0, h->stream, gi, gd, (int)G, (int)nq, (int)k,
                      d_out_idx, d_out_d2);
   GLOC_HIP(hipGetLastError());

@@ -40,7 +40,7 @@ class RegParams(C.Structure):
     _fields_ = [("ransac_iters", C.c_uint32), ("inlier_thresh", C.c_float),
                 ("min_inlier_ratio", C.c_float), ("icp_iters", C.c_uint32),
                 ("max_corr_dist", C.c_float), ("seed", C.c_uint64),
-                ("ransac_confidence", C.c_float), ("max_rmse", C.c_float)]
+                ("ransac_confidence", C.c_float), ("max_rmse", C.c_float), ("max_final_step", C.c_float)]
 
 
 class BevParams(C.Structure):
@@ -157,6 +157,7 @@ _PROTOS = [
     ("gloc_reg_first_success_multi", _i, [_vp, _sz, _vp, _vp, _sz, _vp, C.POINTER(RegParams), _vp, _vp, _vp, _vp,
                                           C.POINTER(_u64)]),
     ("gloc_reg_select_first_ok", _i, [_vp, _sz]),
+    ("gloc_reg_final_steps", _i, [_vp, _vp, _sz]),
     ("gloc_reg_nn", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     ("gloc_reg_ransac_hypotheses", _i, [_vp, _vp, _vp, _vp, _sz, _u64, _u32, _u32, _vp, _vp, _vp,
                                         C.c_float]),
@@ -690,6 +691,12 @@ class Registrar:
                                                s.shape[0], seed, cand, n_hyp, _np_ptr(Rt),
                                                _np_ptr(valid), _np_ptr(inl), inlier_thresh))
         return Rt, valid, inl
+
+    def final_steps(self, n_jobs):
+        """Per job of the last batch: RMS displacement of the last ICP update (what max_final_step gates)."""
+        out = np.empty(n_jobs, np.float32)
+        check(lib().gloc_reg_final_steps(self._h, _np_ptr(out), n_jobs))
+        return out
 
     def profile(self, kernel):
         ms, n = C.c_double(), C.c_uint64()

@@ -897,9 +897,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // and a 24-bit sum of 128 of them is exact to 1e-7 of that -- 1e-11 of the raw sum.  solve_kernel puts the raw
   // moments back together in fp64 (sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T: exact products of
   // fp32 values), in the fixed order of the partials.
-  float mv[ACC_NV];
+  float mv[17], pp = 0.f;  // (pp: sum |p'|^2, for the RMS size of the ICP update -- solve_kernel)
 #pragma unroll
-  for (int k = 0; k < ACC_NV; ++k) mv[k] = 0.f;
+  for (int k = 0; k < 17; ++k) mv[k] = 0.f;
   const float cen[3] = {0.5f * (wlo[0] + whi[0]), 0.5f * (wlo[1] + whi[1]), 0.5f * (wlo[2] + whi[2])};
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
@@ -917,6 +917,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const float P[3] = {px[s] - cen[0], py[s] - cen[1], pz[s] - cen[2]};
         const float Q[3] = {q.x - cen[0], q.y - cen[1], q.z - cen[2]};
         mv[0] += 1.f;
+        pp = __builtin_fmaf(P[2], P[2], __builtin_fmaf(P[1], P[1], __builtin_fmaf(P[0], P[0], pp)));
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           mv[1 + a] += P[a];
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     // reduce-scatter: at every step a lane keeps half of its values and hands the other half to its
     // partner, so 16 values cost 8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6.  Lane l ends with moment
     // (l >> 2) & 15 (all four lanes of a quad).  The partial: 17 floats + the centre (WavePartial).
-    static_assert(ACC_NV == 17, "16 scattered moments + the d2 sum");
+    static_assert(ACC_NV == 18, "16 scattered moments, the d2 sum, sum |p'|^2");
     static_assert(sizeof(double) * ACC_NV >= sizeof(float) * WAVE_PARTIAL_FLOATS, "a wave partial fits a partial's slot");
     float* out = reinterpret_cast<float*>(partials + ((size_t)job * n_part + gi) * ACC_NV);
 #pragma unroll
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     float x = mv[0], y = mv[16];
     x += xor_lane<2>(x);
     x += xor_lane<1>(x);
-    y = exchange_add<32>(y, y);
+    y = exchange_add<32>(y, pp);  // the two whole-wave sums share the butterfly: lanes 0-31 end with sum d2, 32-63 with sum |p'|^2
     y = exchange_add<16>(y, y);
     y += xor_lane<8>(y);
     y += xor_lane<4>(y);
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       out[18] = cen[1];
       out[19] = cen[2];
     }
+    if (lane == 32) out[20] = y;
   }
   NN_MARK("end");
   if (TRACE && trace && lane == 0) {

@@ -42,8 +42,10 @@ struct gloc_reg {
     std::vector<size_t> n_src;    // per job
     std::vector<float> def_T;     // output rows before the jobs' results go in (initial guess / identity)
     size_t total = 0;
-    float max_rmse = 0.f;
+    float max_rmse = 0.f, max_final_step = 0.f;
+    bool icp = false;
   } pending;
+  std::vector<float> last_final_step;  // per job of the last collected batch (gloc_reg_final_steps)
   int nn_mode = 0;        // 0 culled + compacted (default), 1 exhaustive
   bool trace_on = false;  // dev only: per-wave trace of the culled kernel
   DevBuf trace;
@@ -87,6 +89,7 @@ void init_state(CandState& st, const float* T16, uint32_t ransac_iters = 0) {
   }
   st.best_h = 0xFFFFFFFFu;
   st.niters = ransac_iters;
+  st.last_step = 0.f;
 }
 
 struct BatchDims {
@@ -341,8 +344,9 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
 
 // Waits for the results of the batch enqueue_jobs() queued last (its own event: not for the stream, which may carry the
 // next batch of a handle sharing it) and unpacks them, per job, in job order.
-int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max_rmse, float* out_T, float* out_rmse,
-                 uint32_t* out_inliers, int* out_ok) {
+int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max_rmse, float max_final_step, float* out_T,
+                 float* out_rmse, uint32_t* out_inliers, int* out_ok) {
+  h->last_final_step.assign(n_jobs, 0.f);
   if (n_jobs == 0) return GLOC_OK;
   GLOC_HIP(hipEventSynchronize(h->done_ev));
   for (uint32_t c = 0; c < n_jobs; ++c) {
@@ -357,7 +361,10 @@ int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max
     const float rmse = n_src ? (float)std::sqrt(st.sum_d2 / (double)n_src) : 0.f;
     if (out_rmse) out_rmse[c] = rmse;
     if (out_inliers) out_inliers[c] = st.best_inl;
-    if (out_ok) out_ok[c] = st.ok && !(max_rmse > 0.f && !(rmse <= max_rmse));
+    // plausibility of the estimate (include/gloc3d.h: max_final_step, max_rmse): the ICP converged, the residual is bounded
+    h->last_final_step[c] = st.last_step;
+    if (out_ok)
+      out_ok[c] = st.ok && !(max_rmse > 0.f && !(rmse <= max_rmse)) && !(max_final_step > 0.f && !(st.last_step <= max_final_step));
   }
   return GLOC_OK;
 }
@@ -367,7 +374,8 @@ int run_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_params*
   GLOC_TRY(enqueue_jobs(h, jh, prm));
   std::vector<size_t> n_src(jh.size());
   for (size_t c = 0; c < jh.size(); ++c) n_src[c] = jh[c].src.n;
-  return collect_jobs(h, (uint32_t)jh.size(), n_src.data(), prm->max_rmse, out_T, out_rmse, out_inliers, out_ok);
+  return collect_jobs(h, (uint32_t)jh.size(), n_src.data(), prm->max_rmse, prm->icp_iters ? prm->max_final_step : 0.f, out_T,
+                      out_rmse, out_inliers, out_ok);
 }
 
 // Every entry point that runs jobs on the handle's workspaces (enqueue_jobs / launch_nn: pinned staging, job table,
@@ -446,6 +454,7 @@ void gloc_reg_default_params(gloc_reg_params* p) {
   p->seed = 1234;
   p->ransac_confidence = 0.99f;  // cv::estimateAffinePartial2D's default, used by the reference
   p->max_rmse = 0.f;
+  p->max_final_step = 0.04f;  // the ICP must have converged (see the header)
 }
 
 int gloc_reg_create(int device, gloc_reg** out) {
@@ -668,6 +677,7 @@ int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_
     for (int i = 0; i < 16; ++i) P.def_T[16 * o + i] = init_T ? init_T[16 * o + i] : ((i % 5 == 0) ? 1.f : 0.f);
   P.total = total;
   P.max_rmse = params->max_rmse;
+  P.max_final_step = params->icp_iters ? params->max_final_step : 0.f;
   GLOC_TRY(enqueue_jobs(h, jh, params));
   P.active = true;
   return GLOC_OK;
@@ -689,7 +699,7 @@ int gloc_reg_batch_multi_end(gloc_reg* h, float* out_T, float* out_rmse, uint32_
   std::vector<float> T(16 * std::max<size_t>(nj, 1)), rm(std::max<size_t>(nj, 1));
   std::vector<uint32_t> inl(std::max<size_t>(nj, 1));
   std::vector<int> ok(std::max<size_t>(nj, 1));
-  GLOC_TRY(collect_jobs(h, (uint32_t)nj, P.n_src.data(), P.max_rmse, T.data(), rm.data(), inl.data(), ok.data()));
+  GLOC_TRY(collect_jobs(h, (uint32_t)nj, P.n_src.data(), P.max_rmse, P.max_final_step, T.data(), rm.data(), inl.data(), ok.data()));
   for (size_t j = 0; j < nj; ++j) {
     const size_t o = P.slot[j];
     std::copy(T.begin() + 16 * j, T.begin() + 16 * (j + 1), out_T + 16 * o);
@@ -794,6 +804,13 @@ int gloc_reg_batch_ids(gloc_reg* h, uint32_t q_scan_id, const uint32_t* cand_sca
       GLOC_REQUIRE(cand_scan_ids[c] != 0xFFFFFFFFu, GLOC_ERR_INVALID, "unknown scan id %u", cand_scan_ids[c]);
   return gloc_reg_batch_multi(h, 1, &q_scan_id, cand_scan_ids, n_cand, cand_stream_ids, init_T, params, out_T,
                               out_rmse, out_inliers, out_ok);
+}
+
+int gloc_reg_final_steps(gloc_reg* h, float* out, size_t n) {
+  GLOC_REQUIRE(h && (out || !n), GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(n <= h->last_final_step.size(), GLOC_ERR_INVALID, "the last batch had %zu jobs", h->last_final_step.size());
+  std::copy(h->last_final_step.begin(), h->last_final_step.begin() + n, out);
+  return GLOC_OK;
 }
 
 int gloc_reg_select_first_ok(const int* ok, size_t n_cand) {

@@ -90,6 +90,8 @@ struct CandState {
   double sum_d2;      // of the last S1 pass
   uint32_t niters;    // RANSAC: iterations still allowed (adaptive stop), starts at ransac_iters
   int ransac_done;
+  float last_step;    // RMS displacement of the matched points by the last ICP update (gloc_reg_params.max_final_step)
+  float pad_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -541,10 +543,10 @@ __global__ __launch_bounds__(64) void ransac_scan_kernel(const uint32_t* __restr
 // culled search accumulates in its own epilogue): source moved by Tf on the fly, targets via corr;
 // optional gate d2 < gate2 on the pair distance.  MODE 1 (RANSAC refit): pre-gathered pairs, gate =
 // inlier of states[job].bestRt.  Each work-group writes ACC_NV partial sums
-// (n, sp[3], sq[3], spq[9], sum_d2_all) -- reduced in a fixed order by solve_kernel.
+// (n, sp[3], sq[3], spq[9], sum_d2_all, spp = sum |p|^2) -- reduced in a fixed order by solve_kernel.
 constexpr int ACC_THREADS = 256;
 constexpr int ACC_PER_BLOCK = 2048;
-constexpr int ACC_NV = 17;
+constexpr int ACC_NV = 18;
 
 template <int MODE>
 __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
@@ -598,6 +600,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
 #pragma unroll
         for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += P[a] * Q[b];
       }
+      v[17] += (P[0] * P[0] + P[1] * P[1]) + P[2] * P[2];
     }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -617,13 +620,14 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
 
 // K6b.  One work-group per job: the job's partials (one per source group when the culled search
 // accumulated them, PER_GROUP, else one per ACC_PER_BLOCK slots) are summed in a fixed order --
-// thread (k, r) takes partials r, r + 60, ... of moment k, thread k then the 60 sub-sums in order --
+// thread (k, r) takes partials r, r + 56, ... of moment k, thread k then the 56 sub-sums in order --
 // thread 0 solves Kabsch and composes.
 // MODE 0 (ICP step): T <- dT * T.   MODE 1 (RANSAC refit): T <- T_r * T0, falling back to the
 // un-refitted best hypothesis when fewer than 3 inliers, or to T0 when no hypothesis was valid.
-constexpr int WAVE_PARTIAL_FLOATS = 20;  // the culled search's partial: 17 fp32 moments about the wave's centre + the centre
-constexpr int SOLVE_R = 60;
+constexpr int WAVE_PARTIAL_FLOATS = 21;  // the culled search's partial: 17 fp32 moments about the wave's centre, the centre, sum |p'|^2
+constexpr int SOLVE_R = 56;  // (56 x 18 moments = 1008 threads)
 constexpr int SOLVE_THREADS = 1024;
+static_assert(SOLVE_R * ACC_NV <= SOLVE_THREADS, "a thread per (stride class, moment)");
 
 template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,
@@ -715,9 +719,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
     for (uint32_t g = (uint32_t)tid; g < cnt; g += SOLVE_THREADS) {
       typedef float f32x2_ __attribute__((ext_vector_type(2)));
       const f32x2_* f2 = reinterpret_cast<const f32x2_*>(base + (size_t)g * (2 * ACC_NV));  // (a slot is 136 B: 8-byte aligned)
-      float f[WAVE_PARTIAL_FLOATS];
+      float f[WAVE_PARTIAL_FLOATS + 1];
 #pragma unroll
-      for (int i = 0; i < WAVE_PARTIAL_FLOATS / 2; ++i) {
+      for (int i = 0; i < (WAVE_PARTIAL_FLOATS + 1) / 2; ++i) {
         const f32x2_ t = f2[i];
         f[2 * i] = t.x;
         f[2 * i + 1] = t.y;
@@ -726,6 +730,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
       const double c[3] = {(double)f[17], (double)f[18], (double)f[19]};
       v[0] += n;
       v[16] += (double)f[16];
+      // sum |p|^2 = sum |p'|^2 + 2 c . sum p' + n |c|^2
+      v[17] += ((double)f[20] + 2.0 * ((c[0] * (double)f[1] + c[1] * (double)f[2]) + c[2] * (double)f[3])) +
+               n * ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         v[1 + a] += (double)f[1 + a] + n * c[a];
@@ -805,6 +812,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) M[3 * a + b] = v[7 + 3 * a + b] - cnt * (pbar[a] * qbar[b]);
     kabsch_from_cov(M, pbar, qbar, Rd, td);
+    if (MODE == 0) {
+      // how far this update moves the points it was fitted on, RMS: |R c + t - c|^2 + (|R - I|_F^2 / 2) tr cov
+      // (oracle/reg_oracle.c: kabsch_pairs) -- the ICP's convergence measure, read by the host after the last pass
+      double s2 = v[17] * inv - ((pbar[0] * pbar[0] + pbar[1] * pbar[1]) + pbar[2] * pbar[2]), dc2 = 0.0, f2 = 0.0;
+      if (s2 < 0.0) s2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double d = (((Rd[3 * a + 0] * pbar[0] + Rd[3 * a + 1] * pbar[1]) + Rd[3 * a + 2] * pbar[2]) + td[a]) - pbar[a];
+        dc2 += d * d;
+        for (int b = 0; b < 3; ++b) {
+          const double e = Rd[3 * a + b] - (a == b ? 1.0 : 0.0);
+          f2 += e * e;
+        }
+      }
+      st.last_step = (float)sqrt(dc2 + 0.5 * f2 * s2);
+    }
   }
   // (Rd,td) o (Td)
   double Rn[9], tn[3];

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLOC3D_ABI_VERSION 3
+#define GLOC3D_ABI_VERSION 4
 
 enum {
   GLOC_OK = 0,
@@ -189,9 +189,18 @@ typedef struct gloc_reg_params {
                              transform, the analogue of the reference's |1 - scale| < 0.1
                              (loop_detector.cpp:268-272): the RANSAC inlier ratio at 0.6 m alone cannot
                              tell two scenes apart that share a ground plane.  <= 0: off (default) */
+  float max_final_step;    /* > 0 (default 0.04 m; needs icp_iters > 0): a candidate is ok only if, in addition, the ICP
+                             has CONVERGED: the RMS displacement its last update gives the matched points --
+                             sqrt(|R c + t - c|^2 + |R - I|_F^2 / 2 * tr cov), c and cov the centroid and covariance
+                             of those points -- is <= this.  The default plausibility check of the 3-D stage, in
+                             the role of the reference's |1 - scale| < 0.1 on its 2-D fit
+                             (loop_detector.cpp:268-272) and of pcl::IterativeClosestPoint::hasConverged(), which
+                             the reference does not consult: an ICP still creeping after its last pass (a
+                             different-world candidate moves 5 - 30 cm per pass for ever, a same-world one that
+                             started metres off is half-way) has not found the pose.  <= 0: off */
 } gloc_reg_params;
 
-/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99). */
+/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99, max_final_step 0.04). */
 void gloc_reg_default_params(gloc_reg_params* p);
 
 int gloc_reg_create(int device, gloc_reg** out);
@@ -342,6 +351,9 @@ int gloc_reg_first_success_multi(gloc_reg* h, size_t n_queries, const uint32_t* 
  * (registration/global_localization.cpp:519-572 stops at the first match()==true).
  * Returns the rank or -1. */
 int gloc_reg_select_first_ok(const int* ok, size_t n_cand);
+/* The convergence measure of the last batch the handle returned: per job, in job order, the RMS displacement of the
+ * last ICP update (what gloc_reg_params.max_final_step is compared with; 0 for a job without an ICP pass). */
+int gloc_reg_final_steps(gloc_reg* h, float* out, size_t n_jobs);
 
 /* Building blocks, exposed for tests and for callers that drive ICP themselves (host buffers). */
 int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tgt_xyz,

@@ -33,6 +33,7 @@ class RegParams(C.Structure):
         ("seed", C.c_uint64),
         ("ransac_confidence", C.c_float),
         ("max_rmse", C.c_float),
+        ("max_final_step", C.c_float),
     ]
 
 
@@ -104,6 +105,8 @@ def lib():
                                         C.POINTER(RegParams), C.c_uint32, C.c_void_p, _f32p,
                                         C.POINTER(C.c_float), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.oracle_reg_one_nn_step.restype = None
+        L.oracle_reg_one_nn_step.argtypes = L.oracle_reg_one_nn.argtypes + [C.POINTER(C.c_float)]
         L.oracle_reg_many_mt.argtypes = [_f32p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                          C.c_size_t, C.POINTER(RegParams), C.c_void_p, C.c_void_p, C.c_int,
                                          _f32p, _f32p, _u32p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
@@ -253,13 +256,13 @@ def _ref_nn_backend():
 
 def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=3000, inlier_thresh=0.6,
                 min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
-                max_rmse=0.0):
+                max_rmse=0.0, max_final_step=0.04):
     """Candidates of one query registered on `threads` host threads (bench.py's all-cores leg)."""
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     ts = [np.ascontiguousarray(t, np.float32).reshape(-1, 3) for t in tgts]
     n = len(ts)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
-                    ransac_confidence, max_rmse)
+                    ransac_confidence, max_rmse, max_final_step)
     ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in ts])
     cnts = (C.c_size_t * n)(*[t.shape[0] for t in ts])
     T = np.empty((n, 16), np.float32)
@@ -274,24 +277,24 @@ def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=30
 
 def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
             min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
-            ref_nn=False, max_rmse=0.0):
+            ref_nn=False, max_rmse=0.0, max_final_step=0.04):
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,
-                    ransac_confidence, max_rmse)
+                    ransac_confidence, max_rmse, max_final_step)
     T = np.empty(16, np.float32)
-    rmse, inl, hyp, ok = C.c_float(), C.c_uint32(), C.c_uint32(), C.c_int()
+    rmse, inl, hyp, ok, step = C.c_float(), C.c_uint32(), C.c_uint32(), C.c_int(), C.c_float()
     if init_T is not None:
         it = np.ascontiguousarray(init_T, np.float32).reshape(16)
         itp = it.ctypes.data_as(C.c_void_p)
     else:
         itp = None
     be = _ref_nn_backend() if ref_nn else None
-    lib().oracle_reg_one_nn(src, src.shape[0], tgt, tgt.shape[0], itp, C.byref(prm), cand_id,
-                            C.cast(C.byref(be), C.c_void_p) if be is not None else None, T,
-                            C.byref(rmse), C.byref(inl), C.byref(hyp), C.byref(ok))
+    lib().oracle_reg_one_nn_step(src, src.shape[0], tgt, tgt.shape[0], itp, C.byref(prm), cand_id,
+                                 C.cast(C.byref(be), C.c_void_p) if be is not None else None, T,
+                                 C.byref(rmse), C.byref(inl), C.byref(hyp), C.byref(ok), C.byref(step))
     return dict(T=T.reshape(4, 4), rmse=rmse.value, inliers=inl.value, best_hyp=hyp.value,
-                ok=bool(ok.value))
+                ok=bool(ok.value), final_step=step.value)
 
 
 def pose_error(T_gt, T_est):

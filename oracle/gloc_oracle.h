@@ -76,6 +76,8 @@ typedef struct oracle_reg_params {
   uint64_t seed;
   float ransac_confidence;  /* adaptive stop (OpenCV RANSAC default 0.99); <=0 or >=1: off */
   float max_rmse;           /* > 0: ok additionally requires the final rmse <= this; <= 0: off */
+  float max_final_step;     /* > 0: ok additionally requires the ICP to have converged: RMS displacement of the matched
+                               points by its last update <= this (metres); <= 0: off */
 } oracle_reg_params;
 
 /* Iterations after which a 3-point RANSAC reaches `conf` given `inl` of `n` inliers: the smallest k
@@ -137,6 +139,11 @@ void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz,
                        const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
                        const oracle_nn_backend* nn, float* out_T, float* out_rmse,
                        uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok);
+/* the same, also returning the RMS displacement of the last ICP update (what max_final_step is compared with) */
+void oracle_reg_one_nn_step(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                       const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                       const oracle_nn_backend* nn, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok, float* out_final_step);
 /* n_cand candidates of one query over `threads` pthreads (independent work; cand_ids NULL: 0..). */
 void oracle_reg_many_mt(const float* src_xyz, size_t n_src, const float* const* tgt_xyz,
                         const size_t* n_tgt, size_t n_cand, const oracle_reg_params* prm,

@@ -382,10 +382,14 @@ uint32_t oracle_ransac_needed_iters(uint32_t inl, uint32_t n, float conf, uint32
 
 /* Kabsch over pairs (src_i, tgt_corr[i]) with optional gate d2(R0 src_i + t0, tgt) < gate2
  * (gate2 <= 0: all pairs).  Raw moments accumulated in fp64, sequentially. */
+/* step_rms (may be NULL): the RMS displacement this update gives the points it was fitted on -- with c their centroid,
+ * s2 the trace of their covariance: |R c + t - c|^2 + (|R - I|_F^2 / 2) s2 (the second term is the rotation's
+ * 2 (1 - cos theta) times the points' mean squared distance from c: exact for points in the plane of the rotation,
+ * an upper bound otherwise).  The convergence measure of the ICP (gloc_reg_params.max_final_step). */
 static uint32_t kabsch_pairs(const float* src, const float* tgt, const uint32_t* corr, uint32_t n,
                              const float* gateR, const float* gatet, float gate2, double R[9],
-                             double t[3]) {
-  double sp[3] = {0, 0, 0}, sq[3] = {0, 0, 0}, spq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                             double t[3], double* step_rms) {
+  double sp[3] = {0, 0, 0}, sq[3] = {0, 0, 0}, spq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, spp = 0.0;
   uint32_t cnt = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const float* p = src + 3 * (size_t)i;
@@ -401,7 +405,9 @@ static uint32_t kabsch_pairs(const float* src, const float* tgt, const uint32_t*
       sq[a] += (double)q[a];
       for (int b = 0; b < 3; ++b) spq[3 * a + b] += (double)p[a] * (double)q[b];
     }
+    spp += ((double)p[0] * (double)p[0] + (double)p[1] * (double)p[1]) + (double)p[2] * (double)p[2];
   }
+  if (step_rms) *step_rms = 0.0;
   if (cnt < 3) return cnt;
   const double inv = 1.0 / (double)cnt;
   double pbar[3], qbar[3], M[9];
@@ -412,6 +418,19 @@ static uint32_t kabsch_pairs(const float* src, const float* tgt, const uint32_t*
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) M[3 * a + b] = spq[3 * a + b] - (double)cnt * (pbar[a] * qbar[b]);
   oracle_kabsch_from_cov(M, pbar, qbar, R, t);
+  if (step_rms) {
+    double s2 = spp * inv - ((pbar[0] * pbar[0] + pbar[1] * pbar[1]) + pbar[2] * pbar[2]), dc2 = 0.0, f2 = 0.0;
+    if (s2 < 0.0) s2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double d = (((R[3 * a + 0] * pbar[0] + R[3 * a + 1] * pbar[1]) + R[3 * a + 2] * pbar[2]) + t[a]) - pbar[a];
+      dc2 += d * d;
+      for (int b = 0; b < 3; ++b) {
+        const double e = R[3 * a + b] - (a == b ? 1.0 : 0.0);
+        f2 += e * e;
+      }
+    }
+    *step_rms = sqrt(dc2 + 0.5 * f2 * s2);
+  }
   return cnt;
 }
 
@@ -424,10 +443,10 @@ static void compose(const double Ra[9], const double ta[3], const double Rb[9], 
   }
 }
 
-void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
-                       const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
-                       const oracle_nn_backend* nn, float* out_T, float* out_rmse,
-                       uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok) {
+void oracle_reg_one_nn_step(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                            const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                            const oracle_nn_backend* nn, float* out_T, float* out_rmse,
+                            uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok, float* out_final_step) {
   const uint32_t n = (uint32_t)n_src;
   /* a search structure over the (fixed) target, built once and queried every pass -- what PCL's ICP
    * does with its KdTreeFLANN (global_registration.cpp:241-247) */
@@ -497,7 +516,7 @@ void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz,
       /* refit on the inliers of the best hypothesis, then T <- T_r * T0 */
       double Rr[9], tr[3], Rn[9], tn[3];
       const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
-      const uint32_t used = kabsch_pairs(moved, tgt_xyz, corr, n, bR, bt, thr2, Rr, tr);
+      const uint32_t used = kabsch_pairs(moved, tgt_xyz, corr, n, bR, bt, thr2, Rr, tr, NULL);
       if (used < 3) {
         for (int i = 0; i < 9; ++i) Rr[i] = (double)bR[i];
         for (int i = 0; i < 3; ++i) tr[i] = (double)bt[i];
@@ -509,11 +528,12 @@ void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz,
   }
 
   const float gate2 = prm->max_corr_dist > 0.0f ? prm->max_corr_dist * prm->max_corr_dist : 0.0f;
+  double last_step = 0.0; /* of the last ICP update (0 without one) */
   static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
   for (uint32_t it = 0; it < prm->icp_iters && n >= 3 && n_tgt >= 1; ++it) {
     MOVE_AND_MATCH();
     double Rd[9], td[3], Rn[9], tn[3];
-    const uint32_t used = kabsch_pairs(moved, tgt_xyz, corr, n, I9, Z3, gate2, Rd, td);
+    const uint32_t used = kabsch_pairs(moved, tgt_xyz, corr, n, I9, Z3, gate2, Rd, td, &last_step);
     if (used < 3) break;
     compose(Rd, td, Rc, tc, Rn, tn);
     memcpy(Rc, Rn, sizeof(Rn));
@@ -529,13 +549,27 @@ void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz,
   if (out_rmse) *out_rmse = rmse;
   if (out_inliers) *out_inliers = best_inl;
   if (out_best_hyp) *out_best_hyp = best_h;
-  if (out_ok) *out_ok = ok && !(prm->max_rmse > 0.0f && !(rmse <= prm->max_rmse));
+  if (out_final_step) *out_final_step = (float)last_step;
+  /* plausibility of the estimate (the analogue of the reference's |1 - scale| < 0.1, loop_detector.cpp:268-272):
+   * the ICP must have CONVERGED -- its last update moved the scan by no more than max_final_step (RMS over the
+   * matched points) -- and, optionally, the final rmse is bounded */
+  if (out_ok)
+    *out_ok = ok && !(prm->max_rmse > 0.0f && !(rmse <= prm->max_rmse)) &&
+              !(prm->max_final_step > 0.0f && prm->icp_iters > 0 && !((float)last_step <= prm->max_final_step));
   free(moved);
   free(corr);
   free(d2);
   if (nn_handle) nn->free_(nn_handle);
 #undef CAST_T
 #undef MOVE_AND_MATCH
+}
+
+void oracle_reg_one_nn(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                       const float* init_T, const oracle_reg_params* prm, uint32_t cand_id,
+                       const oracle_nn_backend* nn, float* out_T, float* out_rmse,
+                       uint32_t* out_inliers, uint32_t* out_best_hyp, int* out_ok) {
+  oracle_reg_one_nn_step(src_xyz, n_src, tgt_xyz, n_tgt, init_T, prm, cand_id, nn, out_T, out_rmse, out_inliers,
+                         out_best_hyp, out_ok, NULL);
 }
 
 void oracle_reg_one(const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,

@@ -85,7 +85,7 @@ def needed_iters(inl, n, conf, cap):
 
 
 def register(src, tgt, cand_id=0, ransac_iters=3000, inlier_thresh=0.6, min_inlier_ratio=0.3, icp_iters=30, seed=1234,
-             confidence=0.99, max_rmse=0.0, init_T=None):
+             confidence=0.99, max_rmse=0.0, init_T=None, max_final_step=0.04):
     src, tgt = np.ascontiguousarray(src, F), np.ascontiguousarray(tgt, F)
     n = len(src)
     tree = cKDTree(tgt.astype(np.float64))           # float32 coordinates are exact in float64
@@ -131,16 +131,25 @@ def register(src, tgt, cand_id=0, ransac_iters=3000, inlier_thresh=0.6, min_inli
             Tr = np.eye(4)
             Tr[:3, :3], Tr[:3, 3] = R, t
             T = Tr @ T
+    final_step = 0.0
     for _ in range(icp_iters):
         moved, j, d2 = match(T)
-        R, t = kabsch(moved.astype(np.float64), tgt[j].astype(np.float64))
+        P = moved.astype(np.float64)
+        R, t = kabsch(P, tgt[j].astype(np.float64))
+        # convergence measure of the specification: RMS displacement of the matched points by this update, as
+        # |R c + t - c|^2 + |R - I|_F^2 / 2 * tr cov(P)
+        c = P.mean(0)
+        final_step = float(np.sqrt(np.sum((R @ c + t - c) ** 2) + 0.5 * np.sum((R - np.eye(3)) ** 2) * ((P - c) ** 2).sum(1).mean()))
         Td = np.eye(4)
         Td[:3, :3], Td[:3, 3] = R, t
         T = Td @ T
     rmse = float(np.sqrt(d2.astype(np.float64).sum() / n)) if n else 0.0
     if max_rmse > 0 and not rmse <= max_rmse:
         ok = False
-    return dict(T=T.astype(F), rmse=rmse, inliers=best_inl, best_hyp=-1 if best_h is None else best_h, ok=bool(ok))
+    if max_final_step > 0 and icp_iters > 0 and not final_step <= max_final_step:
+        ok = False                                    # the ICP has not converged
+    return dict(T=T.astype(F), rmse=rmse, inliers=best_inl, best_hyp=-1 if best_h is None else best_h, ok=bool(ok),
+                final_step=final_step)
 
 
 def cases():
@@ -179,8 +188,8 @@ if __name__ == "__main__":
     out = {}
     for name, s, t, kw in cases() + [full_size_case()]:
         r = register(s, t, **kw)
-        print(name, "inliers", r["inliers"], "hyp", r["best_hyp"], "rmse", round(r["rmse"], 4), "ok", r["ok"])
+        print(name, "inliers", r["inliers"], "hyp", r["best_hyp"], "rmse", round(r["rmse"], 4), "ok", r["ok"], "final step", round(r["final_step"], 5))
         out[name + "_T"] = r["T"]
-        out[name + "_meta"] = np.array([r["rmse"], r["inliers"], r["best_hyp"], float(r["ok"])], np.float64)
+        out[name + "_meta"] = np.array([r["rmse"], r["inliers"], r["best_hyp"], float(r["ok"]), r["final_step"]], np.float64)
         out[name + "_crc"] = np.array([crc(s), crc(t)], np.uint64)
     np.savez(os.path.join(HERE, "reg_crosscheck.npz"), **out)

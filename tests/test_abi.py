@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(capi):
 
 def test_abi_version_and_defaults(capi):
     L = capi.lib()
-    assert L.gloc_abi_version() == 3
+    assert L.gloc_abi_version() == 4
     p = capi.default_reg_params()
     # constants mirrored from the reference: loop_detector.cpp:257, global_registration.cpp:242
     assert p.ransac_iters == 3000 and abs(p.inlier_thresh - 0.6) < 1e-7 and p.icp_iters == 30

@@ -28,7 +28,8 @@ def test_oracle_agrees_with_the_independent_statement(oracle_mod):
         o = oracle_mod.reg_one(s, t, init_T=kw.get("init_T"), cand_id=kw["cand_id"], ransac_iters=kw["ransac_iters"],
                                icp_iters=kw["icp_iters"], ransac_confidence=kw.get("confidence", 0.99),
                                max_rmse=kw.get("max_rmse", 0.0))
-        T, (rmse, inl, hyp, ok) = g[name + "_T"], g[name + "_meta"]
+        T, (rmse, inl, hyp, ok, fstep) = g[name + "_T"], g[name + "_meta"]
+        assert abs(o["final_step"] - fstep) < 2e-4 * max(1.0, fstep / 0.04), name   # the convergence measure the default gate reads
         assert np.abs(o["T"][:3, 3] - T[:3, 3]).max() < 1e-4, name        # north_star's tolerance: 1e-4 m / 1e-4 rad
         assert _rot_angle(o["T"][:3, :3], T[:3, :3]) < 1e-4, name
         assert abs(o["rmse"] - rmse) < 1e-4 and o["ok"] == bool(ok), name
@@ -45,7 +46,7 @@ def test_the_fixture_is_what_the_generator_makes():
 
 
 def _check(o, g, name):
-    T, (rmse, inl, hyp, ok) = g[name + "_T"], g[name + "_meta"]
+    T, (rmse, inl, hyp, ok, fstep) = g[name + "_T"], g[name + "_meta"]
     assert np.abs(np.asarray(o["T"])[:3, 3] - T[:3, 3]).max() < 1e-4, name
     assert _rot_angle(np.asarray(o["T"])[:3, :3], T[:3, :3]) < 1e-4, name
     assert abs(float(o["rmse"]) - rmse) < 1e-4 and bool(o["ok"]) == bool(ok), name

@@ -86,7 +86,8 @@ def test_full_size_matches_the_independent_statement(reg, capi, scans):
     assert (g["full_size_crc"] == np.array([mc.crc(scans["B"]), mc.crc(scans["A"])], np.uint64)).all()   # the fixture's inputs
     prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
     out = reg.batch(scans["B"], [scans["A"]], params=prm, stream_ids=[0])
-    T, (rmse, inl, hyp, ok) = g["full_size_T"], g["full_size_meta"]
+    T, (rmse, inl, hyp, ok, fstep) = g["full_size_T"], g["full_size_meta"]
+    assert abs(float(reg.final_steps(1)[0]) - fstep) < 2e-4
     assert np.abs(out["T"][0][:3, 3] - T[:3, 3]).max() < POSE_TOL_M
     assert _rot_angle(out["T"][0][:3, :3], T[:3, :3]) < POSE_TOL_RAD
     assert abs(out["rmse"][0] - rmse) < 1e-4 and bool(out["ok"][0]) == bool(ok)
@@ -270,13 +271,39 @@ def test_max_rmse_acceptance(reg, capi, oracle_mod, scans):
     q = np.ascontiguousarray(scans["B"][::16])
     cands = [np.ascontiguousarray(scans["A"][::4]), np.ascontiguousarray(scans["C"][::4])]
     for max_rmse, expect in ((0.0, None), (1.0, [True, False])):
-        prm = capi.default_reg_params(ransac_iters=300, icp_iters=8, max_rmse=max_rmse)
+        prm = capi.default_reg_params(ransac_iters=300, icp_iters=8, max_rmse=max_rmse, max_final_step=0.0)   # (this gate alone)
         g = reg.batch(q, cands, params=prm)
-        o = [oracle_mod.reg_one(q, c, cand_id=i, ransac_iters=300, icp_iters=8, max_rmse=max_rmse)
+        o = [oracle_mod.reg_one(q, c, cand_id=i, ransac_iters=300, icp_iters=8, max_rmse=max_rmse, max_final_step=0.0)
              for i, c in enumerate(cands)]
         assert [bool(x) for x in g["ok"]] == [x["ok"] for x in o]
         if expect is not None:
             assert [bool(x) for x in g["ok"]] == expect
+
+
+def test_convergence_gate_matches_oracle(reg, capi, oracle_mod, scans):
+    """gloc_reg_params.max_final_step (default 0.04 m): ok additionally requires that the last ICP update moved the
+    matched points by no more than that, RMS -- the ICP has converged.  The measure itself equals the oracle's
+    (fp64 moments on both sides), so does ok at thresholds on either side of it; a different scene -- whose ICP keeps
+    creeping -- is rejected where the same place, given passes enough, is accepted; without ICP passes the gate is off."""
+    q = np.ascontiguousarray(scans["B"][::16])
+    cands = [np.ascontiguousarray(scans["A"][::4]), np.ascontiguousarray(scans["C"][::4])]
+    for iters in (3, 12, 40):
+        o0 = [oracle_mod.reg_one(q, c, cand_id=i, ransac_iters=300, icp_iters=iters, max_final_step=0.0) for i, c in enumerate(cands)]
+        g0 = reg.batch(q, cands, params=capi.default_reg_params(ransac_iters=300, icp_iters=iters, max_final_step=0.0))
+        steps = reg.final_steps(2)
+        for c in range(2):
+            assert abs(steps[c] - o0[c]["final_step"]) < 1e-5 + 1e-3 * o0[c]["final_step"], (iters, c, steps[c], o0[c]["final_step"])
+        for thr in (0.5 * float(steps[0]), 2.0 * float(steps[0]) + 1e-6, 0.04):
+            if min(abs(thr - float(s_)) for s_ in steps) < 1e-4:
+                continue                                                   # (too close to call in fp32)
+            g = reg.batch(q, cands, params=capi.default_reg_params(ransac_iters=300, icp_iters=iters, max_final_step=thr))
+            o = [oracle_mod.reg_one(q, c, cand_id=i, ransac_iters=300, icp_iters=iters, max_final_step=thr) for i, c in enumerate(cands)]
+            assert [bool(x) for x in g["ok"]] == [x["ok"] for x in o], (iters, thr)
+            assert [bool(x) for x in g["ok"]] == [bool(g0["ok"][c]) and steps[c] <= thr for c in range(2)], (iters, thr)
+            assert (bits(g["T"]) == bits(g0["T"])).all()                 # a gate changes ok, never a pose
+    assert steps[0] < 0.01 < steps[1]              # 40 passes: the same place has converged, the other scene never does
+    g = reg.batch(q, cands, params=capi.default_reg_params(ransac_iters=300, icp_iters=0))      # no ICP: nothing to converge
+    assert bool(g["ok"][0]) and (reg.final_steps(2) == 0).all()
 
 
 def test_scan_store_ids_equal_host_buffers(reg, capi, scans):
@@ -625,7 +652,7 @@ def test_first_success_equals_select_over_the_full_batch(capi, scans):
           store.add(np.ascontiguousarray(Cc[3::25]))]
     a0, a1, c0 = (store.add(np.ascontiguousarray(x)) for x in (A[::6], A[1::7], Cc[::6]))
     cand = np.array([[c0, a0, a1], [c0, capi.NO_SCAN, a1], [a0, a1, capi.NO_SCAN]], np.uint32)
-    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6, max_rmse=1.0)
+    prm = capi.default_reg_params(ransac_iters=300, icp_iters=6, max_rmse=1.0, max_final_step=0.0)   # (6 passes on thinned clouds: not converged)
     r = capi.Registrar(store=store)
     full = r.batch_multi(qs, cand, params=prm)
     fs = r.first_success_multi(qs, cand, params=prm)

@@ -26,6 +26,7 @@ struct gloc_reg {
   DevBuf jobs, states;           // Job[], CandState[]
   DevBuf corr, d2, pairs;        // [job][ld]
   DevBuf Rt, valid, inliers;     // RANSAC hypotheses
+  DevBuf alive;                  // all-hypotheses RANSAC: [job][H] list of the hypotheses still in the race + [job] counts
   DevBuf partials;               // [job][n_part][ACC_NV] fp64
   DevBuf export_idx, export_d2;  // gloc_reg_nn: results in the caller's index space
   DevBuf counters;               // pairs evaluated by the culled search: NN_STAT_SLOTS partial counts (profiling only)
@@ -293,9 +294,28 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
       ProfScope ps(h->prof, "ransac_score", s);
       // hypotheses per work-group: 16 / 64 (its four waves share them and split every staged tile) or thread <-> hypothesis
       const uint32_t hpb = len <= 16 ? 16u : (len <= 64 ? 64u : 256u);
-      hipLaunchKernelGGL(ransac_score_kernel, dim3((len + hpb - 1) / hpb, cchunks, n_jobs), dim3(256), 0, s,
-                         h->pairs.as<f32x4>(), bd.ld, h->jobs.as<Job>(), H, h0, hpb, h->Rt.as<float>(),
-                         h->valid.as<uint32_t>(), thr2, st, h->inliers.as<uint32_t>());
+      static const unsigned parts_env = getenv("GLOC3D_RANSAC_PARTS") ? (unsigned)atoi(getenv("GLOC3D_RANSAC_PARTS")) : 0u;  // developer override
+      const unsigned NP = parts_env ? parts_env : 8u;
+      if (!adaptive && ph > 0 && len >= 512 && cchunks >= NP) {
+        // every hypothesis scored, not every pair of every hypothesis: an eighth of the pairs at a time, the hypotheses
+        // that can no longer beat the first phase's winner dropped in between (ransac_alive_kernel)
+        GLOC_TRY(h->alive.ensure(sizeof(uint32_t) * ((size_t)H + 1) * n_jobs, s));
+        uint32_t* a_idx = h->alive.as<uint32_t>();
+        uint32_t* a_cnt = a_idx + (size_t)H * n_jobs;
+        for (unsigned q = 0; q < NP; ++q) {
+          const unsigned c0 = q * cchunks / NP, c1 = (q + 1) * cchunks / NP;
+          hipLaunchKernelGGL(ransac_alive_kernel, dim3(n_jobs), dim3(1024), 0, s, h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(),
+                             H, h0, h1, h->jobs.as<Job>(), h->states.as<CandState>(), (uint32_t)(c0 * SC_CHUNK), a_idx, a_cnt);
+          hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, c1 - c0, n_jobs), dim3(256), 0, s,
+                             h->pairs.as<f32x4>(), bd.ld, h->jobs.as<Job>(), H, h0, 256u, h->Rt.as<float>(),
+                             h->valid.as<uint32_t>(), thr2, st, h->inliers.as<uint32_t>(), a_idx, a_cnt, (uint32_t)c0);
+        }
+      } else {
+        hipLaunchKernelGGL(ransac_score_kernel, dim3((len + hpb - 1) / hpb, cchunks, n_jobs), dim3(256), 0, s,
+                           h->pairs.as<f32x4>(), bd.ld, h->jobs.as<Job>(), H, h0, hpb, h->Rt.as<float>(),
+                           h->valid.as<uint32_t>(), thr2, st, h->inliers.as<uint32_t>(), (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, 0u);
+      }
       if (ph + 1 < n_ph)
         hipLaunchKernelGGL(ransac_scan_kernel<false>, dim3(n_jobs), dim3(64), 0, s, h->inliers.as<uint32_t>(),
                            h->valid.as<uint32_t>(), h->Rt.as<float>(), H, h0, h1, h->jobs.as<Job>(), prm->ransac_confidence,
@@ -511,7 +531,7 @@ int gloc_reg_destroy(gloc_reg* h) {
   if (h->own_store) (void)gloc_scan_store_destroy(h->own_store);
   h->prof.destroy();
   for (DevBuf* b : {&h->jobs, &h->states, &h->corr, &h->d2, &h->pairs, &h->Rt, &h->valid, &h->inliers,
-                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff})
+                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff, &h->alive})
     b->release();
   if (h->done_ev) (void)hipEventDestroy(h->done_ev);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -906,7 +926,7 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
                      h->jobs.as<Job>(), n_hyp, 0u, 256u /* thread <-> hypothesis */, h->Rt.as<float>(),
                      h->valid.as<uint32_t>(), inlier_thresh * inlier_thresh, (const CandState*)nullptr,
-                     h->inliers.as<uint32_t>());
+                     h->inliers.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipMemcpyAsync(out_Rt, h->Rt.p, sizeof(float) * 12 * (size_t)n_hyp,
                           hipMemcpyDeviceToHost, s));

@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                                                            const uint32_t* __restrict__ valid,
                                                            float thr2,
                                                            const CandState* __restrict__ states,
-                                                           uint32_t* __restrict__ inliers) {
+                                                           uint32_t* __restrict__ inliers,
+                                                           const uint32_t* __restrict__ alive_idx /* [cand][n_hyp] or null */,
+                                                           const uint32_t* __restrict__ alive_cnt, uint32_t chunk0) {
   // staged pairs, two correspondences per entry, structure-of-arrays: (px0 px1 py0 py1)(pz0 pz1 qx0 qx1)(qy0 qy1 qz0 qz1)
   // so that one packed fp32 instruction moves / measures two correspondences.
   //
@@ -373,12 +375,19 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   const int cand = blockIdx.z;
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
   const uint32_t n = jobs[cand].n_src;
-  if (blockIdx.y * SC_CHUNK >= n) return;
+  const uint32_t chunk = blockIdx.y + chunk0;
+  if (chunk * SC_CHUNK >= n) return;
   // hyp_per_block = 256: thread <-> hypothesis.  64 / 16: the four waves share that many hypotheses, each thread taking
   // a quarter / a sixteenth of every staged tile (the first phases of the adaptive RANSAC need few hypotheses).
   const uint32_t sub = threadIdx.x / hyp_per_block, nsub = 256 / hyp_per_block;
-  const uint32_t h = h_begin + blockIdx.x * hyp_per_block + threadIdx.x % hyp_per_block;
-  const bool hv = h < n_hyp && h < h_begin + (blockIdx.x + 1) * hyp_per_block && valid[(size_t)cand * n_hyp + h];
+  uint32_t h = h_begin + blockIdx.x * hyp_per_block + threadIdx.x % hyp_per_block;
+  bool hv = h < n_hyp && h < h_begin + (blockIdx.x + 1) * hyp_per_block && valid[(size_t)cand * n_hyp + h];
+  if (alive_idx) {  // the hypotheses still in the race, compacted (ransac_alive_kernel): thread <-> list entry
+    const uint32_t na = alive_cnt[cand], e = blockIdx.x * hyp_per_block + threadIdx.x % hyp_per_block;
+    if (blockIdx.x * hyp_per_block >= na) return;  // (uniform over the work-group)
+    hv = e < na;
+    h = hv ? alive_idx[(size_t)cand * n_hyp + e] : 0u;
+  }
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = hv ? Rt[((size_t)cand * n_hyp + h) * 12 + i] : 0.f;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                           fabsf(T[6]) + fabsf(T[7]) + fabsf(T[8]));
   const float tmax = fmaxf(fmaxf(fabsf(T[9]), fabsf(T[10])), fabsf(T[11]));
   const float thr = sqrtf(thr2);
-  const uint32_t i0 = blockIdx.y * SC_CHUNK;
+  const uint32_t i0 = chunk * SC_CHUNK;
   const uint32_t i1 = (i0 + SC_CHUNK) < n ? (i0 + SC_CHUNK) : n;
   uint32_t cnt = 0;
   float* spf = reinterpret_cast<float*>(sp);
@@ -441,6 +450,44 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
     }
   }
   if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);
+}
+
+// K5b'.  Scoring EVERY hypothesis (ransac_confidence off: SURVEY App. B's wording of S2) without scoring every pair of
+// every hypothesis.  The pairs are scored a part (an eighth) at a time; before a part, a hypothesis whose count so far plus
+// all pairs still to come cannot exceed the best FULL count known (the winner of the first 256 hypotheses, which are
+// scored completely first) is out of the race -- it can neither win nor tie ahead of that winner, which has a smaller
+// index -- and the survivors are compacted into a list the scorer's threads map to.  Sound: the selected hypothesis and
+// its count are the every-pair scorer's (the counts of dropped hypotheses stay partial, below the winner's).
+// One work-group per candidate; the list keeps ascending order.
+__global__ __launch_bounds__(1024) void ransac_alive_kernel(const uint32_t* __restrict__ inliers,
+                                                            const uint32_t* __restrict__ valid, uint32_t n_hyp,
+                                                            uint32_t h0, uint32_t h1, const Job* __restrict__ jobs,
+                                                            const CandState* __restrict__ states, uint32_t first_pair,
+                                                            uint32_t* __restrict__ alive_idx, uint32_t* __restrict__ alive_cnt) {
+  __shared__ uint32_t wave_cnt[16], base_s;
+  const int cand = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t n = jobs[cand].n_src, best = states[cand].best_inl;
+  const uint32_t left = n > first_pair ? n - first_pair : 0u;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (uint32_t t0 = h0; t0 < h1; t0 += 1024) {
+    const uint32_t h = t0 + (uint32_t)tid;
+    bool keep = false;
+    if (h < h1 && valid[(size_t)cand * n_hyp + h]) keep = inliers[(size_t)cand * n_hyp + h] + left > best;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base_s, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      if (i < w) off += wave_cnt[i];
+      tot += wave_cnt[i];
+    }
+    if (keep) alive_idx[(size_t)cand * n_hyp + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
+    __syncthreads();
+    if (tid == 0) base_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) alive_cnt[cand] = base_s;
 }
 
 // Iterations after which a 3-point RANSAC reaches `conf` with inlier ratio inl/n: smallest k with

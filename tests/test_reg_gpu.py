@@ -235,6 +235,25 @@ def test_batch_matches_oracle(reg, capi, oracle_mod, scans, conf):
         assert abs(g["rmse"][c] - o["rmse"]) < 1e-5
 
 
+def test_all_3000_hypotheses_scored_without_scoring_every_pair(reg, capi, oracle_mod, scans):
+    """ransac_confidence = 0 (SURVEY App. B's wording of S2: every one of the 3000 hypotheses counts, the best wins, ties
+    to the smallest h): the scorer takes the pairs a quarter at a time and drops, in between, the hypotheses that can no
+    longer beat the winner of the first 256 (ransac_alive_kernel).  The selected hypothesis, its inlier count and the
+    pose are the every-pair oracle's -- on a same-place candidate, a thinner copy and a different scene, whose best
+    hypotheses are beaten late; and the same as with a cap of 700 hypotheses' worth of the old every-pair path where
+    the winner is among them."""
+    q = np.ascontiguousarray(scans["B"][::4])                    # 31 k pairs: eight chunks, two per quarter
+    cands = [np.ascontiguousarray(scans["A"][::2]), np.ascontiguousarray(scans["A"][1::5]),
+             np.ascontiguousarray(scans["C"][::2])]
+    prm = capi.default_reg_params(ransac_iters=3000, icp_iters=2, ransac_confidence=0.0, max_final_step=0.0)
+    g = reg.batch(q, cands, params=prm)
+    for c, cd in enumerate(cands):
+        o = oracle_mod.reg_one(q, cd, cand_id=c, ransac_iters=3000, icp_iters=2, ransac_confidence=0.0, max_final_step=0.0)
+        assert g["inliers"][c] == o["inliers"] and bool(g["ok"][c]) == o["ok"], c
+        assert np.abs(g["T"][c][:3, 3] - o["T"][:3, 3]).max() < POSE_TOL_M
+        assert _rot_angle(g["T"][c][:3, :3], o["T"][:3, :3]) < POSE_TOL_RAD
+
+
 @pytest.mark.parametrize("ransac,icp,init", [(0, 5, False), (200, 0, False), (0, 0, True), (100, 3, True)])
 def test_batch_modes_and_init_guess(reg, capi, oracle_mod, scans, ransac, icp, init):
     from gloc3d_amd import synth

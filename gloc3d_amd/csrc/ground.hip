@@ -3,14 +3,13 @@
 // its helpers FilterGroundByNormals (:63-161), EstimateGround (:19-61), TransformPointsToGround
 // (:163-194).  Steps G1..G7 are stated in oracle/ground_oracle.c; the host-side parts here (bin choice,
 // the sequential RANSAC rule, T_l2g from the plane) are a few dozen scalar operations.
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <cmath>
 #include <new>
 
 #include "common.hpp"
 #include "ground_kernels.hpp"
+#include "seg_sort.hpp"
 
 using namespace gloc;
 using namespace gloc::ground;
@@ -19,7 +18,8 @@ struct gloc_ground {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf stage_in, stage_out;            // host-pointer API staging
-  DevBuf flag, sel, count, cub_tmp;      // stream compaction
+  DevBuf flag, sel, count, tile_cnt;     // stream compaction
+  DevBuf sort_segs, sort_hist;           // the segmented radix sort's descriptor and scratch (seg_sort.hpp)
   DevBuf near, knn_idx, knn_d2, knn_pidx, knn_pd2, bins, hist, normals;
   DevBuf skeys, svals, skeys2, sperm, spts, cbox_lo, cbox_hi;  // culled 10-NN: Hilbert-sorted copy + chunk boxes
   int knn_exhaustive = 0;                // 1: the exhaustive form (kept for comparison)
@@ -105,13 +105,16 @@ int select_flagged(gloc_ground* h, uint32_t n, uint32_t* h_count) {
   hipStream_t s = h->stream;
   GLOC_TRY(h->sel.ensure(sizeof(uint32_t) * std::max<uint32_t>(n, 1), s));
   GLOC_TRY(h->count.ensure(sizeof(uint32_t), s));
-  hipcub::CountingInputIterator<uint32_t> ids(0);
-  size_t tmp = 0;
-  GLOC_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp, ids, h->flag.as<uint8_t>(), h->sel.as<uint32_t>(),
-                                         h->count.as<uint32_t>(), (int)n, s));
-  GLOC_TRY(h->cub_tmp.ensure(std::max<size_t>(tmp, 16), s));
-  GLOC_HIP(hipcub::DeviceSelect::Flagged(h->cub_tmp.p, tmp, ids, h->flag.as<uint8_t>(), h->sel.as<uint32_t>(),
-                                         h->count.as<uint32_t>(), (int)n, s));
+  const uint32_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
+  GLOC_TRY(h->tile_cnt.ensure(sizeof(uint32_t) * std::max<uint32_t>(n_tiles, 1), s));
+  if (n_tiles) {
+    hipLaunchKernelGGL(flag_count_kernel, dim3(n_tiles), dim3(256), 0, s, h->flag.as<uint8_t>(), n, h->tile_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(flag_scatter_kernel, dim3(n_tiles), dim3(256), 0, s, h->flag.as<uint8_t>(), n, h->tile_cnt.as<uint32_t>(),
+                       n_tiles, h->sel.as<uint32_t>(), h->count.as<uint32_t>());
+    GLOC_HIP(hipGetLastError());
+  } else {
+    GLOC_HIP(hipMemsetAsync(h->count.p, 0, sizeof(uint32_t), s));
+  }
   GLOC_HIP(hipMemcpyAsync(h_count, h->count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipStreamSynchronize(s));
   return GLOC_OK;
@@ -135,14 +138,19 @@ int knn_device(gloc_ground* h, const f32x4* d_pts, uint32_t m, uint32_t k, float
     GLOC_TRY(h->cbox_hi.ensure(sizeof(f32x4) * nch, s));
     hipLaunchKernelGGL(hilbert_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, m, -key_range,
                        1023.0f / (2.0f * key_range), h->skeys.as<uint32_t>(), h->svals.as<uint32_t>());
-    size_t tmp = 0;
-    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(),
-                                                h->svals.as<uint32_t>(), h->sperm.as<uint32_t>(), (int)m, 0, 30, s));
-    GLOC_TRY(h->cub_tmp.ensure(std::max<size_t>(tmp, 16), s));
-    GLOC_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.p, tmp, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(),
-                                                h->svals.as<uint32_t>(), h->sperm.as<uint32_t>(), (int)m, 0, 30, s));
-    hipLaunchKernelGGL(gather_sorted_f4_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, h->sperm.as<uint32_t>(),
-                       m, h->spts.as<f32x4>());
+    // the curve keys' order: the repo's own stable segmented radix sort (round 4: hipcub::DeviceRadixSort before), one
+    // segment, four 8-bit digits
+    const segsort::Seg seg{0u, m};
+    GLOC_TRY(h->sort_segs.ensure(sizeof(seg), s));
+    GLOC_TRY(h->sort_hist.ensure(segsort::scratch_bytes(1, m), s));
+    GLOC_HIP(hipMemcpyAsync(h->sort_segs.p, &seg, sizeof(seg), hipMemcpyHostToDevice, s));
+    uint32_t* vbuf[2] = {h->svals.as<uint32_t>(), h->sperm.as<uint32_t>()};
+    const int cur = segsort::sort_pairs<uint32_t, 8>(s, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(), vbuf[0], vbuf[1],
+                                                     h->sort_segs.as<segsort::Seg>(), 1, m, 0, 32, h->sort_hist.as<uint32_t>());
+    GLOC_HIP(hipGetLastError());
+    GLOC_HIP(hipStreamSynchronize(s));  // (`seg` is a stack buffer)
+    const uint32_t* perm = vbuf[cur];
+    hipLaunchKernelGGL(gather_sorted_f4_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, perm, m, h->spts.as<f32x4>());
     hipLaunchKernelGGL(kchunk_boxes_kernel, dim3(nch), dim3(64), 0, s, h->spts.as<f32x4>(), m,
                        h->cbox_lo.as<f32x4>(), h->cbox_hi.as<f32x4>());
     hipLaunchKernelGGL(knn_culled_kernel, dim3((nch + 3) / 4), dim3(256), 0, s, h->spts.as<f32x4>(), m,
@@ -334,7 +342,7 @@ int gloc_ground_destroy(gloc_ground* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->prof.destroy();
-  for (DevBuf* b : {&h->stage_in, &h->stage_out, &h->flag, &h->sel, &h->count, &h->cub_tmp, &h->near, &h->knn_idx,
+  for (DevBuf* b : {&h->stage_in, &h->stage_out, &h->flag, &h->sel, &h->count, &h->tile_cnt, &h->sort_segs, &h->sort_hist, &h->near, &h->knn_idx,
                     &h->knn_d2, &h->knn_pidx, &h->knn_pd2, &h->skeys, &h->svals, &h->skeys2, &h->sperm, &h->spts,
                     &h->cbox_lo, &h->cbox_hi, &h->bins, &h->hist, &h->normals, &h->gpts, &h->planes, &h->valid, &h->inliers,
                     &h->T12})

@@ -168,6 +168,55 @@ __global__ __launch_bounds__(256) void hilbert_keys_kernel(const f32x4* __restri
   vals[i] = i;
 }
 
+// ---- stable compaction of the flagged indices (round 4: hipcub::DeviceSelect::Flagged before) ---------------------------
+// sel[0 .. count) = the indices i with flag[i] != 0, ascending.  Two launches, tiles of 2048 flags: a count per tile;
+// then every tile sums the counts before it (a few hundred at most) and ranks its own flags with ballots -- waves in
+// order, lanes in order -- so the order of the input is kept.
+constexpr int SEL_TILE = 2048;
+
+__global__ __launch_bounds__(256) void flag_count_kernel(const uint8_t* __restrict__ flag, uint32_t n,
+                                                          uint32_t* __restrict__ tile_cnt) {
+  __shared__ uint32_t wc[4];
+  const uint32_t base = blockIdx.x * SEL_TILE;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < SEL_TILE / 256; ++k) {
+    const uint32_t e = base + k * 256 + threadIdx.x;
+    c += (uint32_t)__popcll(__ballot(e < n && flag[e] != 0));  // (per wave, the same in all its lanes)
+  }
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+}
+
+__global__ __launch_bounds__(256) void flag_scatter_kernel(const uint8_t* __restrict__ flag, uint32_t n,
+                                                            const uint32_t* __restrict__ tile_cnt, uint32_t n_tiles,
+                                                            uint32_t* __restrict__ sel, uint32_t* __restrict__ count) {
+  __shared__ uint32_t red[4], wave_cnt[4], off_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t before = 0;  // flags set in the tiles before this one
+  for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) before += tile_cnt[t];
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) red[w] = before;
+  __syncthreads();
+  uint32_t off = (red[0] + red[1]) + (red[2] + red[3]);
+  const uint32_t base = blockIdx.x * SEL_TILE;
+  for (int k = 0; k < SEL_TILE / 256; ++k) {
+    const uint32_t e = base + k * 256 + threadIdx.x;
+    const bool f = e < n && flag[e] != 0;
+    const unsigned long long m = __ballot(f);
+    __syncthreads();  // (the previous round's wave_cnt has been read)
+    if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t wo = off;
+    for (int i = 0; i < w; ++i) wo += wave_cnt[i];
+    if (f) sel[wo + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e;
+    off += (wave_cnt[0] + wave_cnt[1]) + (wave_cnt[2] + wave_cnt[3]);
+  }
+  if (blockIdx.x == n_tiles - 1 && threadIdx.x == 0) *count = off;
+  (void)off_s;
+}
+
 // spts[s] = (x, y, z, bits(index in the unsorted cloud)) of the s-th point in key order
 __global__ __launch_bounds__(256) void gather_sorted_f4_kernel(const f32x4* __restrict__ pts,
                                                                 const uint32_t* __restrict__ perm, uint32_t m,

@@ -235,7 +235,7 @@ int sort_pairs(hipStream_t q, K* k0, K* k1, uint32_t* v0, uint32_t* v1, const Se
 // whenever values ascend with the input position (they do: values are the positions).  Used for the launch order of a
 // scan's source groups (969 groups at 124 k points): one launch instead of the twelve of a four-pass radix sort.
 constexpr int SMALL_MAX = 4096;
-__global__ __launch_bounds__(1024) void small_sort_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+static __global__ __launch_bounds__(1024) void small_sort_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                           const Seg* __restrict__ segs, uint32_t* __restrict__ vals_out) {
   __shared__ unsigned long long a[SMALL_MAX];
   const Seg sg = segs[blockIdx.x];

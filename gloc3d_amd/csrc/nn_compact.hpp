@@ -356,29 +356,61 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     L.src[S] = f32x4{0.f, 0.f, 0.f, 0.f};
     L.key[S] = (unsigned long long)__float_as_uint(-1.f) << 32;
   }
+  // Through the sweep a source's bound lives in LDS (the key) and, for the lane-level tests, in a register as
+  // bests[s] = bound x KS: the units of the chunk-box tests (below).  best[s] itself is read back after the sweep.
+  constexpr float KS = SB2_INV_RANGE * SB2_INV_RANGE / NN_LB_SCALE;
+  float bests[CS];
+#pragma unroll
+  for (int s = 0; s < CS; ++s) bests[s] = best[s] * KS;
   auto wave_max_best = [&]() {
     float m = -1.f;
 #pragma unroll
-    for (int s = 0; s < CS; ++s) m = fmaxf(m, best[s]);  // (-1 where there is no point)
+    for (int s = 0; s < CS; ++s) m = fmaxf(m, bests[s]);  // (negative where there is no point)
     return wave_minmax<true>(m);
   };
-  float wmax = wave_max_best();
+  float wmax_s = wave_max_best();  // the wave's bound, in those units
   const unsigned long long t_pro = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_chunks = 0;
 
   NN_MARK("sweep");
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 1  // dev (timing only, wrong results): stop after the prologue
-  if (wmax > -2.f) return;
+  if (wmax_s > -2.f) return;
 #endif
   // ---- sweep: super-chunk boxes first (64 per ballot), then 64 chunk boxes per surviving batch ----
-  auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {
+  auto box_box_lb = [&](const f32x4& blo, const f32x4& bhi) {  // (super-chunk boxes: corners; the result in units of (64 m)^2)
     const float ex = fmaxf(fmaxf(blo.x - whi[0], wlo[0] - bhi.x), 0.f);
     const float ey = fmaxf(fmaxf(blo.y - whi[1], wlo[1] - bhi.y), 0.f);
     const float ez = fmaxf(fmaxf(blo.z - whi[2], wlo[2] - bhi.z), 0.f);
-    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * NN_LB_SCALE;  // (a bound, not a distance: fused is fine)
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * (SB2_INV_RANGE * SB2_INV_RANGE);  // (a bound, not a distance: fused is fine)
+  };
+  // Chunk boxes are (centre, -half extent / 64) since round 4 (scan_store.hip: chunk_boxes_kernel): the distance of the
+  // wave's box -- kept the same way -- or of a point to a chunk's box along an axis is clamp(|c - c'| / 64 + nh + nh'), one
+  // v_fma_f32 with the abs and clamp modifiers; squared sums in units of (64 m)^2, saturated at one unit per axis (a
+  // bound stays a bound), compared with the bounds scaled once: KS = 1 / 64^2 / NN_LB_SCALE.
+  float wc[3], wnh[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    wc[a] = 0.5f * wlo[a] + 0.5f * whi[a];
+    wnh[a] = -(fmaxf(wc[a] - wlo[a], whi[a] - wc[a]) * 1.0000005f + 1.0e-30f) * SB2_INV_RANGE;
+  }
+  auto axis_e = [](float d, float nh) {
+    float e;
+    asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(e) : "v"(d), "v"(SB2_INV_RANGE), "v"(nh));
+    return e;
+  };
+  auto axis_es = [](float d, float nh_uniform) {  // the half extent in a scalar register (a chunk's box loaded with s_load)
+    float e;
+    asm("v_fma_f32 %0, |%1|, %2, %3 clamp" : "=v"(e) : "v"(d), "v"(SB2_INV_RANGE), "s"(nh_uniform));
+    return e;
+  };
+  auto chunk_box_lb = [&](const f32x4& bc, const f32x4& bnh) {  // this lane's chunk box against the wave's box
+    const float ex = axis_e(bc.x - wc[0], bnh.x + wnh[0]);
+    const float ey = axis_e(bc.y - wc[1], bnh.y + wnh[1]);
+    const float ez = axis_e(bc.z - wc[2], bnh.z + wnh[2]);
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
   };
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 6  // dev (timing only): no sweep at all -- prologue + epilogue
-  for (uint32_t s0 = 0; s0 < (wmax > -2.f ? 0u : ix.nsup); s0 += 64) {
+  for (uint32_t s0 = 0; s0 < (wmax_s > -2.f ? 0u : ix.nsup); s0 += 64) {
 #else
   for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
 #endif
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
       lbs = box_box_lb(ulo, uhi);
     }
-    unsigned long long smask = __builtin_amdgcn_ballot_w64(lbs <= wmax);
+    unsigned long long smask = __builtin_amdgcn_ballot_w64(lbs <= wmax_s);
     // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
     f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
     int cur = -1;
@@ -400,7 +432,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     while (cur >= 0) {
     const unsigned long long t_b0 = now();
     const uint32_t c0 = (s0 + cur) * 64;
-    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax;
+    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax_s;
     const uint32_t cl = c0 + lane;
     const f32x4 blo = nlo, bhi = nhi;
     cur = -1;
@@ -412,8 +444,8 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     }
     if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
     float lbw = __builtin_inff();
-    if (cl < ix.nchunks) lbw = box_box_lb(blo, bhi);
-    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax);
+    if (cl < ix.nchunks) lbw = chunk_box_lb(blo, bhi);
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax_s);
     if constexpr (SPLIT) {
       mask &= pmask;
       w_cand += (uint32_t)__popcll(mask);
@@ -421,30 +453,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     if constexpr (TRACE) a_batch += now() - t_b0;
   NN_MARK("batch_tested");
     // the lane-level test of one chunk box: which of the lane's sources can still use the chunk
-    auto lane_test = [&](const f32x4& lo, const f32x4& hi, bool (&need)[CS], unsigned long long (&nm)[CS]) {
+    auto lane_test = [&](const f32x4& bc, const f32x4& bnh, bool (&need)[CS], unsigned long long (&nm)[CS]) {
       unsigned long long nm_any = 0ull;  // the ballots, taken where the comparisons are made
-      if constexpr (CS == 2) {  // box_lb() of the lane's two points per packed instruction
-        const f32x2 qx = {px[0], px[1]}, qy = {py[0], py[1]}, qz = {pz[0], pz[1]};
-        const f32x2 ax = f32x2{lo.x, lo.x} - qx, bx = qx - f32x2{hi.x, hi.x};
-        const f32x2 ay = f32x2{lo.y, lo.y} - qy, by = qy - f32x2{hi.y, hi.y};
-        const f32x2 az = f32x2{lo.z, lo.z} - qz, bz = qz - f32x2{hi.z, hi.z};
-        const f32x2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
-        const f32x2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
-        const f32x2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-        const f32x2 lb = {__builtin_fmaf(ez.x, ez.x, __builtin_fmaf(ey.x, ey.x, ex.x * ex.x)) * NN_LB_SCALE,
-                          __builtin_fmaf(ez.y, ez.y, __builtin_fmaf(ey.y, ey.y, ex.y * ex.y)) * NN_LB_SCALE};
-        need[0] = lb.x <= best[0];  // (a lane without a point carries the bound -1: nothing passes)
-        need[1] = lb.y <= best[1];
-        nm[0] = __builtin_amdgcn_ballot_w64(need[0]);
-        nm[1] = __builtin_amdgcn_ballot_w64(need[1]);
-        nm_any = nm[0] | nm[1];
-      } else {
 #pragma unroll
-        for (int s = 0; s < CS; ++s) {
-          need[s] = box_lb(px[s], py[s], pz[s], lo, hi) <= best[s];
-          nm[s] = __builtin_amdgcn_ballot_w64(need[s]);
-          nm_any |= nm[s];
-        }
+      for (int s = 0; s < CS; ++s) {  // (CS = 2: the three subtractions pair up in packed instructions)
+        const float ex = axis_es(px[s] - bc.x, bnh.x), ey = axis_es(py[s] - bc.y, bnh.y), ez = axis_es(pz[s] - bc.z, bnh.z);
+        need[s] = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) <= bests[s];  // (no point: the bound -1, nothing passes)
+        nm[s] = __builtin_amdgcn_ballot_w64(need[s]);
+        nm_any |= nm[s];
       }
       return nm_any;
     };
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const unsigned long long t_k0 = now();
-      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax) continue;
+      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax_s) continue;
       const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
       if constexpr (TRACE) n_cand++;
       // the chunk's box straight into scalar registers (round 3: six v_readlane from the lane that tested it before)
@@ -731,10 +747,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
 #pragma unroll
       for (int s = 0; s < CS; ++s) {
         const float nb = __uint_as_float((uint32_t)(L.key[s * 64 + lane] >> 32));
-        changed |= nb < best[s];
-        best[s] = nb;
+        const float nbs = nb * KS;
+        changed |= nbs < bests[s];
+        bests[s] = nbs;
       }
-      if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax = wave_max_best();
+      if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax_s = wave_max_best();
       if constexpr (TRACE) {
         const unsigned long long t_e = now();
         a_refresh += t_e - t_f0;
@@ -755,8 +772,11 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 3  // dev (timing only): no index recovery, no outputs
-  if (wmax > -2.f) return;
+  if (wmax_s > -2.f) return;
 #endif
+  // (the bounds as the sweep left them: the fused minima -- the keys' high words)
+#pragma unroll
+  for (int s = 0; s < CS; ++s) best[s] = __uint_as_float((uint32_t)(L.key[s * 64 + lane] >> 32));
   NN_MARK("recovery");
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
@@ -819,8 +839,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
         const uint32_t cl = c0 + lane;
         bool hit = false;
         if (cl < ix.nchunks) {
-          const f32x4 clo = ix.box_lo[cl], chi = ix.box_hi[cl];
-          hit = !(box_lb(qx, qy, qz, clo, chi) > qb);
+          const f32x4 bc = ix.box_lo[cl], bnh = ix.box_hi[cl];  // (centre, -half extent / 64)
+          const float ex = axis_e(qx - bc.x, bnh.x), ey = axis_e(qy - bc.y, bnh.y), ez = axis_e(qz - bc.z, bnh.z);
+          hit = !(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > qb * KS);
         }
         unsigned long long cm = __builtin_amdgcn_ballot_w64(hit);
         while (cm) {

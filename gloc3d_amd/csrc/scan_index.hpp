@@ -40,7 +40,9 @@ static_assert(sizeof(ScanHeader) == 64, "header is 64 bytes");
 
 struct ScanIndexDev {
   const f32x4* pts;      // Hilbert order: x, y, z, bits(original index)
-  const f32x4* box_lo;   // per chunk of CH points
+  // per chunk of CH points, since round 4 as (centre, -half extent / SB2_RANGE): box_lo holds the centres, box_hi the
+  // negated scaled half extents (the names are the arrays', from when they held the corners)
+  const f32x4* box_lo;
   const f32x4* box_hi;
   // boxes of the sub-blocks of SB points, two sub-blocks (2q, 2q+1) interleaved in 3 float4:
   // (lo0.x lo1.x lo0.y lo1.y) (lo0.z lo1.z hi0.x hi1.x) (hi0.y hi1.y hi0.z hi1.z) -- a lane tests one

@@ -180,8 +180,19 @@ __global__ __launch_bounds__(64) void chunk_boxes_kernel(const ScanBuild* __rest
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
     }
   if (lane == 0) {
-    sb.lo[c] = f32x4{mn[0], mn[1], mn[2], 0.f};
-    sb.hi[c] = f32x4{mx[0], mx[1], mx[2], 0.f};
+    // Stored as CENTRE and NEGATED HALF EXTENT / 64 (scan_index.hpp: SB2_*), like the sub-block boxes since round 3 and
+    // for the same reason: a point's (or a box's) distance to the box along an axis is one v_fma_f32 with the abs and
+    // clamp modifiers, clamp(|p - c| / 64 + nh).  The half extent is rounded up so that [c - h, c + h] contains the box
+    // whatever the rounding of c.
+    float cc[3], nh[3];
+    for (int a = 0; a < 3; ++a) {
+      const float c_ = 0.5f * mn[a] + 0.5f * mx[a];
+      const float he = fmaxf(c_ - mn[a], mx[a] - c_) * 1.0000005f + 1.0e-30f;  // (each difference within 2^-24 of exact)
+      cc[a] = c_;
+      nh[a] = -he * SB2_INV_RANGE;
+    }
+    sb.lo[c] = f32x4{cc[0], cc[1], cc[2], 0.f};
+    sb.hi[c] = f32x4{nh[0], nh[1], nh[2], 0.f};
   }
 }
 
@@ -192,9 +203,14 @@ __global__ __launch_bounds__(64) void super_boxes_kernel(const ScanBuild* __rest
   const uint32_t c = blockIdx.x * 64 + threadIdx.x;
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   if (c < sb.nch) {
+    // the chunk's box back from (centre, -half extent / 64), widened by more than the rounding of the two operations
     const f32x4 a = sb.lo[c], b = sb.hi[c];
-    mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
-    mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+    const float cc[3] = {a.x, a.y, a.z}, he[3] = {-b.x * SB2_RANGE, -b.y * SB2_RANGE, -b.z * SB2_RANGE};
+    for (int k = 0; k < 3; ++k) {
+      const float slack = 2.0e-7f * (fabsf(cc[k]) + he[k]);
+      mn[k] = (cc[k] - he[k]) - slack;
+      mx[k] = (cc[k] + he[k]) + slack;
+    }
   }
   for (int o = 32; o > 0; o >>= 1)
     for (int a = 0; a < 3; ++a) {

@@ -743,6 +743,9 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
       __builtin_amdgcn_wave_barrier();  // all reads of the stage done, all key updates visible
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   NN_MARK("refresh");
+      // (the registers' copies of the bounds serve the tests of LATER candidates: after the wave's last one -- no bit left
+      // in this batch, no batch prefetched, no further group of super-chunks -- nobody reads them)
+      if (mask == 0ull && cur < 0 && s0 + 64 >= ix.nsup) continue;
       bool changed = false;
 #pragma unroll
       for (int s = 0; s < CS; ++s) {

@@ -27,6 +27,7 @@ struct gloc_coarse {
   std::vector<float> res;         // would silently return a wrong (x, y, yaw), so it is rejected
   std::vector<uint32_t> free_ids;
   std::vector<size_t> block_words;                    // size class of each grid's allocation
+  size_t cached_bytes = 0;                            // ... bytes parked in free_blocks (capped: COARSE_CACHE_BYTES)
   std::map<size_t, std::vector<void*>> free_blocks;   // released allocations by size class: a stream of queries
                                                       // adds and releases 25 grids per step -- no hipMalloc / hipFree
                                                       // (both synchronise the device) once the classes are warm
@@ -57,12 +58,14 @@ int check_params(const gloc_coarse_params* p) {
 // size classes are warm: a grid made alone used to cost three synchronisations and a hipMalloc, 2.3 ms in a busy
 // stream against 0.25 ms of device work.
 constexpr size_t CELL_CLASS = 4096;  // cell lists are sized in steps of 4096 cells
+constexpr size_t COARSE_CACHE_BYTES = 256u << 20;  // released grid blocks kept for reuse, at most
 
 int take_block(gloc_coarse* h, size_t words, void** blk) {
   auto it = h->free_blocks.find(words);
   if (it != h->free_blocks.end() && !it->second.empty()) {
     *blk = it->second.back();
     it->second.pop_back();
+    h->cached_bytes -= sizeof(uint32_t) * words;
     return GLOC_OK;
   }
   hipError_t e = hipMalloc(blk, sizeof(uint32_t) * words);
@@ -72,6 +75,7 @@ int take_block(gloc_coarse* h, size_t words, void** blk) {
       for (void* b : kv.second) (void)hipFree(b);
       kv.second.clear();
     }
+    h->cached_bytes = 0;
     e = hipMalloc(blk, sizeof(uint32_t) * words);
   }
   if (e != hipSuccess) {
@@ -132,7 +136,10 @@ int finish_grids(gloc_coarse* h, const gloc_coarse_params* prm, size_t n_grids, 
   }
   if (rc != GLOC_OK) {
     for (size_t i = 0; i < n_grids; ++i)
-      if (blks[i]) h->free_blocks[words[i]].push_back(blks[i]);
+      if (blks[i]) {
+        h->free_blocks[words[i]].push_back(blks[i]);
+        h->cached_bytes += sizeof(uint32_t) * words[i];
+      }
     return rc;
   }
   for (size_t i = 0; i < n_grids; ++i) {
@@ -310,7 +317,15 @@ int gloc_coarse_release(gloc_coarse* h, uint32_t grid_id) {
   GLOC_REQUIRE(grid_id < h->blocks.size() && h->blocks[grid_id], GLOC_ERR_INVALID, "unknown grid id %u", grid_id);
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_HIP(hipStreamSynchronize(h->stream));  // (matches are synchronous: nothing of this handle still reads it)
-  h->free_blocks[h->block_words[grid_id]].push_back(h->blocks[grid_id]);
+  // parked for the next grid of its size class -- up to COARSE_CACHE_BYTES in all (a long stream of grids of varying
+  // cell counts would otherwise pile up device memory that no other allocator can see); beyond that, freed
+  const size_t bytes = sizeof(uint32_t) * h->block_words[grid_id];
+  if (h->cached_bytes + bytes <= COARSE_CACHE_BYTES) {
+    h->free_blocks[h->block_words[grid_id]].push_back(h->blocks[grid_id]);
+    h->cached_bytes += bytes;
+  } else {
+    (void)hipFree(h->blocks[grid_id]);
+  }
   h->blocks[grid_id] = nullptr;
   h->counts[grid_id] = 0;
   h->free_ids.push_back(grid_id);

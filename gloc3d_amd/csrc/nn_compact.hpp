@@ -917,10 +917,14 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
   // ---- outputs: corr / d2 (sorted slots), pairs, the wave's moments ------------------------------
   // Moments about the WAVE'S OWN centre, in fp32 (round 3; fp64 raw moments until then: 11 % of the launch).  The ICP
   // step needs n, sum p, sum q, sum p q^T to ~1e-9 of their size, which for raw coordinates (100 m, 124 k points) takes
-  // fp64; about the centre c of the wave's box the 128 points are a metre or two out, their products of order one,
-  // and a 24-bit sum of 128 of them is exact to 1e-7 of that -- 1e-11 of the raw sum.  solve_kernel puts the raw
-  // moments back together in fp64 (sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T: exact products of
-  // fp32 values), in the fixed order of the partials.
+  // fp64.  About the centre c of the wave's box the coordinates are at most half the wave's extent W (and the matched
+  // target's at most that plus the correspondence distance): a 24-bit sum of 128 products errs by at most
+  // 128 x 2^-24 x (W / 2 + d)^2 -- 2e-5 m^2 for an ordinary wave (W ~ 2 m), 0.04 m^2 for one of the ~10 far-field waves of
+  // a scan (W up to 130 m, d up to tens of metres when no gate is set) -- against entries of sum p q^T of order
+  // 124 000 x (30 m)^2 = 1e8 m^2: 4e-10 relative in the worst case, 1e-13 ordinarily.  solve_kernel puts the raw moments back
+  // together in fp64 (sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T: exact products of fp32 values), in the
+  // fixed order of the partials.  The pose that results is within 1e-5 of the fp64-moment path's
+  // (tests/test_reg_gpu.py::test_every_pass_bit_identical_to_the_brute_force_kernel) and 1e-4 of the oracle's.
   float mv[17], pp = 0.f;  // (pp: sum |p'|^2, for the RMS size of the ICP update -- solve_kernel)
 #pragma unroll
   for (int k = 0; k < 17; ++k) mv[k] = 0.f;

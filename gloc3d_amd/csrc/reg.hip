@@ -45,6 +45,7 @@ struct gloc_reg {
     size_t total = 0;
     float max_rmse = 0.f, max_final_step = 0.f;
     bool icp = false;
+    gloc_scan_store* store = nullptr;  // the store whose in-flight count this batch holds
   } pending;
   std::vector<float> last_final_step;  // per job of the last collected batch (gloc_reg_final_steps)
   int nn_mode = 0;        // 0 culled + compacted (default), 1 exhaustive
@@ -526,6 +527,8 @@ int gloc_reg_destroy(gloc_reg* h) {
   if (!h) return GLOC_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->pending.active && h->pending.store) h->pending.store->inflight--;
+  h->pending.active = false;
   if (h->store) h->store->attached--;
   h->store = nullptr;
   if (h->own_store) (void)gloc_scan_store_destroy(h->own_store);
@@ -700,6 +703,8 @@ int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_
   P.max_final_step = params->icp_iters ? params->max_final_step : 0.f;
   GLOC_TRY(enqueue_jobs(h, jh, params));
   P.active = true;
+  P.store = h->store;
+  h->store->inflight++;  // (gloc_scan_store_build_target_index refuses to re-sort scans under a batch in flight)
   return GLOC_OK;
 }
 
@@ -709,6 +714,15 @@ int gloc_reg_batch_multi_end(gloc_reg* h, float* out_T, float* out_rmse, uint32_
   GLOC_HIP(hipSetDevice(h->device));
   gloc_reg::Pending& P = h->pending;
   P.active = false;
+  struct Done {  // whatever happens below, the batch no longer reads the store's scans once its event has been waited for
+    gloc_reg* h;
+    gloc_scan_store* st;
+    ~Done() {
+      (void)hipEventSynchronize(h->done_ev);
+      if (st) st->inflight--;
+    }
+  } done{h, P.store};
+  P.store = nullptr;
   for (size_t o = 0; o < P.total; ++o) {
     std::copy(P.def_T.begin() + 16 * o, P.def_T.begin() + 16 * (o + 1), out_T + 16 * o);
     if (out_rmse) out_rmse[o] = 0.f;

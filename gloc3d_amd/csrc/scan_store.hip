@@ -1004,6 +1004,10 @@ int gloc_scan_store_build_target_index_batch(gloc_scan_store* st, const uint32_t
   GLOC_REQUIRE(st && (scan_ids || !count), GLOC_ERR_INVALID, "null argument");
   GLOC_HIP(hipSetDevice(st->device));
   std::lock_guard<std::mutex> lk(st->mu);
+  // the re-sort rewrites points, boxes and permutations of a resident scan IN PLACE: a batch in flight on an attached
+  // handle would search half-rewritten boxes (missed neighbours, not only a slower search)
+  GLOC_REQUIRE(st->inflight.load() == 0, GLOC_ERR_STATE,
+               "%d registration batch(es) in flight on this store (gloc_reg_batch_multi_begin without _end)", st->inflight.load());
   std::vector<DevScan*> ps(count);
   for (size_t i = 0; i < count; ++i) {
     GLOC_REQUIRE(scan_ids[i] < st->scans.size() && st->scans[scan_ids[i]].live, GLOC_ERR_INVALID, "unknown scan id %u",

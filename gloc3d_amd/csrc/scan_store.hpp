@@ -52,6 +52,8 @@ struct gloc_scan_store {
             &grp_v0, &grp_v1, &grp_segs, &kd_k0, &kd_k1, &kd_v0, &kd_v1, &kd_p0, &kd_p1, &kd_h0, &kd_h1, &kd_box, &kd_desc};
   }
   std::atomic<int> attached{0};  // registration handles using this store
+  std::atomic<int> inflight{0};  // batches between gloc_reg_batch_multi_begin and _end on any of them: their jobs hold
+                                 // by-value views of scans, so no scan may be re-sorted in place meanwhile
 };
 
 namespace gloc {

@@ -654,8 +654,12 @@ def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
         with pytest.raises(capi.GlocError) as ei:
             call()
         assert ei.value.code == 5, ei.value                # GLOC_ERR_STATE
+    with pytest.raises(capi.GlocError) as ei:              # nor may a scan be re-sorted in place under a batch in flight
+        store.build_target_index_batch(cs[:1])
+    assert ei.value.code == 5
     g = h[0].batch_multi_end()
     assert (bits(g["T"]) == bits(want[0]["T"])).all() and (g["inliers"] == want[0]["inliers"]).all()
+    store.build_target_index_batch(cs[:1])                 # (fine again)
     for r in h + [ref]:
         r.close()
     store.close()

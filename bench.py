@@ -80,7 +80,7 @@ FLOP_PER_PAIR = 8             # 3 sub + 3 mul + 2 add per 
 BYTES_PER_POINT_INDEXED = 16  # sorted float4 (x, y, z, original index)
 KNN_CFGB = (64, 10000)        # BASELINE.json configs[1]
 KNN_SHARD_ROWS = 125000       # one of the 8 shards of configs[4]
-PMC_FILES = ("r03_pmc_traffic_nn_compact.json", "r02_pmc_traffic_nn_compact.json")
+PMC_FILES = ("r04_pmc_traffic_nn_compact.json", "r03_pmc_traffic_nn_compact.json", "r02_pmc_traffic_nn_compact.json")
 
 
 def log(msg):

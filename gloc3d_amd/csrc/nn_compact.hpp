@@ -134,7 +134,7 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // -- 92 % of the 1-NN time -- 3 % (registers, code layout).
 template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */,
           bool WARM = false>
-__global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
+__device__ __forceinline__ void nn_compact_body(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg /* per slot */, uint32_t subs,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
@@ -1041,6 +1041,28 @@ __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(
     (void)t_chunks;
   }
 }
+
+#define NN_COMPACT_PARAMS                                                                                              \
+  const Job *__restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg, uint32_t subs,                     \
+      const CandState *__restrict__ states, const uint32_t *prev_corr, uint32_t *corr, float *__restrict__ d2out,      \
+      f32x4 *__restrict__ pairs, double *__restrict__ partials, uint32_t n_part, size_t ld, float gate2, NnSplit sp,   \
+      unsigned long long *__restrict__ stat_pairs, uint32_t *__restrict__ trace
+#define NN_COMPACT_ARGS jobs, n_jobs, job_group, n_wg, subs, states, prev_corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, stat_pairs, trace
+
+template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false, bool WARM = false>
+__global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(NN_COMPACT_PARAMS) {
+  nn_compact_body<CS, PAIRS, TRACE, SPLIT, WARM>(NN_COMPACT_ARGS);
+}
+
+// The warm moments pass with the split plan in it -- what one query alone runs 20 times -- held to the register budget
+// of six waves per SIMD (80 VGPRs; the compiler takes 82 left alone, one scalar spill more with the limit): the plain
+// kernel fits by itself.
+template <int CS>
+__global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void nn_compact_split_warm_kernel(NN_COMPACT_PARAMS) {
+  nn_compact_body<CS, false, false, true, true>(NN_COMPACT_ARGS);
+}
+#undef NN_COMPACT_PARAMS
+#undef NN_COMPACT_ARGS
 
 }  // namespace reg
 }  // namespace gloc

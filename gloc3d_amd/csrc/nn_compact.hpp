@@ -305,22 +305,27 @@ __device__ __forceinline__ void nn_compact_body(
         b0 = j / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
       } else if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
         const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
-        // lower_bound over the sorted keys, nine-way: eight independent probes per round trip, 6 rounds at 124 k keys
-        // where the binary search took 17 dependent ones -- 46 % of a cold wave's time (traced, round 4)
+        // lower_bound over the sorted keys, (KP + 1)-way: KP independent probes per round trip.  The binary search took 17
+        // dependent trips at 124 k keys (46 % of a cold wave's time, traced); nine-way (8 probes, 7 trips, 56 loads) made the
+        // memory pipe the limit (every lane its own addresses: 40 %); five-way is 8 trips of 4.
+#ifndef GLOC_NN_KEY_PROBES
+#define GLOC_NN_KEY_PROBES 4
+#endif
+        constexpr int KP = GLOC_NN_KEY_PROBES;
         uint32_t lo = 0, hi = ix.n;  // the answer is in [lo, hi]
-        while (hi - lo > 8u) {
+        while (hi - lo > (uint32_t)KP) {
           const uint32_t len = hi - lo;
-          uint32_t pos[8], kv[8];
+          uint32_t pos[KP], kv[KP];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pos[i] = lo + (uint32_t)(((unsigned long long)len * (uint32_t)(i + 1)) / 9u);  // lo < pos < hi, ascending
+          for (int i = 0; i < KP; ++i) pos[i] = lo + (uint32_t)(((unsigned long long)len * (uint32_t)(i + 1)) / (uint32_t)(KP + 1));  // lo < pos < hi, ascending
 #pragma unroll
-          for (int i = 0; i < 8; ++i) kv[i] = ix.keys[pos[i]];
+          for (int i = 0; i < KP; ++i) kv[i] = ix.keys[pos[i]];
           uint32_t nlo = lo, nhi = hi;
 #pragma unroll
-          for (int i = 7; i >= 0; --i)
+          for (int i = KP - 1; i >= 0; --i)
             if (!(kv[i] < key)) nhi = pos[i];      // the first probe that is not below the key bounds the answer from above
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < KP; ++i)
             if (kv[i] < key) nlo = pos[i] + 1;     // the last probe below it, from below
           lo = nlo;
           hi = nhi;
@@ -328,7 +333,7 @@ __device__ __forceinline__ void nn_compact_body(
         {
           uint32_t below = 0;
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < KP; ++i)
             if (lo + i < hi && ix.keys[lo + i] < key) below++;
           lo += below;  // (sorted: the keys below the key are a prefix of [lo, hi))
         }

@@ -398,7 +398,8 @@ def main():
     ap.add_argument("--nn-split-thresh", type=int, default=None, help="culled 1-NN tuning: work estimate (cycles) above which a source group is split")
     ap.add_argument("--nn-sub-jobs", type=int, default=None, help="culled 1-NN tuning: shares of a job's work-groups with their own slot in the launch order")
     ap.add_argument("--nn-mode", choices=["culled", "exhaustive"], default="culled",
-                    help="1-NN search of the registration (identical results)")
+                    help="1-NN search of the registration: identical correspondences, distances and selections bit for bit; poses agree to "
+                         "1e-5 (the culled search sums its moments in fp32 about each wave's centre, the exhaustive one block-wise in fp64)")
     ap.add_argument("--ransac-confidence", type=float, default=None,
                     help="override gloc_reg_params.ransac_confidence (0: score all 3000 hypotheses)")
     ap.add_argument("--no-target-index", action="store_true",
@@ -1031,7 +1032,8 @@ def main():
                                 "note": f"{FLOP_PER_PAIR} flop x {pairs_x:.3e} pairs per launch (20 jobs) / {lx['nn_launch_ms']:.2f} ms; "
                                         "the un-fused reference arithmetic cannot use FMA, which the peak counts as 2 flop"},
                    "same_selection_as_culled": bool(sx == [sels[i * per_step] for i in range(n_ex)]),
-                   "what": "GLOC_REG_NN_EXHAUSTIVE, one query (20 candidates) per batch; identical results to the culled search"})
+                   "what": "GLOC_REG_NN_EXHAUSTIVE, one query (20 candidates) per batch; correspondences, distances and selections identical to the "
+                           "culled search bit for bit, poses to 1e-5 (tests/test_reg_gpu.py::test_every_pass_bit_identical_to_the_brute_force_kernel)"})
         lx.pop("pairs_evaluated_per_source", None)
         for r_ in regs:
             r_.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_CULLED if args.nn_mode == "culled" else capi.REG_NN_EXHAUSTIVE)

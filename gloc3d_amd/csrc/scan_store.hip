@@ -846,12 +846,21 @@ int store_build_target_indices(gloc_scan_store* st, DevScan* const* scans, size_
     hipLaunchKernelGGL(kd_finish_kernel, dim3((max_np + 255) / 256, cnt), dim3(256), 0, q, d_k, pp[cur], hh[cur]);
     launch_boxes(q, st->builds.as<ScanBuild>(), cnt, max_nch, max_npairs, max_nsup);
     GLOC_HIP(hipGetLastError());
-    GLOC_TRY(launch_orders(st, st->builds.as<ScanBuild>(), hb, cnt));  // synchronises the stream
+    // From here on the scans ARE in kd order (kd_finish_kernel rewrote their points, inverse permutations and kpos, the
+    // boxes follow): the bookkeeping says so before anything else can fail, so that a failure below (the launch orders'
+    // scratch) leaves every scan consistent -- cold starts go through kpos, a retry does not re-sort a re-sorted scan,
+    // and the launch orders, which listed groups of the old order, are rebuilt on demand.
     for (DevScan* s : todo) {
       s->idx.kpos = s->kpos_mem;
       s->kd = true;
-      s->order_built = 1u << 2;  // the other launch orders listed groups of the old order: rebuilt on demand
+      s->order_built = 0;
     }
+    const int rc_orders = launch_orders(st, st->builds.as<ScanBuild>(), hb, cnt);  // synchronises the stream
+    if (rc_orders != GLOC_OK) {
+      (void)hipStreamSynchronize(q);
+      return rc_orders;
+    }
+    for (DevScan* s : todo) s->order_built = 1u << 2;
   }
   return GLOC_OK;
 }

@@ -32,6 +32,7 @@ struct gloc_knn {
   DevBuf exact;     // rerank: reference-order distances [nq][KC]
   DevBuf keys2;     // rerank output [nq][k]
   DevBuf qnorm;     // [nq]
+  DevBuf qsplit;    // [nq][dim / 8][8 bf16 h, 8 bf16 m]: the queries of the split-bf16 coarse pass
   DevBuf dev_trace; // developer aid: phase stamps of the fused select + re-rank kernel (null unless enabled)
   DevBuf flags;     // [nq] int
   DevBuf stage_q;   // host-API staging: queries
@@ -115,6 +116,33 @@ int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n
 // Per-query top-K of h->dist: chunked threshold selection + merge(s).  MODE as select_chunk_kernel.
 constexpr int SELECT_ONE_BLOCK_MAX = 16384;  // rows one work-group per query selects from in one launch
 
+// Windows above 16 384 rows: S slices of L rows (a multiple of 64, <= 16 384), one work-group per (slice, query);
+// more slices than the window needs while the launch would leave CUs idle.
+struct SlicePlan {
+  int S, L;
+};
+bool plan_slices(int n_range, int nq, int K, SlicePlan* out) {
+  static const bool off = getenv("GLOC3D_KNN_NO_SLICES") != nullptr;  // developer switch: the chunked form
+  if (off) return false;
+  long long s = ((long long)n_range + SELQ_MAX_ROWS - 1) / SELQ_MAX_ROWS;
+  while (s * nq < 512 && n_range / (s * 2) >= 4096 && s * 2 * K <= SELQ_MAX_ROWS) s *= 2;
+  const int L = (int)((((long long)n_range + s - 1) / s + 63) & ~63ll);
+  const int S = (n_range + L - 1) / L;  // (no empty slice)
+  if ((long long)S * K > SELQ_MAX_ROWS || S > 65535) return false;  // the lists no longer fit one work-group's registers
+  *out = SlicePlan{S, L};
+  return true;
+}
+template <int MODE>
+int launch_slices(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
+                  int n_splits, const SlicePlan& sl, const int* only_flagged) {
+  GLOC_TRY(h->klists.ensure((size_t)nq * sl.S * K * sizeof(uint64_t), h->stream));
+  hipLaunchKernelGGL(select_slices_kernel<MODE>, dim3(sl.S, nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
+                     strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, h->norms.as<float>(), first, n_range, sl.L,
+                     K, h->klists.as<uint64_t>(), only_flagged);
+  GLOC_HIP(hipGetLastError());
+  return GLOC_OK;
+}
+
 template <int MODE>
 int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
                int n_splits, uint64_t* d_keys_out, const int* only_flagged = nullptr,
@@ -126,6 +154,17 @@ int run_select(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n
     hipLaunchKernelGGL(select_query_kernel<MODE>, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
                        strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, h->norms.as<float>(), first, n_range,
                        K, d_keys_out, only_flagged, fo);
+    GLOC_HIP(hipGetLastError());
+    if (finalized) *finalized = fo.idx != nullptr;
+    return GLOC_OK;
+  }
+  SlicePlan sl;
+  if (K <= 64 && !no_selq && plan_slices(n_range, nq, K, &sl)) {  // two launches: slices, then their lists
+    GLOC_TRY(launch_slices<MODE>(h, d_q, nq, K, first, n_range, ld, strideP, n_splits, sl, only_flagged));
+    hipLaunchKernelGGL(select_query_kernel<2>, dim3(nq), dim3(SELQ_THREADS), 0, h->stream,
+                       reinterpret_cast<const float*>(h->klists.as<uint64_t>()), (size_t)2 * sl.S * K, (size_t)0, 1,
+                       (float*)nullptr, (const float*)nullptr, (int)h->dim, (const float*)nullptr, (size_t)0, sl.S * K, K,
+                       d_keys_out, only_flagged, fo);
     GLOC_HIP(hipGetLastError());
     if (finalized) *finalized = fo.idx != nullptr;
     return GLOC_OK;
@@ -179,9 +218,32 @@ int run_exact(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_
 struct MfmaPlan {
   int WQ, NT, KS, BQ, BN;
   int t32 = 0;  // 1: the 32 x 32 x 2 tiles (dist_mfma32_kernel: BQ = 64, BN = 64 * NT)
+  int b3 = 0;   // 1: the split-bf16 form (dist_bf16x3_kernel: BQ = 64, BN = 64 * NT)
 };
 
-MfmaPlan plan_mfma(int nq, int n_range, int dim) {
+MfmaPlan plan_mfma(int nq, int n_range, int dim, bool fp32_only) {
+  // The split-bf16 coarse pass (round 4): the matrix cores stop being the bound, the rows' stream from HBM is.  Tiles of
+  // 64 queries x 128 rows when those alone fill the CUs twice, 64 rows otherwise; K split until ~512 work-groups.
+  static const bool no_b3 = getenv("GLOC3D_KNN_NO_BF16X3") != nullptr;  // developer switch
+  if (!fp32_only && !no_b3 && dim % 8 == 0 && dim >= 8) {
+    const int qblocks = (nq + 63) / 64;
+    int nt = ((long long)((n_range + 127) / 128) * qblocks >= 512) ? 2 : 1;
+    int ks = 1;
+    if (const char* e = getenv("GLOC3D_KNN_B3")) {  // developer override: "NT,KS"
+      int a = 0, b = 0;
+      if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2) && b >= 1 && b <= 16) nt = a, ks = -b;
+    }
+    const long long tiles = (long long)((n_range + 64 * nt - 1) / (64 * nt)) * qblocks;
+    if (ks < 0) {
+      ks = -ks;
+      while (ks > 1 && !((dim % (64 * ks)) == 0 && dim / ks >= 128)) ks /= 2;
+    } else {
+      while (tiles * ks < 512 && ks < 16 && (dim % (64 * ks * 2)) == 0 && dim / (ks * 2) >= 128) ks *= 2;
+    }
+    MfmaPlan b{4, nt, ks, 64, 64 * nt};
+    b.b3 = 1;
+    return b;
+  }
   MfmaPlan best{};
   double best_cost = 1e300;
   const int WQ = nq <= 16 ? 1 : (nq <= 32 ? 2 : 4);
@@ -257,9 +319,9 @@ void launch_mfma_inst(gloc_knn* h, const MfmaPlan& p, const float* d_q, int nq, 
 
 // *finalized: the result (indices, distances) has been written through `fo` already -- no finalize launch
 int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_range,
-             uint64_t* d_keys_out, const FinalOut& fo, bool* finalized) {
+             uint64_t* d_keys_out, const FinalOut& fo, bool* finalized, bool fp32_only) {
   *finalized = false;
-  const MfmaPlan p = plan_mfma(nq, n_range, (int)h->dim);
+  const MfmaPlan p = plan_mfma(nq, n_range, (int)h->dim, fp32_only);
   const int KC = std::max(h->candidates, std::min(64, k + 12));
   const size_t ld = ((size_t)n_range + 63) & ~(size_t)63;
   const size_t qpad = (size_t)((nq + p.BQ - 1) / p.BQ) * p.BQ;
@@ -272,7 +334,25 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     GLOC_TRY(h->n_incomplete.ensure(sizeof(unsigned long long), h->stream));
     GLOC_HIP(hipMemsetAsync(h->n_incomplete.p, 0, sizeof(unsigned long long), h->stream));
   }
-  if (p.t32) {
+  if (p.b3) {
+    {
+      ProfScope ps(h->prof, "split_queries", h->stream);
+      GLOC_TRY(h->qsplit.ensure((size_t)nq * h->dim * sizeof(float), h->stream));
+      const size_t n8 = (size_t)nq * h->dim / 8;
+      hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, h->stream, d_q, n8,
+                         h->qsplit.as<float>());
+    }
+    ProfScope ps(h->prof, "dist_mfma", h->stream);
+    dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
+    const int kps3 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+    if (p.NT == 1)
+      hipLaunchKernelGGL((dist_bf16x3_kernel<1>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), h->qsplit.as<float>(),
+                         h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, strideP);
+    else
+      hipLaunchKernelGGL((dist_bf16x3_kernel<2>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), h->qsplit.as<float>(),
+                         h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, strideP);
+    GLOC_HIP(hipGetLastError());
+  } else if (p.t32) {
     ProfScope ps(h->prof, "dist_mfma", h->stream);
     dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
     const int kps32 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
@@ -306,25 +386,44 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   const float u = 5.9604645e-8f;
   const int kps = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
   const float eps_rel_d = 1.05f * u * (float)(h->dim / 4 + 4);
-  const float eps_rel_n = 1.05f * u * (float)(64 + (kps + 63) / 64 + p.KS + h->dim / 64 + 6 + 3 + 4);
+  static const float eps_scale = getenv("GLOC3D_KNN_EPS_SCALE") ? (float)atof(getenv("GLOC3D_KNN_EPS_SCALE")) : 1.f;  // dev
+  //   split-bf16 form: the dropped product terms 3.03 * 2^-16 = 776 u (knn_kernels.hpp), and its chains are 3 x 64
+  //   products long with the accumulation inside an MFMA priced as truncating adds (2 u each): 384 for the 64
+  const float chain_u = p.b3 ? 776.f + 384.f : 64.f;
+  const float eps_rel_n = eps_scale * 1.05f * u * (chain_u + (float)((kps + 63) / 64 + p.KS + h->dim / 64 + 6 + 3 + 4));
   static const bool no_fused = getenv("GLOC3D_KNN_NO_FUSED_RERANK") != nullptr;  // developer switch: the three launches
-  const bool fused = n_range <= SELQ_MAX_ROWS && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
+  const bool large = n_range > SELQ_MAX_ROWS;  // slices first; an incomplete query is flagged for the host
+  SlicePlan sl{1, 0};
+  const bool fused = (!large || plan_slices(n_range, nq, KC, &sl)) && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
   if (fused) {
     // select + re-rank + completeness check in one launch, one work-group per query
+    if (large) {
+      ProfScope ps(h->prof, "select", h->stream);
+      GLOC_TRY(launch_slices<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, sl, nullptr));
+    }
     ProfScope ps(h->prof, "select_rerank", h->stream);
-    hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
-                       strideP, p.KS, d_q, (int)h->dim, h->norms.as<float>(), first, n_range, KC, k,
-                       h->rows.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n, h->qnorm.as<float>(),
-                       d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo, h->dist.as<float>(),
-                       h->dev_trace.as<unsigned long long>());
+#define SRR_ARGS                                                                                                          \
+  dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld, strideP, p.KS, d_q, (int)h->dim,                  \
+      h->norms.as<float>(), first, n_range, KC, k, h->rows.as<float>(), h->dn_max.as<uint32_t>(), eps_rel_d, eps_rel_n, \
+      h->qnorm.as<float>(), d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo,                \
+      h->dist.as<float>(), h->dev_trace.as<unsigned long long>()
+    if (large)
+      hipLaunchKernelGGL(select_rerank_kernel<true>, SRR_ARGS, h->klists.as<uint64_t>(), sl.S * KC);
+    else
+      hipLaunchKernelGGL(select_rerank_kernel<false>, SRR_ARGS, (const uint64_t*)nullptr, 0);
+#undef SRR_ARGS
     GLOC_HIP(hipGetLastError());
     // (incomplete queries -- rare -- are redone exactly by their own work-group inside the same launch: no
     // read-back, no host synchronisation, no further launch)
     h->stats.last_n_tile = (uint32_t)p.BN;
     h->stats.last_k_split = (uint32_t)p.KS;
     h->stats.last_candidates = (uint32_t)KC;
-    *finalized = fo.idx != nullptr;
-    return GLOC_OK;
+    if (!large) {
+      *finalized = fo.idx != nullptr;
+      return GLOC_OK;
+    }
+    // (large windows: on to the flags' read-back below; the keys are final unless a flagged query is redone, so the
+    // caller's finalize launch writes the result)
   } else {
   // (the query norms of the coarse form are made by the select kernel, which leaves them in h->qnorm)
   GLOC_TRY(run_select<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));
@@ -367,12 +466,15 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   GLOC_HIP(hipMemcpyAsync(h->h_flags, h->flags.p, sizeof(int) * (size_t)nq,
                           hipMemcpyDeviceToHost, h->stream));
   GLOC_HIP(hipStreamSynchronize(h->stream));
+  bool redone = false;
   for (int q = 0; q < nq; ++q) {
     if (h->h_flags[q]) {
       GLOC_TRY(run_exact(h, d_q + (size_t)q * h->dim, 1, k, first, n_range,
                          d_keys_out + (size_t)q * k));
+      redone = true;
     }
   }
+  if (fused && !redone) *finalized = fo.idx != nullptr;  // the fused kernel's own result stands
   return GLOC_OK;
 }
 
@@ -397,18 +499,19 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
     int algo = h->algo;
     const bool mfma_ok = (h->dim % 4 == 0) && k <= 52 && range >= 64;
     if (algo == GLOC_KNN_ALGO_AUTO) algo = (nq > 8 && mfma_ok) ? GLOC_KNN_ALGO_MFMA : GLOC_KNN_ALGO_EXACT;
-    if (algo == GLOC_KNN_ALGO_MFMA && !mfma_ok) algo = GLOC_KNN_ALGO_EXACT;
+    if ((algo == GLOC_KNN_ALGO_MFMA || algo == GLOC_KNN_ALGO_MFMA_FP32) && !mfma_ok) algo = GLOC_KNN_ALGO_EXACT;
     // process queries in blocks that bound the distance workspace (<= 2 GiB)
     const size_t ld = (range + 63) & ~(size_t)63;
     size_t qblk = (size_t)(2ull << 30) / (ld * sizeof(float) * 4);
     qblk = std::min<size_t>(1024, std::max<size_t>(64, qblk / 64 * 64));
     for (size_t q0 = 0; q0 < nq; q0 += qblk) {
       const int cnt = (int)std::min(qblk, nq - q0);
-      if (algo == GLOC_KNN_ALGO_MFMA) {
+      if (algo == GLOC_KNN_ALGO_MFMA || algo == GLOC_KNN_ALGO_MFMA_FP32) {
         h->stats.searches_mfma++;
         bool fin = false;
         const FinalOut fo{d_idx + q0 * k, d_d2 + q0 * k, index_offset, index_stride};
-        GLOC_TRY(run_mfma(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range, keys_out + q0 * k, fo, &fin));
+        GLOC_TRY(run_mfma(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range, keys_out + q0 * k, fo, &fin,
+                          algo == GLOC_KNN_ALGO_MFMA_FP32));
         all_final = all_final && fin;
       } else {
         h->stats.searches_exact++;
@@ -471,6 +574,7 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->exact.release();
   h->keys2.release();
   h->qnorm.release();
+  h->qsplit.release();
   h->dev_trace.release();
   h->flags.release();
   h->stage_q.release();
@@ -518,7 +622,7 @@ int gloc_knn_set_option(gloc_knn* h, int option, int64_t value) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   switch (option) {
     case GLOC_KNN_OPT_ALGO:
-      GLOC_REQUIRE(value >= 0 && value <= 2, GLOC_ERR_INVALID, "bad algorithm %lld", (long long)value);
+      GLOC_REQUIRE(value >= 0 && value <= 3, GLOC_ERR_INVALID, "bad algorithm %lld", (long long)value);
       h->algo = (int)value;
       return GLOC_OK;
     case GLOC_KNN_OPT_CANDIDATES:

@@ -565,6 +565,202 @@ __global__ __launch_bounds__(256) void dist_mfma32_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 (split-bf16 form; round 4): the partial dots on the bf16 matrix cores (16 x the fp32 MFMA rate), so that the
+// coarse pass is bound by the stream of the rows from HBM and not by v_mfma_f32_32x32x2_f32 (64 x 125 000 x 4096:
+// 417 us of fp32 MFMA at its peak against 256 us of HBM).  Every fp32 operand x is cut in two bf16 values on its way
+// into LDS, h = bf16(x) and m = bf16(x - h) (x - h is exact in fp32; both conversions round to nearest), and a
+// product is taken as  qh dh + qh dm + qm dh  -- three v_mfma_f32_32x32x16_bf16 (32 cycles each for K = 16) in place of
+// eight v_mfma_f32_32x32x2_f32 (64 cycles each).  What is dropped, qm dm + (q - qh - qm) d + (qh + qm)(d - dh - dm), is
+// at most 3.03 * 2^-16 |q_i| |d_i| per term (|x - h| <= 2^-8 |x|, |x - h - m| <= 2^-16 |x|): the coarse distance stays a
+// PROVEN approximation -- the bound is in knn.hip, the exact re-rank and the completeness proof are unchanged, and so
+// is every bit of the result.  Products of two bf16 values are exact in fp32; the accumulation inside an MFMA is
+// priced as K sequential truncating adds (two units in the last place each), flushed every 64 k as in the fp32 forms.
+// The queries are split once per search (split_queries_kernel: [q][k / 8][8 bf16 h | 8 bf16 m], the fp32 row's own
+// addressing); the rows are split by the work-group that streams them (3 VALU operations per element).
+// Work-group = 4 waves, 2 along the queries (64) x 2 along the rows (BN = 64 NT); LDS image [h | m][k / 8][row][16 B]:
+// one ds_read_b128 is a lane's whole K = 16 fragment half (lane l: row l % 32, k = 8 (l / 32) + j).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {  // round to nearest even; lo in bits 0..15
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void bf16_split2(float x0, float x1, uint32_t& h, uint32_t& m) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);  // exact
+  m = cvt_pk_bf16(r0, r1);
+}
+__device__ __forceinline__ void bf16_split8(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m) {
+  uint32_t h0, h1, h2, h3, m0, m1, m2, m3;
+  bf16_split2(a.x, a.y, h0, m0);
+  bf16_split2(a.z, a.w, h1, m1);
+  bf16_split2(b.x, b.y, h2, m2);
+  bf16_split2(b.z, b.w, h3, m3);
+  h = u32x4{h0, h1, h2, h3};
+  m = u32x4{m0, m1, m2, m3};
+}
+
+// out: [nq][dim / 8][8 floats' worth: 16 B of h, 16 B of m]; dim % 8 == 0
+__global__ __launch_bounds__(256) void split_queries_kernel(const float* __restrict__ q, size_t n8 /* nq * dim / 8 */,
+                                                            float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f4u a = *reinterpret_cast<const f4u*>(q + i * 8), b = *reinterpret_cast<const f4u*>(q + i * 8 + 4);
+  u32x4 h, m;
+  bf16_split8(f32x4{a.x, a.y, a.z, a.w}, f32x4{b.x, b.y, b.z, b.w}, h, m);
+  u32x4* o = reinterpret_cast<u32x4*>(out + i * 8);
+  o[0] = h;
+  o[1] = m;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void dist_bf16x3_kernel(const float* __restrict__ db,
+                                                          const float* __restrict__ qsplit /* split_queries_kernel */,
+                                                          float* __restrict__ P, int dim, size_t first_row, int n_range,
+                                                          int nq, int k_per_split, size_t ldP, size_t strideP) {
+  constexpr int BQ = 64;
+  constexpr int BN = 64 * NT;
+  constexpr int ROWS = BQ + BN;
+  constexpr int PLANE = ROWS + 1;  // 16-B slots per k / 8 plane
+  constexpr int BK = 32, KO = BK / 8;
+  constexpr int ND = BN * KO / 256;  // 8-float chunks of the rows per thread and step (the queries': exactly one)
+  static_assert(BQ * KO == 256, "the first 256 slots are the queries'");
+  __shared__ u32x4 lds[2 * 2 * KO * PLANE];  // [buffer][h | m][plane][row]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wq = w & 1, wn = w >> 1;
+  const int n0 = blockIdx.x * BN;
+  const int q0 = blockIdx.y * BQ;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
+
+  // slot = (row, plane): thread tid holds query row tid / KO and row chunks BQ + (tid + 256 i) / KO, plane tid % KO
+  const int ko8 = (tid % KO) * 8;
+  const int qrow = tid / KO;
+  const bool qv = q0 + qrow < nq;
+  const float* qsrc = qsplit + (size_t)(qv ? q0 + qrow : 0) * dim;
+  const float* dsrc[ND];  // never null: rows outside the window read its first row and are masked to zero
+  bool dv[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int jj = n0 + (tid + 256 * i) / KO;
+    dv[i] = jj < n_range;
+    dsrc[i] = db + (first_row + (size_t)(dv[i] ? jj : 0)) * dim;
+  }
+  struct Pre {
+    f32x4 q[2], d[ND][2];
+  };
+  auto gload = [&](Pre& pre, int k) {
+    const int kk = k + ko8;
+    const int kc = kk < dim - 8 ? kk : dim - 8;
+    const bool in = kk < kend;  // (kend - kbeg and dim are multiples of 8: a chunk is inside or outside as a whole)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f4u a = *reinterpret_cast<const f4u*>(qsrc + kc), b = *reinterpret_cast<const f4u*>(qsrc + kc + 4);
+      pre.q[0] = (qv && in) ? f32x4{a.x, a.y, a.z, a.w} : z;  // (bit patterns of bf16 pairs: +0 is all zero)
+      pre.q[1] = (qv && in) ? f32x4{b.x, b.y, b.z, b.w} : z;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const f4u a = *reinterpret_cast<const f4u*>(dsrc[i] + kc), b = *reinterpret_cast<const f4u*>(dsrc[i] + kc + 4);
+      pre.d[i][0] = (dv[i] && in) ? f32x4{a.x, a.y, a.z, a.w} : z;
+      pre.d[i][1] = (dv[i] && in) ? f32x4{b.x, b.y, b.z, b.w} : z;
+    }
+  };
+  auto lstore = [&](const Pre& pre, int buf) {
+    u32x4* Lh = lds + buf * 2 * KO * PLANE;
+    u32x4* Lm = Lh + KO * PLANE;
+    const int pl = (tid % KO) * PLANE;
+    Lh[pl + qrow] = __builtin_bit_cast(u32x4, pre.q[0]);
+    Lm[pl + qrow] = __builtin_bit_cast(u32x4, pre.q[1]);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      u32x4 h, m;
+      bf16_split8(pre.d[i][0], pre.d[i][1], h, m);
+      const int row = BQ + (tid + 256 * i) / KO;
+      Lh[pl + row] = h;
+      Lm[pl + row] = m;
+    }
+  };
+
+  f32x16 acc[NT], tot[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[t][r] = 0.f;
+      tot[t][r] = 0.f;
+    }
+  const int a_row = wq * 32 + (lane & 31);
+  const int b_row0 = BQ + wn * NT * 32 + (lane & 31);
+  auto compute = [&](int buf, int k) {
+    const u32x4* Lh = lds + buf * 2 * KO * PLANE;
+    const u32x4* Lm = Lh + KO * PLANE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int pl = (ks * 2 + (lane >> 5)) * PLANE;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, Lh[pl + a_row]), am = __builtin_bit_cast(bf16x8, Lm[pl + a_row]);
+      bf16x8 bh[NT], bm[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bh[t] = __builtin_bit_cast(bf16x8, Lh[pl + b_row0 + t * 32]);
+        bm[t] = __builtin_bit_cast(bf16x8, Lm[pl + b_row0 + t * 32]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+    }
+    if (((k - kbeg) & 32) || (k + BK) >= kend) {  // every 64 k and at the end: flush
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        tot[t] += acc[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      }
+    }
+  };
+
+  Pre preA, preB;
+  gload(preA, kbeg);
+  lstore(preA, 0);
+  gload(preA, kbeg + BK);
+  gload(preB, kbeg + 2 * BK);
+  __syncthreads();
+  for (int k = kbeg; k < kend; k += 2 * BK) {
+    compute(0, k);
+    if (k + BK < kend) {
+      lstore(preA, 1);
+      gload(preA, k + 3 * BK);
+      __syncthreads();
+      compute(1, k + BK);
+      if (k + 2 * BK < kend) {
+        lstore(preB, 0);
+        gload(preB, k + 4 * BK);
+        __syncthreads();
+      }
+    }
+  }
+  // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* Pz = P + (size_t)blockIdx.z * strideP;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = n0 + (wn * NT + t) * 32 + (lane & 31);
+    if (j < n_range) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Pz[(size_t)qq * ldP + j] = tot[t][r];  // rows q >= nq land in the padded part of P
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1 (top-k part): per-query top-K of a distance row, LDS-staged, in two kernels.
 //
 // select_chunk_kernel: grid (chunks, nq), 256 threads, E elements per thread (chunk = 256 E).
@@ -759,12 +955,18 @@ __device__ __forceinline__ float selq_select(const float* __restrict__ row, size
   // the loads of the keys' operands go out before the norm's reduction (one memory round trip, not two)
   // (split by split with every key slot's load issued before the first use: the first form walked the
   // splits inside the slot loop and waited for ten round trips in turn -- 6.5 us of a 14-us selection)
+  // MODE 2 (round 4): `row` holds n_range ready keys -- the slice lists of select_slices_kernel
   float dot[SELQ_EPT], dnv[SELQ_EPT];
+  uint64_t key[SELQ_EPT];
 #pragma unroll
   for (int e = 0; e < SELQ_EPT; ++e) {
     const int j = e * SELQ_THREADS + tid;
-    dot[e] = (j < n_range) ? row[j] : 0.f;
-    dnv[e] = (MODE == 1 && j < n_range) ? dn[first_row + (size_t)j] : 0.f;
+    if (MODE == 2) {
+      key[e] = (j < n_range) ? reinterpret_cast<const uint64_t*>(row)[j] : KEY_SENTINEL;
+    } else {
+      dot[e] = (j < n_range) ? row[j] : 0.f;
+      dnv[e] = (MODE == 1 && j < n_range) ? dn[first_row + (size_t)j] : 0.f;
+    }
   }
   if (MODE == 1) {
     if (n_splits > 1) {  // the usual second split rides in the first batch of loads
@@ -789,7 +991,7 @@ __device__ __forceinline__ float selq_select(const float* __restrict__ row, size
     }
   }
   float qnv = 0.f;
-  if (MODE == 1) {
+  if (MODE == 1 || (MODE == 2 && qr)) {  // (the same sum in every kernel that forms it: the same bits)
     float sq = 0.f;
     for (int d = tid; d < dim; d += SELQ_THREADS) sq += qr[d] * qr[d];
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -798,14 +1000,16 @@ __device__ __forceinline__ float selq_select(const float* __restrict__ row, size
     for (int i = 0; i < SELQ_THREADS / 64; ++i) qnv += qred[i];  // a fixed order, the same in every thread
   }
   // 1: keys and the thread minimum
-  uint64_t key[SELQ_EPT], mn = KEY_SENTINEL;
+  uint64_t mn = KEY_SENTINEL;
 #pragma unroll
   for (int e = 0; e < SELQ_EPT; ++e) {
     const int j = e * SELQ_THREADS + tid;
-    key[e] = KEY_SENTINEL;
-    if (j < n_range) {
-      const float d = (MODE == 1) ? (qnv + dnv[e]) - 2.f * dot[e] : dot[e];  // as select_key<MODE>
-      key[e] = make_key(d, (uint32_t)(first_row + (size_t)j));
+    if (MODE != 2) {
+      key[e] = KEY_SENTINEL;
+      if (j < n_range) {
+        const float d = (MODE == 1) ? (qnv + dnv[e]) - 2.f * dot[e] : dot[e];  // as select_key<MODE>
+        key[e] = make_key(d, (uint32_t)(first_row + (size_t)j));
+      }
     }
     mn = key[e] < mn ? key[e] : mn;
   }
@@ -873,13 +1077,39 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_query_kernel(
   const int tid = threadIdx.x;
   const int q = blockIdx.x;
   if (only_flagged && !only_flagged[q]) return;  // uniform over the work-group
-  const float qnv = selq_select<MODE>(dist + (size_t)q * ld, strideP, n_splits, queries + (size_t)q * dim, dim, dn,
-                                      first_row, n_range, K, buf, qred, &tau_s, &cnt);
+  const float qnv = selq_select<MODE>(dist + (size_t)q * ld, strideP, n_splits,
+                                      MODE == 2 ? nullptr : queries + (size_t)q * dim, dim, dn, first_row, n_range, K,
+                                      buf, qred, &tau_s, &cnt);
   if (MODE == 1 && tid == 0) qn[q] = qnv;
   if (tid < K) {
     out_keys[(size_t)q * K + tid] = buf[tid];
     final_store(fo, (size_t)q * K + tid, buf[tid]);
   }
+}
+
+// Windows above 16 384 rows (round 4; they went through select_chunk_kernel's 256-thread LDS sorts + a merge before:
+// 108 us of a 800-us search over a 125 000-row shard): the window is cut in S slices of L <= 16 384 rows, one
+// work-group per (slice, query) leaves the slice's K smallest keys, and the selection over the S x K keys (MODE 2
+// above: select_query_kernel<2>, or select_rerank_kernel<true>) ends the search.  The K smallest keys of the window
+// are among the slices' K smallest, and keys are distinct (the row is part of the key): the same result.
+template <int MODE>
+__global__ __launch_bounds__(SELQ_THREADS) void select_slices_kernel(
+    const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits, float* __restrict__ qn,
+    const float* __restrict__ queries, int dim, const float* __restrict__ dn, size_t first_row, int n_range, int L, int K,
+    uint64_t* __restrict__ lists /* [nq][S][K] */, const int* __restrict__ only_flagged) {
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.y, sl = blockIdx.x, S = gridDim.x;
+  if (only_flagged && !only_flagged[q]) return;  // uniform over the work-group
+  const int j0 = sl * L;
+  const int n = n_range - j0 < L ? n_range - j0 : L;  // >= 1: the host drops empty slices
+  const float qnv = selq_select<MODE>(dist + (size_t)q * ld + j0, strideP, n_splits, queries + (size_t)q * dim, dim, dn,
+                                      first_row + (size_t)j0, n, K, buf, qred, &tau_s, &cnt);
+  if (MODE == 1 && sl == 0 && tid == 0) qn[q] = qnv;
+  if (tid < K) lists[((size_t)q * S + sl) * K + tid] = buf[tid];
 }
 
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
@@ -1157,13 +1387,15 @@ __device__ __forceinline__ void srr_fallback_exact(const float* __restrict__ db,
   }
 }
 
+template <bool LISTS /* the candidates come from n_list ready keys per query (select_slices_kernel), not from P */>
 __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     const float* __restrict__ P, size_t ld, size_t strideP, int n_splits, const float* __restrict__ queries,
     int dim, const float* __restrict__ dn, size_t first_row, int n_range, int KC, int k,
     const float* __restrict__ db, const uint32_t* __restrict__ dn_max_bits, float eps_rel_d, float eps_rel_n,
     float* __restrict__ qn_out, uint64_t* __restrict__ out_keys /* [nq][k] */, int* __restrict__ flags,
     unsigned long long* __restrict__ n_incomplete, FinalOut fo, float* __restrict__ dist_scratch /* = P: row q of split 0 is this query's */,
-    unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */) {
+    unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */,
+    const uint64_t* __restrict__ lists = nullptr, int n_list = 0) {
   const unsigned long long t_start = dev_trace ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ uint64_t buf[SEL_LIST];
   __shared__ float qred[SELQ_THREADS / 64];
@@ -1175,8 +1407,13 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = blockIdx.x;
   const float* qp = queries + (size_t)q * dim;
-  const float qnv = selq_select<1>(P + (size_t)q * ld, strideP, n_splits, qp, dim, dn, first_row, n_range, KC, buf,
-                                   qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
+  float qnv;
+  if constexpr (LISTS)
+    qnv = selq_select<2>(reinterpret_cast<const float*>(lists + (size_t)q * n_list), 0, 1, qp, dim, dn, 0, n_list, KC, buf,
+                         qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
+  else
+    qnv = selq_select<1>(P + (size_t)q * ld, strideP, n_splits, qp, dim, dn, first_row, n_range, KC, buf,
+                         qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
   if (tid == 0) qn_out[q] = qnv;
   if (dev_trace && tid == 0) {
     dev_trace[q * 16 + 0] = t_start;
@@ -1228,6 +1465,9 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
       }
     }
   }
+  // (a window above 16 384 rows is not searched exactly by ONE work-group -- 16 GB through one CU at a million rows: the
+  // flag goes to the host, which redoes the query on the exact path, knn.hip)
+  if constexpr (!LISTS)
   if (!complete)  // uniform over the work-group (every wave computed the same proof)
     srr_fallback_exact(db, qp, dim, first_row, n_range, k, dist_scratch + (size_t)q * ld, buf, qred, &tau_s, &cnt, S, exact_s,
                        rows_s, out_keys + (size_t)q * k, fo, (size_t)q * k);

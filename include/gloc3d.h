@@ -55,7 +55,11 @@ typedef struct gloc_knn gloc_knn;
 enum {
   GLOC_KNN_ALGO_AUTO = 0,  /* exact streaming kernel for few queries, MFMA path otherwise */
   GLOC_KNN_ALGO_EXACT = 1, /* reference-order fp32 differences on the vector ALUs, one pass */
-  GLOC_KNN_ALGO_MFMA = 2   /* fp32-MFMA -2Q.D^T + norms, LDS top-k', exact re-rank, verified */
+  GLOC_KNN_ALGO_MFMA = 2,  /* matrix-core coarse pass -2Q.D^T + norms (operands split in two bf16 values, three bf16
+                              MFMAs per product -- a proven bound on what that drops; fp32 MFMA when dim % 8 != 0),
+                              top-k' selection, exact re-rank in the reference's order, completeness proven per query
+                              (an unproven query is redone on the exact path): the same bits as GLOC_KNN_ALGO_EXACT */
+  GLOC_KNN_ALGO_MFMA_FP32 = 3 /* the same with the coarse pass on the fp32 MFMA (the rounds 1 - 3 form) */
 };
 enum {
   GLOC_KNN_OPT_ALGO = 1,

@@ -30,7 +30,7 @@ def test_matches_reference_goldens(capi, case, algo):
     ix.close()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("N,D,Q,k", [(1, 8, 1, 1), (63, 4, 2, 5), (100, 7, 3, 20), (257, 510, 9, 20),
                                      (1000, 96, 17, 20), (2049, 33, 33, 1), (3000, 256, 70, 50),
                                      (5000, 1024, 130, 20)])
@@ -46,7 +46,7 @@ def test_ragged_shapes_vs_oracle(capi, oracle_mod, algo, N, D, Q, k):
     ix.close()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_window_empty_and_short(capi, oracle_mod, algo):
     from gloc3d_amd import synth
     db = synth.descriptors_traj(7, 0, 400, 128)
@@ -61,7 +61,7 @@ def test_window_empty_and_short(capi, oracle_mod, algo):
     ix.close()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_duplicates_in_index_order_and_incremental_add(capi, oracle_mod, algo):
     from gloc3d_amd import synth
     db = synth.descriptors_iid(8, 0, 900, 64)
@@ -304,7 +304,7 @@ def test_save_load_round_trip(capi, oracle_mod, tmp_path):
     c.close()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("N,D,Q,k", [(16384, 64, 12, 20), (16385, 64, 12, 20), (12000, 100, 20, 52), (40, 4096, 10, 20)])
 def test_one_work_group_per_query_select_limits(capi, oracle_mod, algo, N, D, Q, k):
     """The one-launch selection (<= 16384 rows, <= 64 keys) at its limits, one row past them (chunked form),
@@ -319,7 +319,7 @@ def test_one_work_group_per_query_select_limits(capi, oracle_mod, algo, N, D, Q,
     ix.close()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_select_with_near_rows_on_few_threads(capi, oracle_mod, algo):
     """Rows j with j % 1024 < 4 lie near the query: four of the selecting work-group's 1024 threads hold all the
     small keys, so more than 64 keys pass the threshold of thread minima (the list is sorted through LDS then);
@@ -338,5 +338,27 @@ def test_select_with_near_rows_on_few_threads(capi, oracle_mod, algo):
     for k in (20, 33):
         idx, d2 = ix.search(q, k, first, N)
         oi, od = oracle_mod.knn_search(db, q, k, first, N)
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("N,first,Q", [(40001, 13, 9), (70000, 0, 1), (33000, 5000, 40)])
+def test_sliced_select_above_16384_rows(capi, oracle_mod, algo, N, first, Q):
+    """Windows above 16 384 rows (slices of <= 16 384 rows, then the selection over the slices' lists): a window that
+    does not start at 0, a ragged last slice, the near rows of query 0 crowded into ONE slice (all its k results come
+    from one list) and duplicated rows on both sides of a slice boundary (ties by row index across lists)."""
+    from gloc3d_amd import synth
+    D = 64
+    db = synth.descriptors_iid(61, 0, N, D)
+    q = synth.descriptors_iid(62, 0, Q, D)
+    near = first + 100 + np.arange(40)                      # 40 near rows, all in the first slice
+    db[near] = (q[0][None, :] + np.float32(0.02) * synth.descriptors_iid(63, 0, 40, D)).astype(np.float32)
+    for j in (first + 4000, first + 9000, first + 17000, N - 2):         # the same row in several slices
+        db[j] = db[near[3]]
+    ix = _index(capi, db, algo)
+    for k in (1, 20, 52):
+        idx, d2 = ix.search(q, k, first, N)
+        oi, od = oracle_mod.knn_search(db, q, k, first, N, threads=4)
         assert (idx == oi).all() and (bits(d2) == bits(od)).all()
     ix.close()

@@ -23,6 +23,10 @@ ix.synchronize(); dt = (time.time() - t) / a.reps
 flop = 2.0 * a.q * a.n * a.d; byt = 4.0 * (a.n * a.d + a.q * a.d)
 print(f"kNN {a.q}x{a.n}x{a.d} k={a.k} algo={a.algo}: {dt*1e6:.1f} us/search (wall, device resident) -> {a.q/dt:.0f} queries/s; "
       f"whole-search {flop/dt/1e12:.1f} TFLOP/s, {byt/dt/1e12:.2f} TB/s; stats {ix.stats()}")
+if os.environ.get("GLOC3D_KNN_PROF"):  # dev: per-stage device time (HIP events around the stages, below the C ABI)
+    ix.set_option(capi.KNN_OPT_PROFILE, 1); ix.profile_reset()
+    for _ in range(10): ix.search_device(q.data_ptr(), a.q, a.k, idx.data_ptr(), d2.data_ptr())
+    print("stage us:", {n: round(ix.profile(n)[0] / 10 * 1e3, 1) for n in ("norms", "dist_mfma", "dist_exact", "select", "select_rerank", "rerank", "finalize")})
 if os.environ.get("GLOC3D_KNN_TRACE"):  # dev: phase stamps of the fused select + re-rank kernel (s_memtime ticks)
     import ctypes as C
     L = capi.lib(); f = L.gloc_knn_debug_trace; f.restype = C.c_int

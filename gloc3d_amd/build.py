@@ -18,6 +18,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("GLOC3D_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# knn.hip: MFMA accumulators in architectural VGPRs -- the split-bf16 distance kernel adds its accumulators to running
+# totals every 64 k, and from AGPRs that is a v_accvgpr_read per register and step (measured: 121 of the main loop's
+# ~330 vector instructions); without AGPRs the kernel also fits three work-groups per CU (161 registers, not 192)
+PER_SOURCE = {"knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(out, deps):
@@ -37,7 +41,7 @@ def build(force=False, verbose=False):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + PER_SOURCE.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -96,7 +96,8 @@ int launch_dist_exact(gloc_knn* h, const float* d_q, int nq, size_t first, int n
   while (RW > 4 && (long long)((n_range + RW - 1) / RW) * qgroups < 2048) RW >>= 1;
   if (RW < 4) RW = 4;
   const unsigned gx = (unsigned)((n_range + 4 * RW - 1) / (4 * RW));
-  dim3 grid(gx, (unsigned)qgroups), block(256);
+  // (the flagged pass over a large window: y = 1, every work-group walks the flags)
+  dim3 grid(gx, (only_flagged && (long long)gx * qgroups > 4096) ? 1u : (unsigned)qgroups), block(256);
   float* dist = h->dist.as<float>();
   const float* db = h->rows.as<float>();
 #define LAUNCH_EXACT(QT_)                                                                      \
@@ -136,9 +137,20 @@ template <int MODE>
 int launch_slices(gloc_knn* h, const float* d_q, int nq, int K, size_t first, int n_range, size_t ld, size_t strideP,
                   int n_splits, const SlicePlan& sl, const int* only_flagged) {
   GLOC_TRY(h->klists.ensure((size_t)nq * sl.S * K * sizeof(uint64_t), h->stream));
-  hipLaunchKernelGGL(select_slices_kernel<MODE>, dim3(sl.S, nq), dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld,
-                     strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, h->norms.as<float>(), first, n_range, sl.L,
-                     K, h->klists.as<uint64_t>(), only_flagged);
+  // (the flagged pass: y = 1, every work-group walks the flags)
+#define SLICES_ARGS                                                                                                 \
+  dim3(SELQ_THREADS), 0, h->stream, h->dist.as<float>(), ld, strideP, n_splits, h->qnorm.as<float>(), d_q, (int)h->dim, \
+      h->norms.as<float>(), first, n_range, sl.L, K, h->klists.as<uint64_t>(), only_flagged, nq
+  if constexpr (MODE == 0) {  // (only the exact pass is ever launched for flagged queries)
+    if (only_flagged)
+      hipLaunchKernelGGL((select_slices_kernel<0, true>), dim3(sl.S, 1), SLICES_ARGS);
+    else
+      hipLaunchKernelGGL((select_slices_kernel<0, false>), dim3(sl.S, nq), SLICES_ARGS);
+  } else {
+    GLOC_REQUIRE(!only_flagged, GLOC_ERR_STATE, "internal: flagged selection of coarse distances");
+    hipLaunchKernelGGL((select_slices_kernel<MODE, false>), dim3(sl.S, nq), SLICES_ARGS);
+  }
+#undef SLICES_ARGS
   GLOC_HIP(hipGetLastError());
   return GLOC_OK;
 }
@@ -335,22 +347,50 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     GLOC_HIP(hipMemsetAsync(h->n_incomplete.p, 0, sizeof(unsigned long long), h->stream));
   }
   if (p.b3) {
-    {
+    // few work-groups: each splits its queries itself; many: once, ahead of the launch
+    dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
+    static const int qraw_env = getenv("GLOC3D_KNN_B3_QRAW") ? atoi(getenv("GLOC3D_KNN_B3_QRAW")) : -1;  // developer switch
+    const bool qraw = qraw_env >= 0 ? qraw_env != 0 : (long long)grid.x * grid.y * grid.z <= 1024;
+    const float* qsrc = d_q;
+    if (!qraw) {
       ProfScope ps(h->prof, "split_queries", h->stream);
       GLOC_TRY(h->qsplit.ensure((size_t)nq * h->dim * sizeof(float), h->stream));
       const size_t n8 = (size_t)nq * h->dim / 8;
       hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, h->stream, d_q, n8,
                          h->qsplit.as<float>());
+      qsrc = h->qsplit.as<float>();
     }
     ProfScope ps(h->prof, "dist_mfma", h->stream);
-    dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
     const int kps3 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
-    if (p.NT == 1)
-      hipLaunchKernelGGL((dist_bf16x3_kernel<1>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), h->qsplit.as<float>(),
-                         h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, strideP);
-    else
-      hipLaunchKernelGGL((dist_bf16x3_kernel<2>), grid, dim3(256), 0, h->stream, h->rows.as<float>(), h->qsplit.as<float>(),
-                         h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, strideP);
+    static const int ko_env = getenv("GLOC3D_KNN_B3_KO") ? atoi(getenv("GLOC3D_KNN_B3_KO")) : 0;  // developer switch: 4 or 8
+    const int ko = (ko_env == 4 || ko_env == 8) ? ko_env : 4;
+    static const int phase = getenv("GLOC3D_KNN_B3_PHASE") ? atoi(getenv("GLOC3D_KNN_B3_PHASE")) : 5;  // developer switch
+#define B3(NT_, QR_, KO_)                                                                                             \
+  do {                                                                                                                \
+    constexpr int lds_bytes = b3_lds_bytes<NT_, KO_>();                                                               \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set && lds_bytes > 48 * 1024) {                                                                         \
+      GLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_bf16x3_kernel<NT_, QR_, KO_>),                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                          \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((dist_bf16x3_kernel<NT_, QR_, KO_>), grid, dim3(256), lds_bytes, h->stream,                    \
+                       h->rows.as<float>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld,     \
+                       strideP, phase);                                                                               \
+  } while (0)
+#define B3Q(NT_, KO_)          \
+  do {                         \
+    if (qraw)                  \
+      B3(NT_, true, KO_);      \
+    else                       \
+      B3(NT_, false, KO_);     \
+  } while (0)
+    if (p.NT == 1 && ko == 4) B3Q(1, 4);
+    else if (p.NT == 1) B3Q(1, 8);
+    else if (ko == 4) B3Q(2, 4);
+    else B3Q(2, 8);
+#undef B3Q
+#undef B3
     GLOC_HIP(hipGetLastError());
   } else if (p.t32) {
     ProfScope ps(h->prof, "dist_mfma", h->stream);
@@ -447,16 +487,27 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   h->stats.last_n_tile = (uint32_t)p.BN;
   h->stats.last_k_split = (uint32_t)p.KS;
   h->stats.last_candidates = (uint32_t)KC;
-  if (n_range <= SELECT_ONE_BLOCK_MAX && k <= 2048 / std::max(1, (n_range + 255) / 256)) {
-    // Incomplete queries are redone on the exact path ON THE DEVICE: the two kernels are always
-    // launched and leave at once unless the query's flag is set -- no read-back, no host synchronisation.
+  SlicePlan fb_sl;
+  if ((n_range <= SELECT_ONE_BLOCK_MAX && k <= 2048 / std::max(1, (n_range + 255) / 256)) ||
+      (k <= 64 && plan_slices(n_range, nq, k, &fb_sl))) {
+    // Incomplete queries are redone on the exact path ON THE DEVICE: the kernels are always
+    // launched and leave at once unless the query's flag is set -- no read-back, no host synchronisation
+    // (windows above 16 384 rows too since round 4: the read-back of the flags stalled the launches of a run of searches
+    // behind a host synchronisation, ~35 us of a 460-us search over a 125 000-row shard).
     // (The coarse partial dots in h->dist are dead by now: the exact distances of the flagged queries
     // reuse the buffer, row q at q * ld.)
     GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld, h->flags.as<int>()));
-    GLOC_TRY(run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out, h->flags.as<int>()));
+    if (fused && large) {  // the fused kernel has written the result through `fo`: the flagged queries' is replaced
+      bool fin = false;
+      GLOC_TRY(run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out, h->flags.as<int>(), fo, &fin));
+      *finalized = fo.idx != nullptr;
+    } else {
+      GLOC_TRY(run_select<0>(h, d_q, nq, k, first, n_range, ld, 0, 1, d_keys_out, h->flags.as<int>()));
+    }
     return GLOC_OK;
   }
-  // large windows: completeness flags -> host; incomplete queries are redone on the exact path
+  // windows too large for that (the slices' lists no longer fit one work-group): completeness flags -> host;
+  // incomplete queries are redone on the exact path
   if (h->h_flags_cap < (size_t)nq) {
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     h->h_flags = nullptr;

@@ -9,6 +9,7 @@
 // groups of four differences, ((d0^2 + d1^2) + d2^2) + d3^2, added sequentially over d, scalar tail,
 // no FMA contraction (this translation unit is compiled with -ffp-contract=off).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -156,19 +157,33 @@ __global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* S = S_all + w * 64 * S_PITCH;
   const int row0 = (blockIdx.x * 4 + w) * RW;  // relative to first_row
-  const int q0 = blockIdx.y * QT;
-  if (only_flagged && !only_flagged[q0]) return;  // uniform over the work-group
-  const int nvq = (nq - q0) < QT ? (nq - q0) : QT;
   auto row_of = [&](int r) -> long long {
     const int rr = row0 + r;
     return rr < n_range ? (long long)(first_row + (size_t)rr) : -1;
   };
-  const float acc =
-      exact_pairs_wave<QT>(db, queries + (size_t)q0 * dim, dim, RW, row_of, nvq, S);
-  if (lane < QT * RW) {
-    const int t = lane / RW, r = lane % RW;
-    if (t < nvq && row0 + r < n_range) dist[(size_t)(q0 + t) * ld + (size_t)(row0 + r)] = acc;
+  // (the grid's y may be shorter than the query groups: the flagged pass over a large window is launched with y = 1
+  // and walks the flags -- a work-group per (row tile, query) that leaves at once is 31 000 dispatches at 64 x 125 000)
+  auto one = [&](int q0) {
+    const int nvq = (nq - q0) < QT ? (nq - q0) : QT;
+    const float acc =
+        exact_pairs_wave<QT>(db, queries + (size_t)q0 * dim, dim, RW, row_of, nvq, S);
+    if (lane < QT * RW) {
+      const int t = lane / RW, r = lane % RW;
+      if (t < nvq && row0 + r < n_range) dist[(size_t)(q0 + t) * ld + (size_t)(row0 + r)] = acc;
+    }
+  };
+  if (only_flagged && gridDim.y == 1 && QT == 1) {  // the walk: 256 flags per round trip, usually none set
+    for (int base = 0; base < nq; base += 256) {
+      const int f = (base + (int)threadIdx.x < nq) ? only_flagged[base + threadIdx.x] : 0;
+      if (!__syncthreads_or(f)) continue;
+      for (int q0 = base; q0 < nq && q0 < base + 256; ++q0)
+        if (only_flagged[q0]) one(q0);  // uniform over the work-group
+    }
+    return;
   }
+  const int q0 = blockIdx.y * QT;
+  if (only_flagged && !only_flagged[q0]) return;  // uniform over the work-group
+  one(q0);
 }
 
 // K1 (exact form, few queries -- the reference's own pattern: kdtree_->query one descriptor at a time,
@@ -615,19 +630,31 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const float* __restr
   o[1] = m;
 }
 
-template <int NT>
+// QRAW: `qsplit` holds the fp32 queries themselves and the work-group splits them as it does the rows (a launch of few
+// work-groups: cheaper than the split kernel's launch ahead of it).
+// KO: planes of 8 k per step (4: steps of 32 k, 128 contiguous bytes of a row per step; 8: steps of 64 k, 256 bytes).
+// LDS is dynamic: 2 buffers x [h | m] x KO planes x PLANE slots of 16 B.
+template <int NT, int KO>
+constexpr int b3_lds_bytes() {
+  return 2 * 2 * KO * (64 + 64 * NT + 2) * 16;
+}
+template <int NT, bool QRAW, int KO>
 __global__ __launch_bounds__(256) void dist_bf16x3_kernel(const float* __restrict__ db,
                                                           const float* __restrict__ qsplit /* split_queries_kernel */,
                                                           float* __restrict__ P, int dim, size_t first_row, int n_range,
-                                                          int nq, int k_per_split, size_t ldP, size_t strideP) {
+                                                          int nq, int k_per_split, size_t ldP, size_t strideP,
+                                                          int phase /* groups of 64 k per row tile, 0: none */) {
   constexpr int BQ = 64;
   constexpr int BN = 64 * NT;
   constexpr int ROWS = BQ + BN;
-  constexpr int PLANE = ROWS + 1;  // 16-B slots per k / 8 plane
-  constexpr int BK = 32, KO = BK / 8;
-  constexpr int ND = BN * KO / 256;  // 8-float chunks of the rows per thread and step (the queries': exactly one)
-  static_assert(BQ * KO == 256, "the first 256 slots are the queries'");
-  __shared__ u32x4 lds[2 * 2 * KO * PLANE];  // [buffer][h | m][plane][row]
+  // 16-B slots per k / 8 plane, = 2 mod 8: the eight lanes of a ds_write_b128 group (two rows x four planes) fall on
+  // eight different slots of the 128-B bank row (PLANE = ROWS + 1: two-way, a third of all LDS cycles by the counters)
+  constexpr int PLANE = ROWS + 2;
+  constexpr int BK = 8 * KO;
+  static_assert(KO == 4 || KO == 8, "steps of 32 or 64 k");
+  constexpr int NQ = BQ * KO / 256;  // 8-float chunks per thread and step: of the queries,
+  constexpr int ND = BN * KO / 256;  // of the rows
+  extern __shared__ u32x4 lds[];     // [buffer][h | m][plane][row]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wq = w & 1, wn = w >> 1;
@@ -635,69 +662,95 @@ __global__ __launch_bounds__(256) void dist_bf16x3_kernel(const float* __restric
   const int q0 = blockIdx.y * BQ;
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
+  // Every work-group starts its walk over k at another group of 64 k and wraps around (rows are 16 KB apart: work-groups
+  // that walk in step ask for the same offset of every row at the same time, and the addresses of one moment differ in
+  // their upper bits only -- measured with loads alone: 5.5 TB/s in step, 6.4 TB/s out of step).  The groups' sums are
+  // added in the rotated order: the same number of additions, the same bound.  (Only when the split is whole groups.)
+  const int klen = kend - kbeg;
+  const int rot = (phase > 0 && klen % 64 == 0) ? (int)(((unsigned)blockIdx.x * (unsigned)phase) % (unsigned)(klen / 64)) * 64 : 0;
 
-  // slot = (row, plane): thread tid holds query row tid / KO and row chunks BQ + (tid + 256 i) / KO, plane tid % KO
+  // slot = (row, plane): thread tid holds plane tid % KO of the tile rows (tid + 256 i) / KO -- queries first
   const int ko8 = (tid % KO) * 8;
-  const int qrow = tid / KO;
-  const bool qv = q0 + qrow < nq;
-  const float* qsrc = qsplit + (size_t)(qv ? q0 + qrow : 0) * dim;
-  const float* dsrc[ND];  // never null: rows outside the window read its first row and are masked to zero
-  bool dv[ND];
+  const float* qsrc[NQ];  // never null: rows outside the window (queries past nq) read the first one
+  const float* dsrc[ND];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int qq = q0 + (tid + 256 * i) / KO;
+    qsrc[i] = qsplit + (size_t)(qq < nq ? qq : 0) * dim;
+  }
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     const int jj = n0 + (tid + 256 * i) / KO;
-    dv[i] = jj < n_range;
-    dsrc[i] = db + (first_row + (size_t)(dv[i] ? jj : 0)) * dim;
+    dsrc[i] = db + (first_row + (size_t)(jj < n_range ? jj : 0)) * dim;
   }
   struct Pre {
-    f32x4 q[2], d[ND][2];
+    f32x4 q[NQ][2], d[ND][2];
   };
+  // (the loads are left raw -- no select on a loaded value before its stage is stored, or the wait for it lands right
+  // behind the load and the two stages in flight are none: rows outside the window compute garbage nobody stores, and
+  // the chunks that can lie beyond kend, when the split's length is no multiple of the step, are zeroed at the store)
   auto gload = [&](Pre& pre, int k) {
-    const int kk = k + ko8;
+    int kr = k + rot;  // (steps never straddle the wrap: rot and the steps are multiples of the step)
+    kr = kr >= kend ? kr - klen : kr;
+    const int kk = kr + ko8;
     const int kc = kk < dim - 8 ? kk : dim - 8;
-    const bool in = kk < kend;  // (kend - kbeg and dim are multiples of 8: a chunk is inside or outside as a whole)
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    {
-      const f4u a = *reinterpret_cast<const f4u*>(qsrc + kc), b = *reinterpret_cast<const f4u*>(qsrc + kc + 4);
-      pre.q[0] = (qv && in) ? f32x4{a.x, a.y, a.z, a.w} : z;  // (bit patterns of bf16 pairs: +0 is all zero)
-      pre.q[1] = (qv && in) ? f32x4{b.x, b.y, b.z, b.w} : z;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const f4u a = *reinterpret_cast<const f4u*>(qsrc[i] + kc), b = *reinterpret_cast<const f4u*>(qsrc[i] + kc + 4);
+      pre.q[i][0] = f32x4{a.x, a.y, a.z, a.w};
+      pre.q[i][1] = f32x4{b.x, b.y, b.z, b.w};
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const f4u a = *reinterpret_cast<const f4u*>(dsrc[i] + kc), b = *reinterpret_cast<const f4u*>(dsrc[i] + kc + 4);
-      pre.d[i][0] = (dv[i] && in) ? f32x4{a.x, a.y, a.z, a.w} : z;
-      pre.d[i][1] = (dv[i] && in) ? f32x4{b.x, b.y, b.z, b.w} : z;
+      pre.d[i][0] = f32x4{a.x, a.y, a.z, a.w};
+      pre.d[i][1] = f32x4{b.x, b.y, b.z, b.w};
     }
   };
-  auto lstore = [&](const Pre& pre, int buf) {
+  auto lstore = [&](const Pre& pre, int buf, int k) {
     u32x4* Lh = lds + buf * 2 * KO * PLANE;
     u32x4* Lm = Lh + KO * PLANE;
     const int pl = (tid % KO) * PLANE;
-    Lh[pl + qrow] = __builtin_bit_cast(u32x4, pre.q[0]);
-    Lm[pl + qrow] = __builtin_bit_cast(u32x4, pre.q[1]);
+    const bool tail = k + BK > kend;             // uniform
+    const bool out = tail && k + ko8 >= kend;    // (kend - kbeg and dim are multiples of 8: a chunk is in or out whole)
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int row = (tid + 256 * i) / KO;
+      if constexpr (QRAW) {
+        u32x4 h, m;
+        bf16_split8(pre.q[i][0], pre.q[i][1], h, m);
+        Lh[pl + row] = out ? z : h;
+        Lm[pl + row] = out ? z : m;
+      } else {
+        Lh[pl + row] = out ? z : __builtin_bit_cast(u32x4, pre.q[i][0]);
+        Lm[pl + row] = out ? z : __builtin_bit_cast(u32x4, pre.q[i][1]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       u32x4 h, m;
       bf16_split8(pre.d[i][0], pre.d[i][1], h, m);
       const int row = BQ + (tid + 256 * i) / KO;
-      Lh[pl + row] = h;
-      Lm[pl + row] = m;
+      Lh[pl + row] = out ? z : h;
+      Lm[pl + row] = out ? z : m;
     }
   };
 
+  // acc: the chain of one group of 64 k (its first MFMA takes a literal zero as C: nothing to clear), added to tot at the
+  // group's end.  The loop below walks two steps per turn, buffer 0 then buffer 1: with steps of 32 k buffer 0 opens
+  // a group and buffer 1 ends it; with steps of 64 k every step is a group.
   f32x16 acc[NT], tot[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc[t][r] = 0.f;
-      tot[t][r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) tot[t][r] = 0.f;
   const int a_row = wq * 32 + (lane & 31);
   const int b_row0 = BQ + wn * NT * 32 + (lane & 31);
-  auto compute = [&](int buf, int k) {
+  auto compute = [&](int buf, auto opens) {
     const u32x4* Lh = lds + buf * 2 * KO * PLANE;
     const u32x4* Lm = Lh + KO * PLANE;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int pl = (ks * 2 + (lane >> 5)) * PLANE;
@@ -709,41 +762,42 @@ __global__ __launch_bounds__(256) void dist_bf16x3_kernel(const float* __restric
         bm[t] = __builtin_bit_cast(bf16x8, Lm[pl + b_row0 + t * 32]);
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[t], (decltype(opens)::value && ks == 0) ? zero : acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[t], acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
     }
-    if (((k - kbeg) & 32) || (k + BK) >= kend) {  // every 64 k and at the end: flush
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        tot[t] += acc[t];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      }
-    }
   };
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tot[t] += acc[t];
+  };
+  constexpr bool STEP_IS_GROUP = BK == 64;
 
   Pre preA, preB;
   gload(preA, kbeg);
-  lstore(preA, 0);
+  lstore(preA, 0, kbeg);
   gload(preA, kbeg + BK);
   gload(preB, kbeg + 2 * BK);
   __syncthreads();
   for (int k = kbeg; k < kend; k += 2 * BK) {
-    compute(0, k);
+    compute(0, std::true_type{});
+    if constexpr (STEP_IS_GROUP) flush();
     if (k + BK < kend) {
-      lstore(preA, 1);
+      lstore(preA, 1, k + BK);
       gload(preA, k + 3 * BK);
       __syncthreads();
-      compute(1, k + BK);
+      compute(1, std::integral_constant<bool, STEP_IS_GROUP>{});
+      if constexpr (STEP_IS_GROUP) flush();
       if (k + 2 * BK < kend) {
-        lstore(preB, 0);
+        lstore(preB, 0, k + 2 * BK);
         gload(preB, k + 4 * BK);
         __syncthreads();
       }
     }
+    if constexpr (!STEP_IS_GROUP) flush();  // the group's 64 k (fewer at the end of the split)
   }
   // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float* Pz = P + (size_t)blockIdx.z * strideP;
@@ -1092,24 +1146,41 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_query_kernel(
 // work-group per (slice, query) leaves the slice's K smallest keys, and the selection over the S x K keys (MODE 2
 // above: select_query_kernel<2>, or select_rerank_kernel<true>) ends the search.  The K smallest keys of the window
 // are among the slices' K smallest, and keys are distinct (the row is part of the key): the same result.
-template <int MODE>
+// WALK: the flagged pass -- y = 1 and every work-group walks the flags (as dist_exact_kernel); a template flag because the
+// loop around the selection costs the MODE 1 instance 28 spilled registers.
+template <int MODE, bool WALK>
 __global__ __launch_bounds__(SELQ_THREADS) void select_slices_kernel(
     const float* __restrict__ dist, size_t ld, size_t strideP, int n_splits, float* __restrict__ qn,
     const float* __restrict__ queries, int dim, const float* __restrict__ dn, size_t first_row, int n_range, int L, int K,
-    uint64_t* __restrict__ lists /* [nq][S][K] */, const int* __restrict__ only_flagged) {
+    uint64_t* __restrict__ lists /* [nq][S][K] */, const int* __restrict__ only_flagged, int nq) {
   __shared__ uint64_t buf[SEL_LIST];
   __shared__ float qred[SELQ_THREADS / 64];
   __shared__ uint64_t tau_s;
   __shared__ int cnt;
   const int tid = threadIdx.x;
-  const int q = blockIdx.y, sl = blockIdx.x, S = gridDim.x;
-  if (only_flagged && !only_flagged[q]) return;  // uniform over the work-group
+  const int sl = blockIdx.x, S = gridDim.x;
   const int j0 = sl * L;
   const int n = n_range - j0 < L ? n_range - j0 : L;  // >= 1: the host drops empty slices
-  const float qnv = selq_select<MODE>(dist + (size_t)q * ld + j0, strideP, n_splits, queries + (size_t)q * dim, dim, dn,
-                                      first_row + (size_t)j0, n, K, buf, qred, &tau_s, &cnt);
-  if (MODE == 1 && sl == 0 && tid == 0) qn[q] = qnv;
-  if (tid < K) lists[((size_t)q * S + sl) * K + tid] = buf[tid];
+  auto one = [&](int q) {
+    const float qnv = selq_select<MODE>(dist + (size_t)q * ld + j0, strideP, n_splits, queries + (size_t)q * dim, dim,
+                                        dn, first_row + (size_t)j0, n, K, buf, qred, &tau_s, &cnt);
+    if (MODE == 1 && sl == 0 && tid == 0) qn[q] = qnv;
+    if (tid < K) lists[((size_t)q * S + sl) * K + tid] = buf[tid];
+  };
+  if constexpr (WALK) {  // SELQ_THREADS flags per round trip, usually none set
+    for (int base = 0; base < nq; base += SELQ_THREADS) {
+      const int f = (base + tid < nq) ? only_flagged[base + tid] : 0;
+      if (!__syncthreads_or(f)) continue;
+      for (int q = base; q < nq && q < base + SELQ_THREADS; ++q) {
+        if (!only_flagged[q]) continue;  // uniform over the work-group
+        one(q);
+        __syncthreads();  // buf is the next query's
+      }
+    }
+  } else {
+    if (only_flagged && !only_flagged[blockIdx.y]) return;  // uniform over the work-group
+    one(blockIdx.y);
+  }
 }
 
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).

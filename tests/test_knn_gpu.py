@@ -362,3 +362,44 @@ def test_sliced_select_above_16384_rows(capi, oracle_mod, algo, N, first, Q):
         oi, od = oracle_mod.knn_search(db, q, k, first, N, threads=4)
         assert (idx == oi).all() and (bits(d2) == bits(od)).all()
     ix.close()
+
+
+@pytest.mark.parametrize("algo", [2, 3])
+def test_unproven_queries_above_16384_rows_are_redone_on_the_device(capi, oracle_mod, algo):
+    """Rows closer to each other than the coarse form can resolve, in a window above 16 384 rows: the fused selection +
+    re-rank over the slices' lists flags the queries, and the exact pass (distances, slices, list selection -- launched
+    for flagged queries only) replaces their results, with no read-back of the flags."""
+    from gloc3d_amd import synth
+    N, D, Q = 20000, 256, 9
+    base = synth.descriptors_iid(71, 0, 1, D)
+    db = (base + np.float32(2e-4) * synth.descriptors_iid(72, 0, N, D)).astype(np.float32)
+    q = (base + np.float32(2e-4) * synth.descriptors_iid(73, 0, Q, D)).astype(np.float32)
+    ix = _index(capi, db, algo)
+    idx, d2 = ix.search(q, 20)
+    oi, od = oracle_mod.knn_search(db, q, 20, threads=4)
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    assert ix.stats()["queries_fallback"] > 0
+    ix.close()
+
+
+@pytest.mark.parametrize("D", [256, 4096])
+def test_split_bf16_bound_across_the_resolution_of_the_coarse_form(capi, oracle_mod, D):
+    """The split-bf16 coarse pass drops product terms of relative size 2^-16: a database whose rows sit at a graded
+    distance from the queries (spread 1 ... 3e-4 of the norm) walks the gaps between neighbours from far above to
+    far below that resolution.  Whatever the coarse order is, the result has to be the reference's bits -- by the
+    proof where the gaps are wide, by the exact pass where they are not (a bound set too tight would show here as a
+    neighbour missing from a result)."""
+    from gloc3d_amd import synth
+    N, Q = 3000, 16
+    base = synth.descriptors_iid(81, 0, 1, D)
+    fallbacks = []
+    for i, spread in enumerate((1.0, 0.3, 0.1, 3e-2, 1e-2, 3e-3, 3e-4)):
+        db = (base + np.float32(spread) * synth.descriptors_iid(82 + i, 0, N, D)).astype(np.float32)
+        q = (base + np.float32(spread) * synth.descriptors_iid(92 + i, 0, Q, D)).astype(np.float32)
+        ix = _index(capi, db, 2)
+        idx, d2 = ix.search(q, 20)
+        oi, od = oracle_mod.knn_search(db, q, 20, threads=4)
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all(), spread
+        fallbacks.append(ix.stats()["queries_fallback"])
+        ix.close()
+    assert fallbacks[0] == 0 and fallbacks[-1] == Q, fallbacks   # proven at the wide end, redone at the narrow end

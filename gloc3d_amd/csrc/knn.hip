@@ -350,7 +350,7 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     // few work-groups: each splits its queries itself; many: once, ahead of the launch
     dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
     static const int qraw_env = getenv("GLOC3D_KNN_B3_QRAW") ? atoi(getenv("GLOC3D_KNN_B3_QRAW")) : -1;  // developer switch
-    const bool qraw = qraw_env >= 0 ? qraw_env != 0 : (long long)grid.x * grid.y * grid.z <= 1024;
+    const bool qraw = qraw_env >= 0 ? qraw_env != 0 : (long long)grid.x * grid.y * grid.z <= 768;  // (64 x 125 000, 977 work-groups: 456 us split ahead, 461 in-kernel)
     const float* qsrc = d_q;
     if (!qraw) {
       ProfScope ps(h->prof, "split_queries", h->stream);

@@ -362,8 +362,6 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     }
     ProfScope ps(h->prof, "dist_mfma", h->stream);
     const int kps3 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
-    static const int ko_env = getenv("GLOC3D_KNN_B3_KO") ? atoi(getenv("GLOC3D_KNN_B3_KO")) : 0;  // developer switch: 4 or 8
-    const int ko = (ko_env == 4 || ko_env == 8) ? ko_env : 4;
     static const int phase = getenv("GLOC3D_KNN_B3_PHASE") ? atoi(getenv("GLOC3D_KNN_B3_PHASE")) : 5;  // developer switch
 #define B3(NT_, QR_, KO_)                                                                                             \
   do {                                                                                                                \
@@ -385,10 +383,10 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     else                       \
       B3(NT_, false, KO_);     \
   } while (0)
-    if (p.NT == 1 && ko == 4) B3Q(1, 4);
-    else if (p.NT == 1) B3Q(1, 8);
-    else if (ko == 4) B3Q(2, 4);
-    else B3Q(2, 8);
+    // (steps of 64 k -- KO = 8, 256 contiguous bytes of a row per step -- measured no faster at either size: 444 / 479 us
+    // against 456 / 448 at 64 x 125 000, and slower at 64 x 10 000; only the 32-k instances are built)
+    if (p.NT == 1) B3Q(1, 4);
+    else B3Q(2, 4);
 #undef B3Q
 #undef B3
     GLOC_HIP(hipGetLastError());

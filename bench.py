@@ -1165,8 +1165,14 @@ def main():
             "us_per_search": us, "queries": KNN_CFGB[0], "rows": KNN_CFGB[1], "dim": DIM, "kernel_us": kern,
             "roofline_us": roof_s * 1e6, "frac_of_roofline": roof_s * 1e6 / us,
             "fp32_mfma_roofline_us": fp32_s * 1e6, "frac_of_fp32_mfma_roofline": fp32_s * 1e6 / us,
+            "frac_of_round3_roofline": fp32_s * 1e6 / us,   # (the key of the shard record; VERDICT r3 item 2 asked >= 0.55 of THIS roofline)
             "coarse_kernel_tflops": flop / (kern["dist_mfma"] * 1e-6) / 1e12 if kern["dist_mfma"] > 0 else None,
             "coarse_kernel_hbm_gbs": 4.0 * KNN_CFGB[1] * DIM / (kern["dist_mfma"] * 1e-6) / 1e9 if kern["dist_mfma"] > 0 else None,
+            # the coarse kernel against three peaks: the fp32 MFMA peak it no longer runs on (by the 2 Q N D flop of the product --
+            # round 3's mfma_kernel_frac_of_peak, 0.52 then), the bf16 MFMA peak by the 3 x 2 Q N D it issues, and HBM
+            "coarse_kernel_frac_of_fp32_mfma_peak": flop / (kern["dist_mfma"] * 1e-6) / 1e12 / PEAK_FP32_TFLOPS if kern["dist_mfma"] > 0 else None,
+            "coarse_kernel_frac_of_bf16_mfma_peak": 3.0 * flop / (kern["dist_mfma"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS if kern["dist_mfma"] > 0 else None,
+            "coarse_kernel_frac_of_hbm": 4.0 * KNN_CFGB[1] * DIM / (kern["dist_mfma"] * 1e-6) / 1e9 / PEAK_HBM_GBS if kern["dist_mfma"] > 0 else None,
             "queries_fallback": st_["queries_fallback"],
             "what": "BASELINE configs[1]: 64 queries x 10 000 x 4096 fp32, device resident, wall clock over 50 back-to-back searches. "
                     "Round 4: the coarse pass runs on the bf16 matrix cores (operands split in two bf16 values, three MFMAs per "

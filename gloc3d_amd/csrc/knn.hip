@@ -2,6 +2,7 @@
 // Replaces registration/loop_detector.cpp:34-45,66-79 (KD-tree build + query) and
 // main.py:317-324 (faiss.IndexFlatL2 add/search) of the reference.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cstdlib>
 #include <vector>
@@ -366,11 +367,12 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 #define B3(NT_, QR_, KO_)                                                                                             \
   do {                                                                                                                \
     constexpr int lds_bytes = b3_lds_bytes<NT_, KO_>();                                                               \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set && lds_bytes > 48 * 1024) {                                                                         \
+    static std::atomic<uint64_t> attr_set{0}; /* bit d: done on device d (the attribute belongs to the device's copy) */ \
+    const uint64_t dev_bit = 1ull << (h->device & 63);                                                                \
+    if (lds_bytes > 48 * 1024 && !(attr_set.load(std::memory_order_relaxed) & dev_bit)) {                            \
       GLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_bf16x3_kernel<NT_, QR_, KO_>),                 \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                          \
-      attr_set = true;                                                                                                \
+      attr_set.fetch_or(dev_bit, std::memory_order_relaxed);                                                          \
     }                                                                                                                 \
     hipLaunchKernelGGL((dist_bf16x3_kernel<NT_, QR_, KO_>), grid, dim3(256), lds_bytes, h->stream,                    \
                        h->rows.as<float>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld,     \

@@ -294,63 +294,117 @@ __device__ __forceinline__ void nn_compact_body(
   // ---- upper bounds -> LDS state -----------------------------------------------------------------
   // warm: the previous pass's correspondence (a sorted position: one coherent 16-byte gather);
   // cold: the five curve neighbours of the point's key in the target's order
+  uint32_t b0s[CS];
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
-    uint32_t b0 = 0;
-    if (ix.n) {
-      const uint32_t j = pj[s];
-      if (j < ix.n) {
-        const f32x4 t = pt[s];
-        best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
-        b0 = j / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
-      } else if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
-        const uint32_t key = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
-        // lower_bound over the sorted keys, (KP + 1)-way: KP independent probes per round trip.  The binary search took 17
-        // dependent trips at 124 k keys (46 % of a cold wave's time, traced); nine-way (8 probes, 7 trips, 56 loads) made the
-        // memory pipe the limit (every lane its own addresses: 40 %); five-way is 8 trips of 4.
+    b0s[s] = 0;
+    if (ix.n && pj[s] < ix.n) {
+      const f32x4 t = pt[s];
+      best[s] = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
+      b0s[s] = pj[s] / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
+    }
+  }
+  if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
+    // lower_bound over the sorted keys, (KP + 1)-way: KP independent probes per round trip.  The binary search took 17
+    // dependent trips at 124 k keys (46 % of a cold wave's time, traced); nine-way (8 probes, 7 trips, 56 loads) made the
+    // memory pipe the limit (every lane its own addresses: 40 %); five-way is 8 trips of 4.  The lane's CS sources search
+    // TOGETHER (round 4, late): one after the other they were 2 x 10 dependent trips, 40 % of a cold wave's time -- cold launch
+    // of 500 jobs 3.47 -> 3.07 ms; with the trips shared the loads count again: 3 / 4 / 6 / 8 probes 2.96 / 3.07 / 3.32 / 3.22 ms.
 #ifndef GLOC_NN_KEY_PROBES
-#define GLOC_NN_KEY_PROBES 4
+#define GLOC_NN_KEY_PROBES 3
 #endif
-        constexpr int KP = GLOC_NN_KEY_PROBES;
-        uint32_t lo = 0, hi = ix.n;  // the answer is in [lo, hi]
-        while (hi - lo > (uint32_t)KP) {
-          const uint32_t len = hi - lo;
-          uint32_t pos[KP], kv[KP];
+    constexpr int KP = GLOC_NN_KEY_PROBES;
+    bool cold[CS];
+    uint32_t key[CS], lo[CS], hi[CS];
+    bool any = false;
 #pragma unroll
-          for (int i = 0; i < KP; ++i) pos[i] = lo + (uint32_t)(((unsigned long long)len * (uint32_t)(i + 1)) / (uint32_t)(KP + 1));  // lo < pos < hi, ascending
+    for (int s = 0; s < CS; ++s) {
+      cold[s] = ix.n && !(pj[s] < ix.n);
+      key[s] = morton_key(px[s], py[s], pz[s], ix.hdr->ox, ix.hdr->oy, ix.hdr->oz, ix.hdr->inv_cell);
+      lo[s] = 0;
+      hi[s] = cold[s] ? ix.n : 0u;  // the answer is in [lo, hi]; a source with a bound searches nothing
+      any |= cold[s];
+    }
+    if (any) {
+      for (;;) {
+        bool go = false;
 #pragma unroll
-          for (int i = 0; i < KP; ++i) kv[i] = ix.keys[pos[i]];
-          uint32_t nlo = lo, nhi = hi;
+        for (int s = 0; s < CS; ++s) go |= hi[s] - lo[s] > (uint32_t)KP;
+        if (!go) break;
+        uint32_t pos[CS][KP], kv[CS][KP];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+          const uint32_t len = hi[s] - lo[s];
+#pragma unroll
+          for (int i = 0; i < KP; ++i) {  // lo < pos < hi, ascending (an interval already short: probes it will not use)
+            pos[s][i] = lo[s] + (uint32_t)(((unsigned long long)len * (uint32_t)(i + 1)) / (uint32_t)(KP + 1));
+            pos[s][i] = pos[s][i] < ix.n ? pos[s][i] : ix.n - 1;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+          for (int i = 0; i < KP; ++i) kv[s][i] = ix.keys[pos[s][i]];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+          if (!(hi[s] - lo[s] > (uint32_t)KP)) continue;
+          uint32_t nlo = lo[s], nhi = hi[s];
 #pragma unroll
           for (int i = KP - 1; i >= 0; --i)
-            if (!(kv[i] < key)) nhi = pos[i];      // the first probe that is not below the key bounds the answer from above
+            if (!(kv[s][i] < key[s])) nhi = pos[s][i];  // the first probe that is not below the key bounds the answer from above
 #pragma unroll
           for (int i = 0; i < KP; ++i)
-            if (kv[i] < key) nlo = pos[i] + 1;     // the last probe below it, from below
-          lo = nlo;
-          hi = nhi;
+            if (kv[s][i] < key[s]) nlo = pos[s][i] + 1;  // the last probe below it, from below
+          lo[s] = nlo;
+          hi[s] = nhi;
         }
-        {
-          uint32_t below = 0;
+      }
+      uint32_t kl[CS][KP];
 #pragma unroll
-          for (int i = 0; i < KP; ++i)
-            if (lo + i < hi && ix.keys[lo + i] < key) below++;
-          lo += below;  // (sorted: the keys below the key are a prefix of [lo, hi))
-        }
+      for (int s = 0; s < CS; ++s)
+#pragma unroll
+        for (int i = 0; i < KP; ++i) kl[s][i] = (lo[s] + i < hi[s]) ? ix.keys[lo[s] + i] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        uint32_t below = 0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+          if (lo[s] + i < hi[s] && kl[s][i] < key[s]) below++;
+        lo[s] += below;  // (sorted: the keys below the key are a prefix of [lo, hi))
+      }
+      // the five curve neighbours of the key's place
+      uint32_t pjj[CS][5];
+#pragma unroll
+      for (int s = 0; s < CS; ++s)
+#pragma unroll
         for (int d = -2; d <= 2; ++d) {
-          long long jj = (long long)lo + d;
+          long long jj = (long long)lo[s] + d;
           jj = jj < 0 ? 0 : (jj >= (long long)ix.n ? (long long)ix.n - 1 : jj);
           // (a target index is in kd order: the curve neighbour's place among the points comes from kpos)
-          const uint32_t pj = ix.kpos ? ix.kpos[jj] : (uint32_t)jj;
-          const f32x4 t = ix.pts[pj];
-          const float dd = dist2(px[s], py[s], pz[s], t.x, t.y, t.z);
+          pjj[s][d + 2] = !cold[s] ? 0u : (ix.kpos ? ix.kpos[jj] : (uint32_t)jj);
+        }
+      f32x4 tn[CS][5];
+#pragma unroll
+      for (int s = 0; s < CS; ++s)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) tn[s][d] = ix.pts[pjj[s][d]];
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        if (!cold[s]) continue;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+          const float dd = dist2(px[s], py[s], pz[s], tn[s][d].x, tn[s][d].y, tn[s][d].z);
           if (dd < best[s]) {
             best[s] = dd;
-            b0 = pj / (SB / 4);
+            b0s[s] = pjj[s][d] / (SB / 4);
           }
         }
       }
     }
+  }
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    const uint32_t b0 = b0s[s];
     if (!valid[s]) best[s] = -1.f;  // a lane without a point: a bound no box lower bound (>= 0) passes
     const int slot = s * 64 + lane;
     L.src[slot] = f32x4{px[s], py[s], pz[s], 0.f};

@@ -843,36 +843,42 @@ __device__ __forceinline__ void nn_compact_body(
   // ---- index recovery: smallest ORIGINAL index among the targets at the minimum distance ----
   // bpos = that target's sorted position (what is stored), (qx, qy, qz) its coordinates
   uint32_t bpos[CS];
+  {
+    // (both sources' quarters are fetched before either is measured: one dependent round trip per wave, not CS)
+    uint32_t bch[CS];
+    bool rec[CS];
+    f32x4 t[CS][SB / 4];
 #pragma unroll
-  for (int s = 0; s < CS; ++s) {
-    bpos[s] = 0xFFFFFFFFu;
-    if (!valid[s] || !ix.n) continue;
-    const int slot = s * 64 + lane;
-    const uint32_t bch = (uint32_t)L.key[slot];  // (sub-block << 2) | quarter: 4 targets
-    const bool tie = L.tie[slot] != 0;
-    uint32_t bj = 0xFFFFFFFFu;
-    float bd = __builtin_inff();
-    if (!tie) {
-      // (the store pads the scan to whole chunks, so the loads are unconditional)
-      GPTR(f32x4) tp = ix.pts + (size_t)bch * (SB / 4);
+    for (int s = 0; s < CS; ++s) {
+      const int slot = s * 64 + lane;
+      bch[s] = (uint32_t)L.key[slot];  // (sub-block << 2) | quarter: 4 targets
+      rec[s] = valid[s] && ix.n && L.tie[slot] == 0;
+      // (the store pads the scan to whole chunks, so the loads are unconditional; a lane with nothing to recover reads quarter 0)
+      GPTR(f32x4) tp = ix.pts + (size_t)(rec[s] ? bch[s] : 0u) * (SB / 4);
+#pragma unroll
+      for (int u = 0; u < SB / 4; ++u) t[s][u] = tp[u];
+    }
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      bpos[s] = 0xFFFFFFFFu;
+      if (!rec[s]) continue;
+      uint32_t bj = 0xFFFFFFFFu;
+      float bd = __builtin_inff();
       const f32x2 pxy = {px[s], py[s]};
-      f32x4 t[SB / 4];
-#pragma unroll
-      for (int u = 0; u < SB / 4; ++u) t[u] = tp[u];
 #pragma unroll
       for (int u = 0; u < SB / 4; ++u) {
         // dist2(): x and y share one packed instruction (a loaded point's x, y are a register pair);
         // same roundings as the scalar form
-        const f32x2 dxy = pxy - f32x2{t[u].x, t[u].y};
+        const f32x2 dxy = pxy - f32x2{t[s][u].x, t[s][u].y};
         const f32x2 sxy = dxy * dxy;
-        const float dz = pz[s] - t[u].z;
+        const float dz = pz[s] - t[s][u].z;
         const float d2 = (sxy.x + sxy.y) + dz * dz;
-        const uint32_t o = __float_as_uint(t[u].w);  // padding carries 0xFFFFFFFF: never smaller
+        const uint32_t o = __float_as_uint(t[s][u].w);  // padding carries 0xFFFFFFFF: never smaller
         // the un-fused minimum of the quarter (the search compared fused distances), smallest original index first
         if (d2 < bd || (d2 == bd && o < bj)) {
           bd = d2;
           bj = o;
-          bpos[s] = bch * (SB / 4) + u;
+          bpos[s] = bch[s] * (SB / 4) + u;
         }
       }
       if (bpos[s] != 0xFFFFFFFFu) best[s] = bd;

@@ -462,8 +462,7 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
       *finalized = fo.idx != nullptr;
       return GLOC_OK;
     }
-    // (large windows: on to the flags' read-back below; the keys are final unless a flagged query is redone, so the
-    // caller's finalize launch writes the result)
+    // (large windows: on to the flagged-only exact pass below -- a work-group per query cannot redo a window of that size)
   } else {
   // (the query norms of the coarse form are made by the select kernel, which leaves them in h->qnorm)
   GLOC_TRY(run_select<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, h->keys.as<uint64_t>()));

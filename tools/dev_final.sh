@@ -17,3 +17,4 @@ python tools/dev_nn_timeline.py 256 60000 > $O/r04_nn_timeline_lone_query_planne
 python tools/dev_nn_timeline.py 0 0 > $O/r04_nn_timeline_lone_query_unplanned.txt 2>&1
 python tools/dev_split_sweep.py 0,0 256,60000 > $O/r04_lone_query_plans.txt 2>&1
 cat $O/r04_lone_query_plans.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"

@@ -40,6 +40,17 @@ struct gloc_knn {
   DevBuf stage_idx, stage_d2;
   int* h_flags = nullptr;  // pinned
   size_t h_flags_cap = 0;
+  // The split-bf16 coarse pass proves less on data whose neighbours lie close together relative to the norms (its bound is
+  // eight times the fp32 form's): a search whose queries mostly went to the exact pass costs far more than the fp32 coarse pass
+  // would have.  The fallback counter is copied to the host behind every tracked search (no wait: it is looked at when the
+  // next search finds the copy done); above a quarter of the queries the handle's next 64 searches take the fp32 form, then
+  // the split form is tried again.  Results do not depend on it.
+  unsigned long long* h_inc = nullptr;  // pinned: the counter as of the tracked search
+  hipEvent_t inc_ev = nullptr;
+  bool inc_pending = false;
+  unsigned long long inc_seen = 0;      // the counter at the last look
+  size_t inc_queries = 0;               // queries of the tracked search
+  int coarse_fp32_left = 0;             // searches still to run on the fp32 coarse pass
   int algo = GLOC_KNN_ALGO_AUTO;
   int candidates = 32;
   Profiler prof;
@@ -554,6 +565,23 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
     const size_t ld = (range + 63) & ~(size_t)63;
     size_t qblk = (size_t)(2ull << 30) / (ld * sizeof(float) * 4);
     qblk = std::min<size_t>(1024, std::max<size_t>(64, qblk / 64 * 64));
+    // the coarse form of this search (see h_inc): look at the last tracked search's count if its copy has landed
+    static const bool no_adapt = getenv("GLOC3D_KNN_NO_ADAPT") != nullptr;  // developer switch
+    bool tracked = false;
+    if (algo == GLOC_KNN_ALGO_MFMA && !no_adapt) {
+      if (h->inc_pending && hipEventQuery(h->inc_ev) == hipSuccess) {
+        const unsigned long long now = *h->h_inc, delta = now - h->inc_seen;
+        h->inc_seen = now;
+        h->inc_pending = false;
+        if (delta * 4 > h->inc_queries) h->coarse_fp32_left = 64;
+      }
+      if (h->coarse_fp32_left > 0) {
+        h->coarse_fp32_left--;
+        algo = GLOC_KNN_ALGO_MFMA_FP32;
+      } else {
+        tracked = !h->inc_pending;
+      }
+    }
     for (size_t q0 = 0; q0 < nq; q0 += qblk) {
       const int cnt = (int)std::min(qblk, nq - q0);
       if (algo == GLOC_KNN_ALGO_MFMA || algo == GLOC_KNN_ALGO_MFMA_FP32) {
@@ -570,6 +598,17 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
         GLOC_TRY(run_exact(h, d_q + q0 * h->dim, cnt, (int)k, first_row, (int)range, keys_out + q0 * k, fo, &fin));
         all_final = all_final && fin;
       }
+    }
+    if (tracked && h->n_incomplete.p) {  // the fallback count as of this search, for the next one to look at
+      if (!h->h_inc) {
+        GLOC_HIP(hipHostMalloc((void**)&h->h_inc, sizeof(unsigned long long)));
+        *h->h_inc = 0;
+        GLOC_HIP(hipEventCreateWithFlags(&h->inc_ev, hipEventDisableTiming));
+      }
+      GLOC_HIP(hipMemcpyAsync(h->h_inc, h->n_incomplete.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+      GLOC_HIP(hipEventRecord(h->inc_ev, h->stream));
+      h->inc_pending = true;
+      h->inc_queries = nq;
     }
   }
   h->stats.queries_total += nq;
@@ -631,6 +670,8 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->stage_idx.release();
   h->stage_d2.release();
   if (h->h_flags) (void)hipHostFree(h->h_flags);
+  if (h->h_inc) (void)hipHostFree(h->h_inc);
+  if (h->inc_ev) (void)hipEventDestroy(h->inc_ev);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return GLOC_OK;

@@ -58,7 +58,9 @@ enum {
   GLOC_KNN_ALGO_MFMA = 2,  /* matrix-core coarse pass -2Q.D^T + norms (operands split in two bf16 values, three bf16
                               MFMAs per product -- a proven bound on what that drops; fp32 MFMA when dim % 8 != 0),
                               top-k' selection, exact re-rank in the reference's order, completeness proven per query
-                              (an unproven query is redone on the exact path): the same bits as GLOC_KNN_ALGO_EXACT */
+                              (an unproven query is redone on the exact path): the same bits as GLOC_KNN_ALGO_EXACT.  A handle
+                              whose searches keep failing that proof (rows clustered tightly relative to their norms) runs
+                              its next searches with the fp32 coarse pass, whose bound is eight times tighter */
   GLOC_KNN_ALGO_MFMA_FP32 = 3 /* the same with the coarse pass on the fp32 MFMA (the rounds 1 - 3 form) */
 };
 enum {

@@ -403,3 +403,30 @@ def test_split_bf16_bound_across_the_resolution_of_the_coarse_form(capi, oracle_
         fallbacks.append(ix.stats()["queries_fallback"])
         ix.close()
     assert fallbacks[0] == 0 and fallbacks[-1] == Q, fallbacks   # proven at the wide end, redone at the narrow end
+
+
+def test_handle_leaves_the_split_form_when_its_proofs_keep_failing(capi, oracle_mod):
+    """Rows clustered tightly relative to their norms: the split-bf16 coarse pass (bound 8 x the fp32 form's) cannot prove
+    its candidate sets and every query goes to the exact pass, while the fp32 coarse pass proves them all.  The handle
+    notices (the fallback counter of a search is looked at by a later one, without a wait) and takes the fp32 form for
+    its next searches: the same bits throughout, and the fallbacks stop."""
+    from gloc3d_amd import synth
+    N, D, Q = 5000, 2048, 64
+    cen = synth.descriptors_iid(111, 0, 7, D)
+    rng = np.random.default_rng(5)
+    db = (cen[rng.integers(0, 7, N)] + np.float32(0.05) * synth.descriptors_iid(112, 0, N, D)).astype(np.float32)
+    q = (db[rng.integers(0, N, Q)] + np.float32(0.02) * synth.descriptors_iid(113, 0, Q, D)).astype(np.float32)
+    oi, od = oracle_mod.knn_search(db, q, 5, threads=4)
+    ix = _index(capi, db, 2)
+    seen = []
+    for _ in range(6):
+        idx, d2 = ix.search(q, 5)                       # (the host-buffer entry point waits for its result: the copy has landed)
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+        seen.append(ix.stats()["queries_fallback"])
+    ix.close()
+    assert seen[0] > Q // 4, seen                       # the split form fell back ...
+    assert seen[-1] == seen[2], seen                    # ... and after the handle looked, nothing falls back any more
+    ix = _index(capi, db, 3)                            # the fp32 form proves these queries
+    ix.search(q, 5)
+    assert ix.stats()["queries_fallback"] == 0
+    ix.close()

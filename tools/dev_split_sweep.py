@@ -27,6 +27,8 @@ for plan in plans:
         reg.set_option(capi.REG_OPT_NN_JOB_GROUP, plan[2])
     if len(plan) > 3:
         reg.set_option(capi.REG_OPT_NN_SUB_JOBS, plan[3])
+    if len(plan) > 4:
+        reg.set_option(capi.REG_OPT_NN_SRC_PER_LANE, plan[4])
     reg.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, helpers)
     reg.set_option(capi.REG_OPT_NN_SPLIT_THRESH, thresh)
     res = {}

@@ -21,7 +21,37 @@ FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-co
 # knn.hip: MFMA accumulators in architectural VGPRs -- the split-bf16 distance kernel adds its accumulators to running
 # totals every 64 k, and from AGPRs that is a v_accvgpr_read per register and step (measured: 121 of the main loop's
 # ~330 vector instructions); without AGPRs the kernel also fits three work-groups per CU (161 registers, not 192)
-PER_SOURCE = {"knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+PER_SOURCE = {"knn.hip": MFMA_VGPR_FORM}
+_probe = {}
+
+
+def mfma_vgpr_form_supported():
+    """Does this hipcc's LLVM know -amdgpu-mfma-vgpr-form?  Probed once by compiling an empty translation unit; a compiler
+    without it still builds the library (192 registers and AGPR copies in the split-bf16 kernel: slower, same results) and
+    bench.py records which it was (build_flags.mfma_vgpr_form)."""
+    if "ok" not in _probe:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void probe_kernel() {}\n")
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--cuda-device-only"] + MFMA_VGPR_FORM + ["-c", src, "-o", os.path.join(d, "probe.o")],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _probe["ok"] = r.returncode == 0
+    return _probe["ok"]
+
+
+def per_source_flags(src):
+    fl = PER_SOURCE.get(src, [])
+    if fl == MFMA_VGPR_FORM and not mfma_vgpr_form_supported():
+        print(f"[gloc3d build] warning: {HIPCC} rejects {' '.join(MFMA_VGPR_FORM)}: {src} is built without it "
+              "(the split-bf16 distance kernel keeps its accumulators in AGPRs: same results, slower)", file=sys.stderr)
+        return []
+    return fl
+
+
+FLAG_NOTE = os.path.join(LIBDIR, "build_flags.json")
 
 
 def _stale(out, deps):
@@ -41,7 +71,7 @@ def build(force=False, verbose=False):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + PER_SOURCE.get(src, []) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + per_source_flags(src) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -56,7 +86,20 @@ def build(force=False, verbose=False):
         # it runs on (PyTorch bundles its own; two runtimes in one process cannot share the GPU).
         # gloc3d_amd.capi preloads one with RTLD_GLOBAL; the C++ command lines link /opt/rocm's.
         run(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        import json
+        with open(FLAG_NOTE, "w") as f:   # travels with the .so (git-ignored like it); bench.py copies it into its line
+            json.dump({"mfma_vgpr_form": bool(mfma_vgpr_form_supported()), "flags": FLAGS, "hipcc": HIPCC}, f)
     return LIB
+
+
+def build_flags():
+    """What the library in lib/ was built with (None when the note is missing: a library built by hand)."""
+    import json
+    try:
+        with open(FLAG_NOTE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def build_test_variant(force=False, verbose=False):

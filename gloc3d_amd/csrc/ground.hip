@@ -120,6 +120,8 @@ int select_flagged(gloc_ground* h, uint32_t n, uint32_t* h_count) {
   return GLOC_OK;
 }
 
+__global__ void one_segment_kernel(segsort::Seg* seg, uint32_t n) { *seg = segsort::Seg{0u, n}; }
+
 // key_range: every coordinate of the cloud lies in [-key_range, key_range] (the range filter's radius);
 // points outside are clamped into the outermost cells, which only loosens the order, not the result.
 int knn_device(gloc_ground* h, const f32x4* d_pts, uint32_t m, uint32_t k, float key_range) {
@@ -140,15 +142,15 @@ int knn_device(gloc_ground* h, const f32x4* d_pts, uint32_t m, uint32_t k, float
                        1023.0f / (2.0f * key_range), h->skeys.as<uint32_t>(), h->svals.as<uint32_t>());
     // the curve keys' order: the repo's own stable segmented radix sort (round 4: hipcub::DeviceRadixSort before), one
     // segment, four 8-bit digits
-    const segsort::Seg seg{0u, m};
-    GLOC_TRY(h->sort_segs.ensure(sizeof(seg), s));
+    // (the one-segment descriptor is written by a one-thread kernel: a copy from a stack variable needed a host
+    // synchronisation inside every scan's ground stage -- ADVICE r4)
+    GLOC_TRY(h->sort_segs.ensure(sizeof(segsort::Seg), s));
     GLOC_TRY(h->sort_hist.ensure(segsort::scratch_bytes(1, m), s));
-    GLOC_HIP(hipMemcpyAsync(h->sort_segs.p, &seg, sizeof(seg), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(one_segment_kernel, dim3(1), dim3(1), 0, s, h->sort_segs.as<segsort::Seg>(), m);
     uint32_t* vbuf[2] = {h->svals.as<uint32_t>(), h->sperm.as<uint32_t>()};
     const int cur = segsort::sort_pairs<uint32_t, 8>(s, h->skeys.as<uint32_t>(), h->skeys2.as<uint32_t>(), vbuf[0], vbuf[1],
                                                      h->sort_segs.as<segsort::Seg>(), 1, m, 0, 32, h->sort_hist.as<uint32_t>());
     GLOC_HIP(hipGetLastError());
-    GLOC_HIP(hipStreamSynchronize(s));  // (`seg` is a stack buffer)
     const uint32_t* perm = vbuf[cur];
     hipLaunchKernelGGL(gather_sorted_f4_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d_pts, perm, m, h->spts.as<f32x4>());
     hipLaunchKernelGGL(kchunk_boxes_kernel, dim3(nch), dim3(64), 0, s, h->spts.as<f32x4>(), m,

@@ -74,19 +74,57 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
+// Round 5: the six steps are v_min/v_max_f32 WITH the DPP operand, written out.  From fminf(x, dpp(x)) the compiler
+// makes three instructions a step (v_mov_b32_dpp, a v_max x, x that quiets a signalling NaN, the v_min) and four for
+// the two row steps: 22 vector instructions a reduction, seven reductions in a wave's prologue and one after most
+// processed chunks -- 255 of the wave's 2 208 (ISA count).  v_min/v_max_f32 return the other operand when one is a NaN,
+// as fminf / fmaxf do; the hazard (a VALU write of a register two or fewer slots before a DPP read of it) is covered
+// by the s_nop the compiler cannot place inside an asm.
 template <bool MAX>
 __device__ __forceinline__ float wave_minmax(float x) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
-  x = op(x, dpp_f32<0xB1>(x));   // quad_perm [1,0,3,2]
-  x = op(x, dpp_f32<0x4E>(x));   // quad_perm [2,3,0,1]
-  x = op(x, dpp_f32<0x141>(x));  // row_half_mirror
-  x = op(x, dpp_f32<0x140>(x));  // row_mirror
   // across the four rows: row_bcast:15 hands a row's value (all its lanes hold it) to the next row -- rows 1 and 3
-  // take it -- then row_bcast:31 hands rows 0-1's to rows 2 and 3; lanes left out keep x (old = x: op(x, x) = x).
+  // take it -- then row_bcast:31 hands rows 0-1's to rows 2 and 3; lanes left out keep x.
   // Lane 63 ends with the wave's value: one v_readlane instead of four plus three combines.
-  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x142, 0xA, 0xF, false)));
-  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x143, 0xC, 0xF, false)));
+  if constexpr (MAX)
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+        : "+v"(x));
+  else
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+        : "+v"(x));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+// The wave's box: three minima and three maxima, the six chains interleaved -- a register is read by a DPP operand
+// five instructions after it was written, so only the first step needs the wait states.
+__device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
+#define GLOC_BOX_STEP(CTRL)                                      \
+  "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t" \
+  "v_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\t" \
+  "v_min_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
+  asm("s_nop 1\n\t"
+      GLOC_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+      GLOC_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+      GLOC_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+      GLOC_BOX_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+      GLOC_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      GLOC_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 0"
+      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+#undef GLOC_BOX_STEP
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo[a]), 63));
+    hi[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi[a]), 63));
+  }
 }
 
 // (xor_lane<O>: lane_ops.hpp -- DPP below 16 lanes; ds_bpermute kept the LDS pipe busy and was worth 6 % of the launch)
@@ -283,11 +321,7 @@ __device__ __forceinline__ void nn_compact_body(
     wlo[2] = fminf(wlo[2], pz[s]); whi[2] = fmaxf(whi[2], pz[s]);
     best[s] = 3.402823466e+38f;
   }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    wlo[a] = wave_minmax<false>(wlo[a]);
-    whi[a] = wave_minmax<true>(whi[a]);
-  }
+  wave_box(wlo, whi);
 
   const unsigned long long t_box = now();
   NN_MARK("upper_bounds");
@@ -813,7 +847,12 @@ __device__ __forceinline__ void nn_compact_body(
         changed |= nbs < bests[s];
         bests[s] = nbs;
       }
-      if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax_s = wave_max_best();
+      // A warm pass starts from bounds that are nearly final (the previous pass's neighbour): the WAVE's bound hardly moves,
+      // and re-reducing it after every chunk cost more than the candidates it spared (round 5, same box: 38.16 -> 37.87 ms of
+      // 1-NN per step; dropping the lanes' refresh as well: 38.30).  The stale value is still an upper bound: same result.
+      if constexpr (!WARM) {
+        if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax_s = wave_max_best();
+      }
       if constexpr (TRACE) {
         const unsigned long long t_e = now();
         a_refresh += t_e - t_f0;

@@ -45,7 +45,8 @@ struct gloc_reg {
     size_t total = 0;
     float max_rmse = 0.f, max_final_step = 0.f;
     bool icp = false;
-    gloc_scan_store* store = nullptr;  // the store whose in-flight count this batch holds
+    gloc_scan_store* store = nullptr;  // the store whose scans this batch pins ...
+    std::vector<uint32_t> pinned;      // ... and their ids (store_pin)
   } pending;
   std::vector<float> last_final_step;  // per job of the last collected batch (gloc_reg_final_steps)
   int nn_mode = 0;        // 0 culled + compacted (default), 1 exhaustive
@@ -477,7 +478,7 @@ void gloc_reg_default_params(gloc_reg_params* p) {
   p->seed = 1234;
   p->ransac_confidence = 0.99f;  // cv::estimateAffinePartial2D's default, used by the reference
   p->max_rmse = 0.f;
-  p->max_final_step = 0.03f;  // the ICP must have converged (see the header)
+  p->max_final_step = 0.f;  // off, as the reference: its 3-D stage takes what the ICP returns (GLOC_REG_FINAL_STEP_SUGGESTED: see the header)
 }
 
 int gloc_reg_create(int device, gloc_reg** out) {
@@ -529,7 +530,8 @@ int gloc_reg_destroy(gloc_reg* h) {
   if (!h) return GLOC_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  if (h->pending.active && h->pending.store) h->pending.store->inflight--;
+  if (h->pending.active && h->pending.store) store_pin(h->pending.store, h->pending.pinned.data(), h->pending.pinned.size(), -1);
+  h->pending.pinned.clear();
   h->pending.active = false;
   if (h->store) h->store->attached--;
   h->store = nullptr;
@@ -702,10 +704,21 @@ int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_
   P.total = total;
   P.max_rmse = params->max_rmse;
   P.max_final_step = params->icp_iters ? params->max_final_step : 0.f;
-  GLOC_TRY(enqueue_jobs(h, jh, params));
+  // the scans the jobs read are pinned BEFORE the first launch (gloc_scan_store_build_target_index refuses to re-sort
+  // them in place until _end), and released again if the enqueue fails part-way: whatever was launched is waited for first
+  P.pinned.assign(q_scan_ids, q_scan_ids + n_queries);
+  for (size_t o = 0; o < total; ++o)
+    if (cand_scan_ids[o] != 0xFFFFFFFFu) P.pinned.push_back(cand_scan_ids[o]);
+  store_pin(h->store, P.pinned.data(), P.pinned.size(), +1);
+  const int rc = enqueue_jobs(h, jh, params);
+  if (rc != GLOC_OK) {
+    (void)hipStreamSynchronize(h->stream);
+    store_pin(h->store, P.pinned.data(), P.pinned.size(), -1);
+    P.pinned.clear();
+    return rc;
+  }
   P.active = true;
   P.store = h->store;
-  h->store->inflight++;  // (gloc_scan_store_build_target_index refuses to re-sort scans under a batch in flight)
   return GLOC_OK;
 }
 
@@ -720,7 +733,8 @@ int gloc_reg_batch_multi_end(gloc_reg* h, float* out_T, float* out_rmse, uint32_
     gloc_scan_store* st;
     ~Done() {
       (void)hipEventSynchronize(h->done_ev);
-      if (st) st->inflight--;
+      if (st) store_pin(st, h->pending.pinned.data(), h->pending.pinned.size(), -1);
+      h->pending.pinned.clear();
     }
   } done{h, P.store};
   P.store = nullptr;

@@ -846,6 +846,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
     st.sum_d2 = v[16];
     if (v[0] < 3.0) {
       st.frozen = 1;
+      st.last_step = __builtin_inff();  // an ICP that stopped for want of correspondences has not converged (max_final_step)
       return;
     }
   } else {

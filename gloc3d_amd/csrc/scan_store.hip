@@ -883,6 +883,12 @@ int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out) {
   return GLOC_OK;
 }
 
+void store_pin(gloc_scan_store* st, const uint32_t* ids, size_t count, int delta) {
+  std::lock_guard<std::mutex> lk(st->mu);
+  for (size_t i = 0; i < count; ++i)
+    if (ids[i] < st->scans.size() && st->scans[ids[i]].live) st->scans[ids[i]].pins += delta;
+}
+
 }  // namespace reg
 }  // namespace gloc
 
@@ -1013,15 +1019,17 @@ int gloc_scan_store_build_target_index_batch(gloc_scan_store* st, const uint32_t
   GLOC_REQUIRE(st && (scan_ids || !count), GLOC_ERR_INVALID, "null argument");
   GLOC_HIP(hipSetDevice(st->device));
   std::lock_guard<std::mutex> lk(st->mu);
-  // the re-sort rewrites points, boxes and permutations of a resident scan IN PLACE: a batch in flight on an attached
-  // handle would search half-rewritten boxes (missed neighbours, not only a slower search)
-  GLOC_REQUIRE(st->inflight.load() == 0, GLOC_ERR_STATE,
-               "%d registration batch(es) in flight on this store (gloc_reg_batch_multi_begin without _end)", st->inflight.load());
+  // the re-sort rewrites points, boxes and permutations of a resident scan IN PLACE: a batch in flight that reads the scan
+  // would search half-rewritten boxes (missed neighbours, not only a slower search).  Only scans that still need the
+  // re-sort AND are pinned by such a batch are refused (round 5; round 4 refused every call while any batch was in flight)
   std::vector<DevScan*> ps(count);
   for (size_t i = 0; i < count; ++i) {
     GLOC_REQUIRE(scan_ids[i] < st->scans.size() && st->scans[scan_ids[i]].live, GLOC_ERR_INVALID, "unknown scan id %u",
                  scan_ids[i]);
     ps[i] = &st->scans[scan_ids[i]];
+    GLOC_REQUIRE(ps[i]->kd || ps[i]->n <= (size_t)SB || ps[i]->pins == 0, GLOC_ERR_STATE,
+                 "scan %u is read by %d registration batch(es) in flight (gloc_reg_batch_multi_begin without _end)", scan_ids[i],
+                 ps[i]->pins);
   }
   return store_build_target_indices(st, ps.data(), count);
 }

@@ -32,6 +32,8 @@ struct DevScan {
   }
   bool live = false;
   bool kd = false;  // the index is in kd order (target index)
+  int pins = 0;     // batches in flight (gloc_reg_batch_multi_begin .. _end) whose jobs hold a by-value view of THIS scan:
+                    // it may not be re-sorted in place meanwhile (store_pin / store_unpin, under the store's mutex)
 };
 
 struct gloc_scan_store {
@@ -52,8 +54,6 @@ struct gloc_scan_store {
             &grp_v0, &grp_v1, &grp_segs, &kd_k0, &kd_k1, &kd_v0, &kd_v1, &kd_p0, &kd_p1, &kd_h0, &kd_h1, &kd_box, &kd_desc};
   }
   std::atomic<int> attached{0};  // registration handles using this store
-  std::atomic<int> inflight{0};  // batches between gloc_reg_batch_multi_begin and _end on any of them: their jobs hold
-                                 // by-value views of scans, so no scan may be re-sorted in place meanwhile
 };
 
 namespace gloc {
@@ -77,6 +77,10 @@ int store_build_order(gloc_scan_store* st, DevScan& s, int cs);
 // Copy of scan `id` (by value: the table may grow under another thread) with `order` = the launch order
 // for `cs` sources per lane (cs = 0: the scan is used as a target only, no order).  GLOC_ERR_INVALID if unknown.
 int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out);
+// A batch about to be enqueued pins the scans its jobs read (BEFORE its first launch, under the store's mutex: a re-sort
+// either sees the pins or has finished its own enqueue); gloc_scan_store_build_target_index refuses a pinned scan that
+// still needs the re-sort, and no other.  Ids no longer live are skipped by both.
+void store_pin(gloc_scan_store* st, const uint32_t* ids, size_t count, int delta);
 
 }  // namespace reg
 }  // namespace gloc

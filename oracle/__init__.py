@@ -256,7 +256,7 @@ def _ref_nn_backend():
 
 def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=3000, inlier_thresh=0.6,
                 min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
-                max_rmse=0.0, max_final_step=0.03):
+                max_rmse=0.0, max_final_step=0.0):
     """Candidates of one query registered on `threads` host threads (bench.py's all-cores leg)."""
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     ts = [np.ascontiguousarray(t, np.float32).reshape(-1, 3) for t in tgts]
@@ -277,7 +277,7 @@ def reg_many_mt(src, tgts, threads, ref_nn=False, cand_ids=None, ransac_iters=30
 
 def reg_one(src, tgt, init_T=None, cand_id=0, ransac_iters=3000, inlier_thresh=0.6,
             min_inlier_ratio=0.3, icp_iters=30, max_corr_dist=0.0, seed=1234, ransac_confidence=0.99,
-            ref_nn=False, max_rmse=0.0, max_final_step=0.03):
+            ref_nn=False, max_rmse=0.0, max_final_step=0.0):
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
     tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 3)
     prm = RegParams(ransac_iters, inlier_thresh, min_inlier_ratio, icp_iters, max_corr_dist, seed,

@@ -534,7 +534,10 @@ void oracle_reg_one_nn_step(const float* src_xyz, size_t n_src, const float* tgt
     MOVE_AND_MATCH();
     double Rd[9], td[3], Rn[9], tn[3];
     const uint32_t used = kabsch_pairs(moved, tgt_xyz, corr, n, I9, Z3, gate2, Rd, td, &last_step);
-    if (used < 3) break;
+    if (used < 3) { /* the ICP stops for want of correspondences: NOT converged, whatever its earlier updates were */
+      last_step = (double)INFINITY;
+      break;
+    }
     compose(Rd, td, Rc, tc, Rn, tn);
     memcpy(Rc, Rn, sizeof(Rn));
     memcpy(tc, tn, sizeof(tn));

@@ -70,7 +70,7 @@ def headline(capi):
     cand_sid = np.array([[place_sid[int(g)] for g in row] for row in idx], np.uint32)
     reg = capi.Registrar(store=store)
     prm = capi.default_reg_params(ransac_iters=bench.RANSAC_ITERS, icp_iters=bench.ICP_ITERS,
-                                  min_inlier_ratio=bench.MIN_INLIER_RATIO, max_rmse=bench.MAX_RMSE)
+                                  min_inlier_ratio=bench.MIN_INLIER_RATIO, max_rmse=bench.MAX_RMSE, max_final_step=bench.MAX_FINAL_STEP)
     out = reg.batch_multi(q_sid, cand_sid, params=prm)          # THE launch sequence: 25 x 20 = 500 jobs per launch
     yield dict(bench=bench, store=store, reg=reg, prm=prm, idx=idx, d2=d2, q_desc=q_desc, q_place=q_place, q_sid=q_sid,
                cand_sid=cand_sid, out=out, place_pose=place_pose, q_poses=q_poses, neg=neg)
@@ -91,7 +91,7 @@ def test_two_whole_queries_of_the_500_job_launch_match_the_checker(headline, ora
     h = headline
     store, out, b = h["store"], h["out"], h["bench"]
     use_ref = oracle_mod.have_ref()          # the reference's own nanoflann kd-tree as the 1-NN search
-    kw = dict(ransac_iters=b.RANSAC_ITERS, icp_iters=b.ICP_ITERS, min_inlier_ratio=b.MIN_INLIER_RATIO, max_rmse=b.MAX_RMSE)
+    kw = dict(ransac_iters=b.RANSAC_ITERS, icp_iters=b.ICP_ITERS, min_inlier_ratio=b.MIN_INLIER_RATIO, max_rmse=b.MAX_RMSE, max_final_step=b.MAX_FINAL_STEP)
     for qi in CHECKED_QUERIES:
         q = store.download(h["q_sid"][qi])
         assert q.shape[0] > 120000

@@ -84,7 +84,7 @@ def test_full_size_matches_the_independent_statement(reg, capi, scans):
     spec.loader.exec_module(mc)
     g = np.load(os.path.join(here, "golden", "reg_crosscheck.npz"))
     assert (g["full_size_crc"] == np.array([mc.crc(scans["B"]), mc.crc(scans["A"])], np.uint64)).all()   # the fixture's inputs
-    prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
+    prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0, max_final_step=0.03)   # (as the fixture was made)
     out = reg.batch(scans["B"], [scans["A"]], params=prm, stream_ids=[0])
     T, (rmse, inl, hyp, ok, fstep) = g["full_size_T"], g["full_size_meta"]
     assert abs(float(reg.final_steps(1)[0]) - fstep) < 2e-4
@@ -300,7 +300,7 @@ def test_max_rmse_acceptance(reg, capi, oracle_mod, scans):
 
 
 def test_convergence_gate_matches_oracle(reg, capi, oracle_mod, scans):
-    """gloc_reg_params.max_final_step (default 0.03 m): ok additionally requires that the last ICP update moved the
+    """gloc_reg_params.max_final_step (off by default; bench.py passes 0.03 m): ok additionally requires that the last ICP update moved the
     matched points by no more than that, RMS -- the ICP has converged.  The measure itself equals the oracle's
     (fp64 moments on both sides), so does ok at thresholds on either side of it; a different scene -- whose ICP keeps
     creeping -- is rejected where the same place, given passes enough, is accepted; without ICP passes the gate is off."""
@@ -323,6 +323,14 @@ def test_convergence_gate_matches_oracle(reg, capi, oracle_mod, scans):
     assert steps[0] < 0.01 < steps[1]              # 40 passes: the same place has converged, the other scene never does
     g = reg.batch(q, cands, params=capi.default_reg_params(ransac_iters=300, icp_iters=0))      # no ICP: nothing to converge
     assert bool(g["ok"][0]) and (reg.final_steps(2) == 0).all()
+    # An ICP that stops for want of correspondences (nothing within a micrometre) has NOT converged: its step reads +inf
+    # and the check, when asked for, rejects it -- in the kernel and in the checker (it read 0 and passed)
+    kw = dict(ransac_iters=300, icp_iters=3, max_corr_dist=1e-6)
+    g = reg.batch(q, cands[:1], params=capi.default_reg_params(**kw))
+    assert bool(g["ok"][0]) and np.isinf(reg.final_steps(1)[0])
+    g = reg.batch(q, cands[:1], params=capi.default_reg_params(max_final_step=0.03, **kw))
+    o = oracle_mod.reg_one(q, cands[0], max_final_step=0.03, **kw)
+    assert not bool(g["ok"][0]) and not o["ok"] and np.isinf(o["final_step"])
 
 
 def test_scan_store_ids_equal_host_buffers(reg, capi, scans):
@@ -609,6 +617,7 @@ def test_split_groups_decide_ties_by_the_original_index(capi, oracle_mod):
         assert (out["T"][0] == np.eye(4, dtype=np.float32)).all()
         idx, d2 = r.debug_corr(0, len(src))
         assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+        assert np.isinf(r.final_steps(1)[0])     # an ICP that stops for want of correspondences has not converged
         r.close()
 
 
@@ -654,12 +663,15 @@ def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
         with pytest.raises(capi.GlocError) as ei:
             call()
         assert ei.value.code == 5, ei.value                # GLOC_ERR_STATE
-    with pytest.raises(capi.GlocError) as ei:              # nor may a scan be re-sorted in place under a batch in flight
-        store.build_target_index_batch(cs[:1])
+    with pytest.raises(capi.GlocError) as ei:              # nor may a scan THE BATCH READS be re-sorted in place under it
+        store.build_target_index_batch(qs[:1])             # (a query scan of the batch, still in curve order)
     assert ei.value.code == 5
+    store.build_target_index_batch(cs[:1])                 # already in kd order: nothing to re-sort, no error (round 5)
+    fresh = store.add(np.ascontiguousarray(A[2::40]))
+    store.build_target_index_batch([fresh])                # a scan no batch in flight reads: re-sorted (add_keyframe's path)
     g = h[0].batch_multi_end()
     assert (bits(g["T"]) == bits(want[0]["T"])).all() and (g["inliers"] == want[0]["inliers"]).all()
-    store.build_target_index_batch(cs[:1])                 # (fine again)
+    store.build_target_index_batch(qs[:1])                 # (fine again)
     for r in h + [ref]:
         r.close()
     store.close()

@@ -94,7 +94,7 @@ FLOP_PER_PAIR = 8             # 3 sub + 3 mul + 2 add per 
 BYTES_PER_POINT_INDEXED = 16  # sorted float4 (x, y, z, original index)
 KNN_CFGB = (64, 10000)        # BASELINE.json configs[1]
 KNN_SHARD_ROWS = 125000       # one of the 8 shards of configs[4]
-PMC_FILES = ("r04_pmc_traffic_nn_compact.json", "r03_pmc_traffic_nn_compact.json", "r02_pmc_traffic_nn_compact.json")
+PMC_FILES = ("r05_pmc_traffic_nn_compact.json", "r04_pmc_traffic_nn_compact.json", "r03_pmc_traffic_nn_compact.json", "r02_pmc_traffic_nn_compact.json")
 
 
 def log(msg):
@@ -343,7 +343,7 @@ def cpu_baseline(q_scan, cand_scans, n_places, min_inlier_ratio, gpu_rows=None):
         t0 = time.time()
         oracle.knn_search(db, q, TOP_K)
         t_knn = time.time() - t0
-    kw = dict(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS, min_inlier_ratio=min_inlier_ratio, max_rmse=MAX_RMSE)
+    kw = dict(ransac_iters=RANSAC_ITERS, icp_iters=ICP_ITERS, min_inlier_ratio=min_inlier_ratio, max_rmse=MAX_RMSE, max_final_step=MAX_FINAL_STEP)
     t0 = time.time()
     res = [oracle.reg_one(q_scan, c, cand_id=i, ref_nn=use_ref, **kw) for i, c in enumerate(cand_scans)]
     t_reg = time.time() - t0
@@ -428,6 +428,9 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each step's queries inline")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="wait for a step's registration before the next step's is enqueued (round 2's loop)")
+    ap.add_argument("--reg-streams", type=int, choices=[1, 2], default=1,
+                    help="streams of the two pipelined registration handles: 1 = one stream (batch after batch), 2 = a stream "
+                         "each (two batches run side by side on the device)")
     ap.add_argument("--no-negatives", action="store_true", help="every place carries a world-A scan")
     ap.add_argument("--coarse", action="store_true",
                     help="also run the reference's 2-D step: the coarse (x, y, yaw) match of every (query, candidate) "
@@ -600,7 +603,8 @@ def main():
         tune(reg_b)
         reg_stream = torch.cuda.Stream(device=dev)
         reg.set_stream(reg_stream.cuda_stream)
-        reg_b.set_stream(reg_stream.cuda_stream)
+        reg_stream_b = torch.cuda.Stream(device=dev) if args.reg_streams == 2 else reg_stream
+        reg_b.set_stream(reg_stream_b.cuda_stream)
         regs.append(reg_b)
 
     def prof(name):

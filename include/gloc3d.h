@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLOC3D_ABI_VERSION 4
+#define GLOC3D_ABI_VERSION 5
 
 enum {
   GLOC_OK = 0,

@@ -17,7 +17,7 @@ def _index(capi, db, algo=0, **opts):
     return ix
 
 
-@pytest.mark.parametrize("algo", [1, 2, 0])
+@pytest.mark.parametrize("algo", [1, 2, 3, 0])   # exact, split-bf16 coarse, fp32-MFMA coarse, auto
 @pytest.mark.parametrize("case", KNN_CASES)
 def test_matches_reference_goldens(capi, case, algo):
     db, q, k, g_idx, g_bits = load_knn_case(case)

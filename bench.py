@@ -33,7 +33,11 @@ Prints ONE JSON line (rank 0):
   roofline              the dominant kernel (K4 point-NN), HIP-event timed inside the timed region;
   legs                  (N = 1) the same pipeline with each work-reducing choice switched off, and on harder
                         data: all 3000 RANSAC hypotheses scored; the brute-force 1-NN kernel; candidate poses
-                        drawn as SURVEY cfg C writes them; candidates 5-20 m away;
+                        drawn as SURVEY cfg C writes them; candidates 5-20 m away; 96 distinct ray-cast poses
+                        along a loop (data_loop_views); the convergence check on worlds it was not chosen on
+                        (gate_holdout);
+  top-level scalars     copies of the nested figures (knn_cfgB_us, lone_query_ms, knn_shard125k_q64_us,
+                        success_rate, loop_views_qps ...): the driver's record keeps scalar keys only;
   sub_records           (N = 1) BASELINE configs[1] (kNN 64 x 10k x 4096), configs[2] (one query alone incl.
                         its preparation), one shard of configs[4] (kNN over 125k x 4096);
   cpu_baseline          the CPU checker on this box's host cores: ONE WHOLE query (kNN + its 20 candidates),

@@ -419,7 +419,7 @@ def synth_fill_device(device, stream, kind, seed, first_row, n, dim, out_ptr, ro
 def default_reg_params(**over):
     p = RegParams()
     lib().gloc_reg_default_params(C.byref(p))
-    if os.environ.get("GLOC3D_MAX_FINAL_STEP"):          # developer override of the default convergence gate
+    if os.environ.get("GLOC3D_MAX_FINAL_STEP"):          # developer override of the convergence check's threshold
         p.max_final_step = float(os.environ["GLOC3D_MAX_FINAL_STEP"])
     for k_, v in over.items():
         setattr(p, k_, v)

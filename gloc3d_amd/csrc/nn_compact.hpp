@@ -218,13 +218,19 @@ __device__ __forceinline__ void nn_compact_body(
   // rotates: within a row of 8 slots by the row number, and from one group of slots to the next -- any regular pattern
   // in the jobs' costs (bench.py: every fourth candidate is from a different world, 22 % dearer) would otherwise
   // load the same XCDs in every group: measured, XCDs 1 and 5 of 8 carried every such job and the launch waited for them.
-  const uint32_t per = n_wg * job_group, grp = blockIdx.x / per, rem = blockIdx.x % per;
-  const uint32_t slot = rem % job_group, wgv = rem / job_group;
+  // (round 5: the grid is (slots of a group, work-groups of a slot, groups) -- the same linear order, slot fastest, and the
+  // three divisions of a one-dimensional block index by run-time values are gone: 12 vector + 60 scalar instructions a wave)
+  const uint32_t grp = blockIdx.z, slot = blockIdx.x, wgv = blockIdx.y;
+  const uint32_t lin_block = slot + job_group * (wgv + n_wg * grp);
   uint32_t vin = slot;  // the virtual job of the slot, within the group
   if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
   const uint32_t vjob = grp * job_group + vin;
   if (vjob >= n_jobs * subs) return;
-  const uint32_t job = vjob / subs, wg = wgv * subs + vjob % subs;
+  uint32_t job = vjob, wg = wgv;
+  if (subs != 1u) {  // (uniform; shares of a job only in small batches: the usual launch pays no division)
+    job = vjob / subs;
+    wg = wgv * subs + vjob % subs;
+  }
   const Job& J = jobs[job];
   const uint32_t n_src = J.n_src;
   // the first sp.hx waves of a job are helpers (they start with the job's widest groups); then one wave per group
@@ -864,7 +870,7 @@ __device__ __forceinline__ void nn_compact_body(
   NN_MARK("sweep_end");
   // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
   // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
-  if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (blockIdx.x % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
+  if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (lin_block % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
   if (SPLIT && lane == 0) {
     const uint32_t wk = (part == 0 ? NN_W_FIXED : 0u) + NN_W_CAND * w_cand + NN_W_CHUNK * n_processed + NN_W_ITEM * (uint32_t)n_items;
     uint32_t* wp = sp.work + (size_t)job * n_part + gi;
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ void nn_compact_body(
   }
   NN_MARK("end");
   if (TRACE && trace && lane == 0) {
-    const size_t wid = (size_t)blockIdx.x * NN_WPB + w;
+    const size_t wid = (size_t)lin_block * NN_WPB + w;
     uint32_t* tw = trace + NN_TRACE_WORDS * wid;
     const unsigned long long t_end = now();
     tw[0] = (uint32_t)(t_end - t_start);

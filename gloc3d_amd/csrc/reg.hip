@@ -155,6 +155,10 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     const uint32_t jg = (uint32_t)h->nn_job_group;
     const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
     const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
+    // (launched as (slots of a group, work-groups of a slot, groups): the same linear order without the divisions)
+    GLOC_REQUIRE(n_wg <= 65535u && (n_slots + jg - 1) / jg <= 65535u, GLOC_ERR_INVALID,
+                 "the culled search's grid: %u work-groups per job slot (scans above ~8 M points) or %u job groups exceed 65535", n_wg,
+                 (n_slots + jg - 1) / jg);
     if (h->trace_on) {
       h->trace_waves = (size_t)grid * NN_WPB;
       if (h->trace.ensure(h->trace_waves * 4 * NN_TRACE_WORDS, h->stream)) return GLOC_ERR_NOMEM;
@@ -176,7 +180,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
   } while (0)
 #define LAUNCH_COMPACT_T(CS_, P_, T_, S_, W_) LAUNCH_COMPACT_K((nn_compact_kernel<CS_, P_, T_, S_, W_>), P_)
 #define LAUNCH_COMPACT_K(K_, P_)                                                                         \
-  hipLaunchKernelGGL(K_, dim3(grid), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
+  hipLaunchKernelGGL(K_, dim3(jg, n_wg, (n_slots + jg - 1) / jg), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
                      bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \

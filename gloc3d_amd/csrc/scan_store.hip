@@ -1044,6 +1044,10 @@ int gloc_scan_store_release(gloc_scan_store* st, uint32_t scan_id) {
   std::lock_guard<std::mutex> lk(st->mu);
   GLOC_REQUIRE(scan_id < st->scans.size() && st->scans[scan_id].live, GLOC_ERR_INVALID, "unknown scan id %u",
                scan_id);
+  // (its block would go back to the cache and be handed to the next upload while the batch's kernels still read it)
+  GLOC_REQUIRE(st->scans[scan_id].pins == 0, GLOC_ERR_STATE,
+               "scan %u is read by %d registration batch(es) in flight (gloc_reg_batch_multi_begin without _end)", scan_id,
+               st->scans[scan_id].pins);
   st->live_count--;
   st->live_bytes -= st->scans[scan_id].block_bytes;
   store_free_scan(st, st->scans[scan_id], true);

@@ -666,6 +666,9 @@ def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
     with pytest.raises(capi.GlocError) as ei:              # nor may a scan THE BATCH READS be re-sorted in place under it
         store.build_target_index_batch(qs[:1])             # (a query scan of the batch, still in curve order)
     assert ei.value.code == 5
+    with pytest.raises(capi.GlocError) as ei:              # ... nor released: its memory would be handed to the next upload
+        store.release(qs[0])
+    assert ei.value.code == 5
     store.build_target_index_batch(cs[:1])                 # already in kd order: nothing to re-sort, no error (round 5)
     fresh = store.add(np.ascontiguousarray(A[2::40]))
     store.build_target_index_batch([fresh])                # a scan no batch in flight reads: re-sorted (add_keyframe's path)

@@ -9,3 +9,5 @@ python tools/pmc_traffic_json.py $O/r05_bench_n1_pmc_summary.json $O/r05_bench_n
 cp profiles/r05_pmc_traffic_nn_compact.json $O/r05_pmc_traffic_nn_compact.json
 python bench.py --steps 20 --warmup 5 > $O/r05_bench_n1.json 2> $O/r05_bench_n1.err
 python tools/bench_line.py < $O/r05_bench_n1.json
+timeout -k 10 300 python tools/fuzz_reg.py 3000 55 > $O/r05_reg_fuzz.txt 2>&1; tail -2 $O/r05_reg_fuzz.txt
+timeout -k 10 300 python tools/fuzz_knn.py 300 12 > $O/r05_knn_fuzz.txt 2>&1; tail -2 $O/r05_knn_fuzz.txt

@@ -919,12 +919,12 @@ __device__ __forceinline__ void nn_compact_body(
         const float dz = pz[s] - t[s][u].z;
         const float d2 = (sxy.x + sxy.y) + dz * dz;
         const uint32_t o = __float_as_uint(t[s][u].w);  // padding carries 0xFFFFFFFF: never smaller
-        // the un-fused minimum of the quarter (the search compared fused distances), smallest original index first
-        if (d2 < bd || (d2 == bd && o < bj)) {
-          bd = d2;
-          bj = o;
-          bpos[s] = bch[s] * (SB / 4) + u;
-        }
+        // the un-fused minimum of the quarter (the search compared fused distances), smallest original index first.
+        // (Selects, not branches: from `a || (b && c)` the compiler made four exec-mask branches a target, 32 a wave.)
+        const bool take = (d2 < bd) | ((d2 == bd) & (o < bj));
+        bd = take ? d2 : bd;
+        bj = take ? o : bj;
+        bpos[s] = take ? bch[s] * (SB / 4) + u : bpos[s];
       }
       if (bpos[s] != 0xFFFFFFFFu) best[s] = bd;
     }

@@ -35,6 +35,19 @@ def test_abi_version_and_defaults(capi):
     assert capi.reg_select_first_ok([0, 0]) == -1
 
 
+def test_bench_passes_the_suggested_convergence_threshold():
+    """bench.py opts into the convergence check explicitly (the library default is off): the value it passes is the one
+    include/gloc3d.h names."""
+    import os, re, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    hdr = open(os.path.join(root, "include", "gloc3d.h")).read()
+    m = re.search(r"#define\s+GLOC_REG_FINAL_STEP_SUGGESTED\s+([0-9.]+)f", hdr)
+    assert m, "GLOC_REG_FINAL_STEP_SUGGESTED is declared"
+    sys.path.insert(0, root)
+    import bench
+    assert abs(float(m.group(1)) - bench.MAX_FINAL_STEP) < 1e-9
+
+
 def test_no_cpu_fallback_without_gpu(capi):
     if capi.lib().gloc_device_count() > 0:
         pytest.skip("a GPU is visible")

@@ -1058,7 +1058,7 @@ def main():
                 "prep_ms": float(np.median([b for _, b in t_lone[2:]])) * 1e3,
                 "ms_per_query_with_stage_events": float(np.median([a for a, _ in t_prof[2:]])) * 1e3,
                 "nn_launch_ms": ms1 / max(n1, 1), "nn_ms_per_query": ms1 / 8, "solve_launch_ms": mss / max(ns, 1),
-                "heavy_group_plan": "default (gloc_reg_set_option NN_SPLIT_HELPERS -1: 256 wave slots per job at 20 jobs, threshold 60000 cycles, 4 slots per job in the launch order)",
+                "heavy_group_plan": "default (gloc_reg_set_option NN_SPLIT_HELPERS -1: 256 wave slots per job at 20 jobs, threshold 60000 cycles, 8 slots per job in the launch order)",
                 "what": "BASELINE configs[2]: 1 query x 20 full-size candidates, RANSAC 3000 adaptive + ICP 20, batch of ONE: "
                         "scan H2D + index, descriptor H2D, top-20, registration, release -- wall clock, nothing overlapped "
                         "(retrieval enqueued beside the scan's indexing was tried in round 5: 3.09 -> 3.16 ms)"}

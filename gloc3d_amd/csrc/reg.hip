@@ -148,7 +148,8 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
     const uint32_t n_wg_job = (bd.max_groups + h->split.hx + NN_WPB - 1) / NN_WPB;  // helper waves first, then one per group
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
-    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 4u : 1u);
+    // (8 shares -- one per XCD -- since round 5: one query alone 105.4 -> 104.1 / 104.4 us per pass against 4)
+    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 8u : 1u);
     // (one group of all the slots of a small batch, so that every job's helpers start at the head of the launch, was
     // tried: one query alone 0.115 ms per pass against 0.108 with groups of 24)
     const uint32_t n_slots = bd.n_jobs * subs;

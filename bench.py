@@ -1278,6 +1278,12 @@ def main():
             "coarse_kernel_frac_of_bf16_mfma_peak": 3.0 * flop / (kern["dist_mfma"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS if kern["dist_mfma"] > 0 else None,
             "coarse_kernel_frac_of_hbm": 4.0 * KNN_CFGB[1] * DIM / (kern["dist_mfma"] * 1e-6) / 1e9 / PEAK_HBM_GBS if kern["dist_mfma"] > 0 else None,
             "queries_fallback": st_["queries_fallback"],
+            # SURVEY 8d asked that cache-resident runs be labelled: 164 MB of rows < the 256 MiB Infinity Cache and the searches run
+            # back to back, so after the first one the rows most likely come from it, not from HBM; FETCH_SIZE (185 MB per coarse
+            # launch after the guide's doubling, profiles/r05_knn_cfgB_pmc.json) counts Infinity-Cache hits too and cannot tell
+            "infinity_cache_resident": True,
+            "infinity_cache_note": "the 164 MB database fits the 256 MiB Infinity Cache and the timed searches run back to back; the L2-miss "
+                                   "counter (FETCH_SIZE, 185 MB per coarse launch) includes Infinity-Cache hits, so residency is inferred, not counted",
             "what": "BASELINE configs[1]: 64 queries x 10 000 x 4096 fp32, device resident, wall clock over 50 back-to-back searches. "
                     "Round 4: the coarse pass runs on the bf16 matrix cores (operands split in two bf16 values, three MFMAs per "
                     "product, a proven bound on what that drops; results bit-identical), so the search's roofline is the rows' "

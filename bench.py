@@ -1440,7 +1440,7 @@ def main():
             "nn_launch_ms": roofline.get("launch_ms") if roofline else None, "roofline_frac": roofline.get("frac") if roofline else None}
     if "knn_cfgB" in sr:
         flat.update(knn_cfgB_us=sr["knn_cfgB"]["us_per_search"], knn_cfgB_frac=sr["knn_cfgB"]["frac_of_roofline"],
-                    knn_cfgB_fallbacks=sr["knn_cfgB"]["queries_fallback"])
+                    knn_cfgB_fallbacks=sr["knn_cfgB"]["queries_fallback"], knn_cfgB_infinity_cache_resident=sr["knn_cfgB"]["infinity_cache_resident"])
     if "knn_shard_125k" in sr:
         flat.update(knn_shard125k_q64_us=sr["knn_shard_125k"]["q64"]["us_per_search"], knn_shard125k_q64_frac=sr["knn_shard_125k"]["q64"]["frac_of_roofline"],
                     knn_shard125k_q1_us=sr["knn_shard_125k"]["q1"]["us_per_search"])

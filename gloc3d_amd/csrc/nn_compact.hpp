@@ -1039,49 +1039,33 @@ __device__ __forceinline__ void nn_compact_body(
 #pragma unroll
   for (int k = 0; k < 17; ++k) mv[k] = 0.f;
   const float cen[3] = {0.5f * (wlo[0] + whi[0]), 0.5f * (wlo[1] + whi[1]), 0.5f * (wlo[2] + whi[2])};
-  // (Round 5: no branches around the moments.  The matched targets of the lane's sources are loaded together and
-  // unconditionally -- a lane without a correspondence reads target 0 -- and a source that does not count enters the sums
-  // as zeros (x + 0 = x and fma(0, 0, x) = x exactly; the sums start at +0 and never become -0): the same bits as the nested
-  // `if`s, which cost two dependent L1 round trips, six exec-mask branches and 35 register clears a wave.)
-  f32x4 qv[CS];
-  bool has[CS];
 #pragma unroll
   for (int s = 0; s < CS; ++s) {
-    has[s] = valid[s] && bpos[s] != 0xFFFFFFFFu;
-    qv[s] = f32x4{NN_FAR, NN_FAR, NN_FAR, 0.f};
-    if (ix.n) qv[s] = ix.pts[has[s] ? bpos[s] : 0u];  // (uniform; just loaded above: an L1 hit)
-  }
-#pragma unroll
-  for (int s = 0; s < CS; ++s) {
+    if (!valid[s]) continue;
     const size_t o = (size_t)job * ld + wave_base + s * 64 + lane;
-    if (valid[s]) {
-      corr[o] = bpos[s];
-      d2out[o] = best[s];
-    }
+    corr[o] = bpos[s];
+    d2out[o] = best[s];
     f32x4 q = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // no correspondence (empty target): never an inlier
-    if (has[s]) q = f32x4{qv[s].x, qv[s].y, qv[s].z, 0.f};
-    if constexpr (!PAIRS) {  // (the pass that writes the pairs is refitted from them: no moments)
+    if (bpos[s] != 0xFFFFFFFFu) {
+      q = ix.pts[bpos[s]];  // just loaded above: an L1 hit
+      q.w = 0.f;
       const float d2 = best[s];
-      const bool use = has[s] && (!(gate2 > 0.f) || d2 < gate2);
-      mv[16] += has[s] ? d2 : 0.f;
-      float P[3] = {px[s] - cen[0], py[s] - cen[1], pz[s] - cen[2]};
-      float Q[3] = {q.x - cen[0], q.y - cen[1], q.z - cen[2]};
+      if constexpr (!PAIRS) mv[16] += d2;
+      if (!PAIRS && (!(gate2 > 0.f) || d2 < gate2)) {  // (the pass that writes the pairs is refitted from them: no moments)
+        const float P[3] = {px[s] - cen[0], py[s] - cen[1], pz[s] - cen[2]};
+        const float Q[3] = {q.x - cen[0], q.y - cen[1], q.z - cen[2]};
+        mv[0] += 1.f;
+        pp = __builtin_fmaf(P[2], P[2], __builtin_fmaf(P[1], P[1], __builtin_fmaf(P[0], P[0], pp)));
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        P[a] = use ? P[a] : 0.f;
-        Q[a] = use ? Q[a] : 0.f;
-      }
-      mv[0] += use ? 1.f : 0.f;
-      pp = __builtin_fmaf(P[2], P[2], __builtin_fmaf(P[1], P[1], __builtin_fmaf(P[0], P[0], pp)));
+        for (int a = 0; a < 3; ++a) {
+          mv[1 + a] += P[a];
+          mv[4 + a] += Q[a];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        mv[1 + a] += P[a];
-        mv[4 + a] += Q[a];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) mv[7 + 3 * a + b] = __builtin_fmaf(P[a], Q[b], mv[7 + 3 * a + b]);
+          for (int b = 0; b < 3; ++b) mv[7 + 3 * a + b] = __builtin_fmaf(P[a], Q[b], mv[7 + 3 * a + b]);
+        }
       }
     }
-    if (PAIRS && valid[s]) {
+    if (PAIRS) {
       pairs[o * 2 + 0] = f32x4{px[s], py[s], pz[s], 0.f};
       pairs[o * 2 + 1] = q;
     }

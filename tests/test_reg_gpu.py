@@ -680,6 +680,71 @@ def test_begin_end_pipeline_on_a_shared_stream(capi, scans):
     store.close()
 
 
+def test_views_and_pins_are_taken_in_one_step(capi, scans):
+    """gloc_reg_batch_multi_begin took its by-value scan views first and pinned the scans afterwards, so a
+    re-sort (add_keyframe's gloc_scan_store_build_target_index) or a release from another thread in between left the
+    batch with a stale view.  Views and pins are now one step under the store's mutex: (1) a begin that fails on an
+    unknown id pins nothing; (2) with another thread re-sorting the batch's candidates into kd order all the while, every
+    batch equals the quiet run bit for bit (a re-sort either happens before the views are taken or is refused)."""
+    import threading
+    import time
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    q = store.add(np.ascontiguousarray(B[::20]))
+    c0 = store.add(np.ascontiguousarray(A[::6]))
+    prm = capi.default_reg_params(ransac_iters=200, icp_iters=4)
+    r = capi.Registrar(store=store)
+    with pytest.raises(capi.GlocError):
+        r.batch_multi_begin([q], np.array([[c0, 123456]], np.uint32), params=prm)      # an id that does not exist
+    store.release(c0)                                        # nothing was left pinned by the failed begin ...
+    with pytest.raises(capi.GlocError):
+        r.batch_multi_end()                                  # ... and no batch is in flight
+    thin = [np.ascontiguousarray(x) for x in (A[::6], A[1::7], Cc[::6], A[2::8])]
+    quiet_ids = [store.add(x) for x in thin]
+    store.build_target_index_batch(quiet_ids)
+    want = r.batch_multi([q], np.array([quiet_ids], np.uint32), params=prm)
+    stop, refused, errors = threading.Event(), [0], []
+    shared = {"ids": None}
+
+    def resorter():
+        while not stop.is_set():
+            ids = shared["ids"]
+            if ids is None:
+                time.sleep(0.0002)
+                continue
+            for i in ids:
+                try:
+                    store.build_target_index_batch([i])
+                except capi.GlocError as e:
+                    if e.code == 5:
+                        refused[0] += 1                      # pinned by the batch in flight: refused, as documented
+                    elif e.code != 1:                        # (GLOC_ERR_INVALID: the main thread has released the id meanwhile)
+                        errors.append(e)
+    th = threading.Thread(target=resorter)
+    th.start()
+    try:
+        for rep in range(12):
+            ids = [store.add(x) for x in thin]               # fresh candidates in curve order ...
+            shared["ids"] = ids                              # ... which the other thread starts re-sorting at once
+            g = r.batch_multi([q], np.array([ids], np.uint32), params=prm)
+            shared["ids"] = None
+            # kd order or curve order, the registration's result is the same (test_target_index_*): bit for bit
+            assert (bits(g["T"]) == bits(want["T"])).all() and (g["inliers"] == want["inliers"]).all(), rep
+            for i in ids:
+                while True:
+                    try:
+                        store.release(i)
+                        break
+                    except capi.GlocError as e:
+                        assert e.code == 5
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    r.close()
+    store.close()
+
+
 def test_first_success_equals_select_over_the_full_batch(capi, scans):
     """The reference's stop-at-first-success loop (global_localization.cpp:519-572) for several queries at once:
     the same rank and pose, bit for bit, as registering all candidates and selecting afterwards -- with fewer

@@ -171,13 +171,13 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // search in the target's curve keys) is not in the kernel at all: measured, its mere presence cost the warm passes
 // -- 92 % of the 1-NN time -- 3 % (registers, code layout).
 template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */,
-          bool WARM = false>
+          bool WARM = false, bool HEAVY = false /* the second launch of a cold pass: the groups its waves gave up (NnHeavy) */>
 __device__ __forceinline__ void nn_compact_body(
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg /* per slot */, uint32_t subs,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
-    size_t ld, float gate2, NnSplit sp, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
+    size_t ld, float gate2, NnSplit sp, NnHeavy hv, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
     uint32_t* __restrict__ trace /* dev only: [wave][NN_TRACE_WORDS]: counts in words 0-7, cycles per region in 8-19 (tools/dev_nn_trace3.py) */) {
   constexpr int S = 64 * CS;        // sources per wave
   constexpr int NSB = CH / SB;      // sub-blocks per chunk
@@ -220,23 +220,44 @@ __device__ __forceinline__ void nn_compact_body(
   // load the same XCDs in every group: measured, XCDs 1 and 5 of 8 carried every such job and the launch waited for them.
   // (round 5: the grid is (slots of a group, work-groups of a slot, groups) -- the same linear order, slot fastest, and the
   // three divisions of a one-dimensional block index by run-time values are gone: 12 vector + 60 scalar instructions a wave)
-  const uint32_t grp = blockIdx.z, slot = blockIdx.x, wgv = blockIdx.y;
-  const uint32_t lin_block = slot + job_group * (wgv + n_wg * grp);
-  uint32_t vin = slot;  // the virtual job of the slot, within the group
-  if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
-  const uint32_t vjob = grp * job_group + vin;
-  if (vjob >= n_jobs * subs) return;
-  uint32_t job = vjob, wg = wgv;
-  if (subs != 1u) {  // (uniform; shares of a job only in small batches: the usual launch pays no division)
-    job = vjob / subs;
-    wg = wgv * subs + vjob % subs;
+  static_assert(!HEAVY || (SPLIT && !WARM && NN_WPB == 1), "the redo of a cold pass's heavy groups folds its parts as the planned split does");
+  uint32_t lin_block, job, wg = 0, heavy_e = 0;
+  if constexpr (HEAVY) {
+    // all parts of a list entry on ONE XCD (work-groups go to the XCDs round-robin: XCD = blockIdx % 8), so that the
+    // target's boxes and points are fetched into one L2, not eight: block b -> XCD x = b % 8, part (b / 8) % PARTS,
+    // entry 8 * (b / 8 / PARTS) + x.  (The list's length is read here: the host never sees it.)
+    lin_block = blockIdx.x;
+    heavy_e = 8u * (blockIdx.x / (8u * NN_HEAVY_PARTS)) + (blockIdx.x & 7u);
+    const uint32_t n_listed = *(CPTR(uint32_t))hv.count;
+    if (heavy_e >= (n_listed < hv.cap ? n_listed : hv.cap)) return;
+    job = ((CPTR(uint32_t))hv.list)[2 * heavy_e];
+  } else {
+    const uint32_t grp = blockIdx.z, slot = blockIdx.x, wgv = blockIdx.y;
+    lin_block = slot + job_group * (wgv + n_wg * grp);
+    uint32_t vin = slot;  // the virtual job of the slot, within the group
+    if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
+    const uint32_t vjob = grp * job_group + vin;
+    if (vjob >= n_jobs * subs) return;
+    job = vjob;
+    wg = wgv;
+    if (subs != 1u) {  // (uniform; shares of a job only in small batches: the usual launch pays no division)
+      job = vjob / subs;
+      wg = wgv * subs + vjob % subs;
+    }
   }
   const Job& J = jobs[job];
   const uint32_t n_src = J.n_src;
   // the first sp.hx waves of a job are helpers (they start with the job's widest groups); then one wave per group
   uint32_t gi, part = 0, parts = 1, hid = 0, plan_word = 0;
   bool own_wave = true;  // the group's own wave at its rank (not a helper)
-  {
+  if constexpr (HEAVY) {
+    gi = ((CPTR(uint32_t))hv.list)[2 * heavy_e + 1];
+    part = (blockIdx.x >> 3) % NN_HEAVY_PARTS;
+    parts = NN_HEAVY_PARTS;
+    hid = heavy_e;
+    own_wave = false;
+    if (gi >= J.n_groups) return;
+  } else {
     const uint32_t wv = __builtin_amdgcn_readfirstlane(wg * NN_WPB + w);
     if (SPLIT && wv < sp.hx) {
       const uint32_t hw = ((CPTR(uint32_t))sp.helper)[(size_t)job * sp.hx + wv];  // (wave-uniform: scalar loads)
@@ -279,7 +300,7 @@ __device__ __forceinline__ void nn_compact_body(
   for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
 
   const uint32_t wave_base = ((CPTR(uint32_t))J.src_order)[gi] * S;
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT && !HEAVY) {
     if (own_wave && (plan_word & 0xFFu) != 0u) return;  // the helpers have this group, all its parts
     hid = plan_word >> 8;
   }
@@ -344,7 +365,18 @@ __device__ __forceinline__ void nn_compact_body(
       b0s[s] = pj[s] / (SB / 4);  // the key's low word: (sub-block << 2) | quarter of the sub-block
     }
   }
-  if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
+  uint8_t tie0[CS];
+#pragma unroll
+  for (int s = 0; s < CS; ++s) tie0[s] = 0;
+  if constexpr (HEAVY) {  // the bounds (and contested flags) of the wave that gave the group up: hv.hkey
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      const unsigned long long k = hv.hkey[(size_t)hid * S + s * 64 + lane];
+      best[s] = __uint_as_float((uint32_t)(k >> 32));
+      b0s[s] = (uint32_t)k & 0x7FFFFFFFu;
+      tie0[s] = (uint8_t)(((uint32_t)k >> 31) & 1u);
+    }
+  } else if constexpr (!WARM) {  // (a warm pass: a point that found no neighbour -- a NaN -- searches without a bound)
     // lower_bound over the sorted keys, (KP + 1)-way: KP independent probes per round trip.  The binary search took 17
     // dependent trips at 124 k keys (46 % of a cold wave's time, traced); nine-way (8 probes, 7 trips, 56 loads) made the
     // memory pipe the limit (every lane its own addresses: 40 %); five-way is 8 trips of 4.  The lane's CS sources search
@@ -449,7 +481,7 @@ __device__ __forceinline__ void nn_compact_body(
     const int slot = s * 64 + lane;
     L.src[slot] = f32x4{px[s], py[s], pz[s], 0.f};
     L.key[slot] = ((unsigned long long)__float_as_uint(best[s]) << 32) | b0;
-    L.tie[slot] = 0;
+    L.tie[slot] = tie0[s];
   }
   if (lane == 0) {  // the dummy slot: a negative bound -- no box lower bound (>= 0) passes it
     L.src[S] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -508,49 +540,6 @@ __device__ __forceinline__ void nn_compact_body(
     const float ez = axis_e(bc.z - wc[2], bnh.z + wnh[2]);
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
   };
-#if defined(GLOC_NN_RET) && GLOC_NN_RET == 6  // dev (timing only): no sweep at all -- prologue + epilogue
-  for (uint32_t s0 = 0; s0 < (wmax_s > -2.f ? 0u : ix.nsup); s0 += 64) {
-#else
-  for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
-#endif
-    float lbs = __builtin_inff();  // (not FLT_MAX: a wave whose bound is still FLT_MAX -- a non-finite source point -- must not pass lanes past the end)
-    if (s0 + lane < ix.nsup) {
-      const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
-      lbs = box_box_lb(ulo, uhi);
-    }
-    unsigned long long smask = __builtin_amdgcn_ballot_w64(lbs <= wmax_s);
-    // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
-    f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
-    int cur = -1;
-    if (smask) {
-      cur = __ffsll((long long)smask) - 1;
-      smask &= smask - 1;
-      const uint32_t cl = (s0 + cur) * 64 + lane;
-      if (cl < ix.nchunks) { nlo = ix.box_lo[cl]; nhi = ix.box_hi[cl]; }
-    }
-    while (cur >= 0) {
-    const unsigned long long t_b0 = now();
-    const uint32_t c0 = (s0 + cur) * 64;
-    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax_s;
-    const uint32_t cl = c0 + lane;
-    const f32x4 blo = nlo, bhi = nhi;
-    cur = -1;
-    if (smask) {
-      cur = __ffsll((long long)smask) - 1;
-      smask &= smask - 1;
-      const uint32_t cn = (s0 + cur) * 64 + lane;
-      if (cn < ix.nchunks) { nlo = ix.box_lo[cn]; nhi = ix.box_hi[cn]; }
-    }
-    if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
-    float lbw = __builtin_inff();
-    if (cl < ix.nchunks) lbw = chunk_box_lb(blo, bhi);
-    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax_s);
-    if constexpr (SPLIT) {
-      mask &= pmask;
-      w_cand += (uint32_t)__popcll(mask);
-    }
-    if constexpr (TRACE) a_batch += now() - t_b0;
-  NN_MARK("batch_tested");
     // the lane-level test of one chunk box: which of the lane's sources can still use the chunk
     auto lane_test = [&](const f32x4& bc, const f32x4& bnh, bool (&need)[CS], unsigned long long (&nm)[CS]) {
       unsigned long long nm_any = 0ull;  // the ballots, taken where the comparisons are made
@@ -563,34 +552,11 @@ __device__ __forceinline__ void nn_compact_body(
       }
       return nm_any;
     };
-    // A wave over a sparse stretch of the curve (the far field: 128 points in a box of 60 m x 130 m, each 0.2 m from
-    // its neighbour) lists hundreds of candidates here and fails nearly all of them at the lane level: it is the wave
-    // a launch of few jobs waits for, and a scalar load per candidate (a miss in the scalar cache: ~400 cycles, nothing
-    // to overlap it with) is most of its time.  A batch with many survivors is therefore thinned first, with each box
-    // taken from the lane that holds it (v_readlane: no memory): what remains goes through the loop below.
-    if (__popcll(mask) > GLOC_NN_THIN_MIN) {
-      const unsigned long long t_t0 = now();
-      unsigned long long keep = 0ull;
-      while (mask) {
-        const int b = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); };
-        const f32x4 lo = {rl(blo.x), rl(blo.y), rl(blo.z), 0.f}, hi = {rl(bhi.x), rl(bhi.y), rl(bhi.z), 0.f};
-        bool need[CS];
-        unsigned long long nm[CS];
-        if constexpr (TRACE) n_cand++;
-        if (lane_test(lo, hi, need, nm) != 0ull) keep |= 1ull << b;
-      }
-      mask = keep;
-      if constexpr (TRACE) a_thin += now() - t_t0;
-    }
-    while (mask) {
-      const int b = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const unsigned long long t_k0 = now();
-      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax_s) continue;
-      const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
-      if constexpr (TRACE) n_cand++;
+    // One candidate chunk: the lane-level test of its box, and -- if a source can still use it -- staging, listing, the
+    // sub-block tests, the evaluation rounds, the refresh of the bounds.  A lambda since round 6: the cold pass calls it
+    // for its SEED chunks before the sweep as well (below); the warm kernel has the one call site it always had.
+    bool gave_up = false;  // (cold pass: the wave has handed its group to the second launch -- NnHeavy)
+    auto visit = [&](const uint32_t c, const bool last, const unsigned long long t_k0) {
       // the chunk's box straight into scalar registers (round 3: six v_readlane from the lane that tested it before)
       const f32x4 lo = ix.cbox_lo[c], hi = ix.cbox_hi[c];
       bool need[CS];
@@ -607,11 +573,31 @@ __device__ __forceinline__ void nn_compact_body(
 #endif
       const unsigned long long nm_any = lane_test(lo, hi, need, nm);
       if constexpr (TRACE) a_cand += now() - t_k0;
-      if (nm_any == 0ull) continue;
+      if (nm_any == 0ull) return;
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 2  // dev (timing only): candidates are tested, none is processed
-      if (nm_any != 0x12345ull) continue;
+      if (nm_any != 0x12345ull) return;
 #endif
       n_processed++;  NN_MARK("candidate_tested");
+      if constexpr (!WARM && !HEAVY) {
+        // a cold wave this deep into its sweep is one of the heavy ones (p99 of a cold wave: ~30 chunks): hand the group to
+        // the second launch and leave -- nothing has been written yet (outputs are the epilogue's)
+        if (hv.cap != 0u && parts == 1 && n_processed == hv.thresh) {
+          uint32_t e = 0;
+          if (lane == 0) e = atomicAdd(hv.count, 1u);
+          e = __builtin_amdgcn_readfirstlane(e);
+          if (e < hv.cap) {
+            if (lane == 0) {
+              hv.list[2 * e] = job;
+              hv.list[2 * e + 1] = gi;
+            }
+#pragma unroll
+            for (int s = 0; s < CS; ++s)  // (the previous chunk's rounds have all been committed: visit() ends behind a barrier)
+              hv.hkey[(size_t)e * S + s * 64 + lane] = L.key[s * 64 + lane] | (L.tie[s * 64 + lane] ? 0x80000000ull : 0ull);
+            gave_up = true;
+            return;
+          }  // (the list is full: the wave goes on by itself)
+        }
+      }
 
       const unsigned long long t_c0 = now();
       // stage the chunk (wave-private LDS; padding never wins) and fetch its 8 sub-block boxes
@@ -844,7 +830,30 @@ __device__ __forceinline__ void nn_compact_body(
   NN_MARK("refresh");
       // (the registers' copies of the bounds serve the tests of LATER candidates: after the wave's last one -- no bit left
       // in this batch, no batch prefetched, no further group of super-chunks -- nobody reads them)
-      if (mask == 0ull && cur < 0 && s0 + 64 >= ix.nsup) continue;
+      if (last) return;
+      if constexpr (HEAVY) {
+        // The parts of a group SHARE their bounds (hv.hkey: a board of one key per source, device-scope atomic min): a part
+        // sees an eighth of the chunks, and on its own would search with the nearest point of ITS eighth as the bound --
+        // on dense ground a ball as full as the whole wave's (measured: the second launch took as long as the waves it
+        // replaced).  Every fourth processed chunk a part puts its keys on the board and adopts what is smaller there --
+        // distance AND location: a location is a place in the target, so any part can recover it.  A minimum that is
+        // contested ACROSS parts (within NN_NEAR of the adopted one, in another sub-block) takes the tie path like one
+        // contested inside a wave; so does an adopted key whose owner had flagged it.
+        if ((n_processed & 3u) == 0u) {
+#pragma unroll
+          for (int s = 0; s < CS; ++s) {
+            const int slot = s * 64 + lane;
+            const unsigned long long k = L.key[slot];
+            const unsigned long long old = __hip_atomic_fetch_min(hv.hkey + (size_t)hid * S + slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long oldk = old & ~0x80000000ull;
+            if (oldk < k) {
+              const float od = __uint_as_float((uint32_t)(oldk >> 32)), md = __uint_as_float((uint32_t)(k >> 32));
+              if ((old & 0x80000000ull) != 0ull || (md <= od * (1.0f + NN_NEAR) && ((uint32_t)oldk >> 2) != ((uint32_t)k >> 2))) L.tie[slot] = 1;
+              L.key[slot] = oldk;
+            }
+          }
+        }
+      }
       bool changed = false;
 #pragma unroll
       for (int s = 0; s < CS; ++s) {
@@ -864,6 +873,131 @@ __device__ __forceinline__ void nn_compact_body(
         a_refresh += t_e - t_f0;
         t_chunks += t_e - t_c0;
       }
+    };
+  // ---- cold pass only: the SEED chunks first (round 6) -------------------------------------------------------
+  // A cold source's bound is its distance to the best of five curve neighbours: within 1.2 x the true distance for half of
+  // the sources, but 8 x for a tenth and 50 x for a hundredth (CPU model on bench.py's distinct ray-casts) -- and the sweep
+  // visits the chunks in index order, so such a source drags every chunk its loose ball touches through the tests until its
+  // own neighbourhood comes up.  On the sensor's near field, where a ball of 3 m holds 10 000 ground points, that made
+  // waves of 3.6 M cycles (1.7 ms: as long as the whole launch of 160 jobs).  The chunks that HOLD those curve neighbours
+  // -- kd cells of 128 points around them -- are therefore visited before the sweep, up to NSEED of them (the first
+  // unserved source's, then the next's ...): the bounds the sweep then starts from are those of a warm pass.  The sweep
+  // skips them (they are done: bounds only tighten).  Same result: every chunk that can hold a nearer-or-equal point is
+  // still visited, once, with bounds that are upper bounds.
+  constexpr int NSEED = 4;
+  uint32_t seed_c[NSEED];
+#pragma unroll
+  for (int k = 0; k < NSEED; ++k) seed_c[k] = 0xFFFFFFFFu;
+  if constexpr (!WARM) {
+    if (parts == 1 && ix.nchunks) {
+      bool pend[CS];
+      uint32_t sc[CS];
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        sc[s] = b0s[s] / (uint32_t)(CH / (SB / 4));  // the chunk of the source's bound (b0 = sorted position / (SB / 4))
+        pend[s] = valid[s] && best[s] < 3.0e38f;      // (a source without a bound has no seed)
+      }
+      for (int k = 0; k < NSEED; ++k) {
+        uint32_t c = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = CS - 1; s >= 0; --s) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(pend[s]);
+          if (m) c = (uint32_t)__builtin_amdgcn_readlane((int)sc[s], __ffsll((long long)m) - 1);
+        }
+        if (c == 0xFFFFFFFFu) break;
+        c = c < ix.nchunks ? c : ix.nchunks - 1;
+#pragma unroll
+        for (int j = 0; j < NSEED; ++j)
+          if (j == k) seed_c[j] = c;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) pend[s] = pend[s] && sc[s] != c;
+        if constexpr (TRACE) n_cand++;
+        visit(c, false, now());
+        if (gave_up) return;
+      }
+    }
+  }
+#if defined(GLOC_NN_RET) && GLOC_NN_RET == 6  // dev (timing only): no sweep at all -- prologue + epilogue
+  for (uint32_t s0 = 0; s0 < (wmax_s > -2.f ? 0u : ix.nsup); s0 += 64) {
+#else
+  for (uint32_t s0 = 0; s0 < ix.nsup; s0 += 64) {
+#endif
+    float lbs = __builtin_inff();  // (not FLT_MAX: a wave whose bound is still FLT_MAX -- a non-finite source point -- must not pass lanes past the end)
+    if (s0 + lane < ix.nsup) {
+      const f32x4 ulo = ix.sup_lo[s0 + lane], uhi = ix.sup_hi[s0 + lane];
+      lbs = box_box_lb(ulo, uhi);
+    }
+    unsigned long long smask = __builtin_amdgcn_ballot_w64(lbs <= wmax_s);
+    // the chunk boxes of the NEXT surviving batch are in flight while the current one is worked on
+    f32x4 nlo = {0.f, 0.f, 0.f, 0.f}, nhi = {0.f, 0.f, 0.f, 0.f};
+    int cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cl = (s0 + cur) * 64 + lane;
+      if (cl < ix.nchunks) { nlo = ix.box_lo[cl]; nhi = ix.box_hi[cl]; }
+    }
+    while (cur >= 0) {
+    const unsigned long long t_b0 = now();
+    const uint32_t c0 = (s0 + cur) * 64;
+    const bool live = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbs), cur)) <= wmax_s;
+    const uint32_t cl = c0 + lane;
+    const f32x4 blo = nlo, bhi = nhi;
+    cur = -1;
+    if (smask) {
+      cur = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      const uint32_t cn = (s0 + cur) * 64 + lane;
+      if (cn < ix.nchunks) { nlo = ix.box_lo[cn]; nhi = ix.box_hi[cn]; }
+    }
+    if (!live) continue;  // the wave's bound tightened since the super-chunk ballot
+    float lbw = __builtin_inff();
+    if (cl < ix.nchunks) lbw = chunk_box_lb(blo, bhi);
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbw <= wmax_s);
+    if constexpr (SPLIT) {
+      mask &= pmask;
+      w_cand += (uint32_t)__popcll(mask);
+    }
+    if constexpr (TRACE) a_batch += now() - t_b0;
+  NN_MARK("batch_tested");
+    // A wave over a sparse stretch of the curve (the far field: 128 points in a box of 60 m x 130 m, each 0.2 m from
+    // its neighbour) lists hundreds of candidates here and fails nearly all of them at the lane level: it is the wave
+    // a launch of few jobs waits for, and a scalar load per candidate (a miss in the scalar cache: ~400 cycles, nothing
+    // to overlap it with) is most of its time.  A batch with many survivors is therefore thinned first, with each box
+    // taken from the lane that holds it (v_readlane: no memory): what remains goes through the loop below.
+    if (__popcll(mask) > GLOC_NN_THIN_MIN) {
+      const unsigned long long t_t0 = now();
+      unsigned long long keep = 0ull;
+      while (mask) {
+        const int b = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); };
+        const f32x4 lo = {rl(blo.x), rl(blo.y), rl(blo.z), 0.f}, hi = {rl(bhi.x), rl(bhi.y), rl(bhi.z), 0.f};
+        bool need[CS];
+        unsigned long long nm[CS];
+        if constexpr (TRACE) n_cand++;
+        if (lane_test(lo, hi, need, nm) != 0ull) keep |= 1ull << b;
+      }
+      mask = keep;
+      if constexpr (TRACE) a_thin += now() - t_t0;
+    }
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const unsigned long long t_k0 = now();
+      if (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbw), b)) > wmax_s) continue;
+      const uint32_t c = __builtin_amdgcn_readfirstlane(c0 + b);
+      if constexpr (!WARM) {  // (a seed chunk: visited before the sweep)
+        bool seeded = false;
+#pragma unroll
+        for (int k = 0; k < NSEED; ++k) seeded |= c == seed_c[k];
+        if (seeded) continue;
+      }
+      if constexpr (TRACE) n_cand++;
+      visit(c, mask == 0ull && cur < 0 && s0 + 64 >= ix.nsup, t_k0);
+      if constexpr (!WARM && !HEAVY) {
+        if (gave_up) return;
+      }
     }
     }  // batches of this super-chunk group
   }
@@ -871,7 +1005,7 @@ __device__ __forceinline__ void nn_compact_body(
   // (one counter for the whole grid serialised the launch: 483 k atomics on one address took 12.6 ns
   // each, which WAS the launch time of the profiled runs of rounds 1 and 2 until this was found)
   if (stat_pairs && lane == 0) atomicAdd(stat_pairs + (lin_block % NN_STAT_SLOTS), n_items * (unsigned long long)SB);
-  if (SPLIT && lane == 0) {
+  if (SPLIT && lane == 0 && (!HEAVY || sp.work != nullptr)) {
     const uint32_t wk = (part == 0 ? NN_W_FIXED : 0u) + NN_W_CAND * w_cand + NN_W_CHUNK * n_processed + NN_W_ITEM * (uint32_t)n_items;
     uint32_t* wp = sp.work + (size_t)job * n_part + gi;
     if (parts == 1) *wp = wk; else atomicAdd(wp, wk);  // (the planner left a zero)
@@ -993,7 +1127,8 @@ __device__ __forceinline__ void nn_compact_body(
 
   // ---- a group searched by several waves: fold the parts, the last one to arrive goes on ---------------------
   if (SPLIT && parts > 1) {
-    unsigned long long* sk = sp.skey + ((size_t)job * sp.hx + hid) * S;
+    unsigned long long* sk = HEAVY ? hv.skey + (size_t)hid * S : sp.skey + ((size_t)job * sp.hx + hid) * S;
+    uint32_t* tick = HEAVY ? hv.ticket + hid : sp.ticket + (size_t)job * sp.hx + hid;
 #pragma unroll
     for (int s = 0; s < CS; ++s) {
       if (bpos[s] == 0xFFFFFFFFu) continue;
@@ -1008,7 +1143,7 @@ __device__ __forceinline__ void nn_compact_body(
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt = expcnt = lgkmcnt = 0
     asm volatile("" ::: "memory");
     uint32_t arrived = 0;
-    if (lane == 0) arrived = __hip_atomic_fetch_add(sp.ticket + (size_t)job * sp.hx + hid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) arrived = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived != parts - 1) return;  // (all lanes: no barrier below)
 #pragma unroll
@@ -1020,7 +1155,7 @@ __device__ __forceinline__ void nn_compact_body(
         bpos[s] = ix.inv[(uint32_t)k];
       }
     }
-    if (lane == 0) sp.ticket[(size_t)job * sp.hx + hid] = 0u;
+    if (lane == 0) *tick = 0u;
   }
   const unsigned long long t_tie = now();
   NN_MARK("outputs");
@@ -1156,12 +1291,18 @@ __device__ __forceinline__ void nn_compact_body(
   const Job *__restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg, uint32_t subs,                     \
       const CandState *__restrict__ states, const uint32_t *prev_corr, uint32_t *corr, float *__restrict__ d2out,      \
       f32x4 *__restrict__ pairs, double *__restrict__ partials, uint32_t n_part, size_t ld, float gate2, NnSplit sp,   \
-      unsigned long long *__restrict__ stat_pairs, uint32_t *__restrict__ trace
-#define NN_COMPACT_ARGS jobs, n_jobs, job_group, n_wg, subs, states, prev_corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, stat_pairs, trace
+      NnHeavy hv, unsigned long long *__restrict__ stat_pairs, uint32_t *__restrict__ trace
+#define NN_COMPACT_ARGS jobs, n_jobs, job_group, n_wg, subs, states, prev_corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, hv, stat_pairs, trace
 
 template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false, bool WARM = false>
 __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(NN_COMPACT_PARAMS) {
   nn_compact_body<CS, PAIRS, TRACE, SPLIT, WARM>(NN_COMPACT_ARGS);
+}
+
+// The second launch of a cold pass: the groups its waves gave up, NN_HEAVY_PARTS waves each (NnHeavy).
+template <int CS, bool PAIRS>
+__global__ __launch_bounds__(64) void nn_compact_heavy_kernel(NN_COMPACT_PARAMS) {
+  nn_compact_body<CS, PAIRS, false, true, false, true>(NN_COMPACT_ARGS);
 }
 
 // The warm moments pass with the split plan in it -- what one query alone runs 20 times -- held to the register budget

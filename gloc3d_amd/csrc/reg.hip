@@ -63,6 +63,11 @@ struct gloc_reg {
   uint32_t nn_split_thresh = 60000;
   DevBuf split_zero, split_ff;     // [work | plan | ticket] and [skey | helper] of the batch
   NnSplit split{};                 // views into them for the batch being enqueued (hx = 0: off)
+  // the groups a cold pass's waves give up and a second launch searches with NN_HEAVY_PARTS waves each (NnHeavy)
+  int nn_heavy_thresh = 32;        // processed chunks at which a cold wave gives up (0: off)
+  DevBuf heavy_buf;                // [count | list | ticket | skey]
+  size_t heavy_cap = 0;            // entries the buffer holds (its ticket / skey parts are self-resetting)
+  NnHeavy heavy{};                 // the view for the batch being enqueued (cap = 0: off)
   uint64_t nn_launches = 0;
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
@@ -129,6 +134,33 @@ int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
   return GLOC_OK;
 }
 
+// The list of a cold pass's heavy groups (NnHeavy): 16 entries per job, at most 16 384; only at two sources per lane.
+int setup_heavy(gloc_reg* h, const BatchDims& bd, int cs) {
+  h->heavy = NnHeavy{};
+  static const bool off = getenv("GLOC3D_NN_NO_HEAVY") != nullptr;  // developer switch
+  if (h->nn_mode == 1 || cs != 2 || h->nn_heavy_thresh <= 0 || off || h->trace_on) return GLOC_OK;
+  const size_t cap = std::min<size_t>((size_t)bd.n_jobs * 16, 16384), S = 64 * (size_t)cs;
+  hipStream_t s = h->stream;
+  if (cap > h->heavy_cap) {
+    const size_t cap2 = std::min<size_t>(std::max<size_t>(cap, 2 * h->heavy_cap), 16384);
+    const size_t head = 256 + cap2 * 8, keys_at = (head + cap2 * 4 + 255) & ~(size_t)255, bytes = keys_at + 2 * cap2 * S * 8;
+    GLOC_TRY(h->heavy_buf.ensure(bytes + 256, s));
+    GLOC_HIP(hipMemsetAsync(h->heavy_buf.p, 0, head + cap2 * 4, s));                                // count, list, tickets
+    GLOC_HIP(hipMemsetAsync(h->heavy_buf.as<char>() + keys_at, 0xFF, cap2 * S * 8, s));            // fold keys (hkey behind them: written before read)
+    h->heavy_cap = cap2;
+  }
+  char* b = h->heavy_buf.as<char>();
+  const size_t head = 256 + h->heavy_cap * 8, keys_at = (head + h->heavy_cap * 4 + 255) & ~(size_t)255;
+  h->heavy.count = reinterpret_cast<uint32_t*>(b);
+  h->heavy.list = reinterpret_cast<uint32_t*>(b + 256);
+  h->heavy.ticket = reinterpret_cast<uint32_t*>(b + head);
+  h->heavy.skey = reinterpret_cast<unsigned long long*>(b + keys_at);
+  h->heavy.hkey = h->heavy.skey + h->heavy_cap * S;
+  h->heavy.cap = (uint32_t)cap;
+  h->heavy.thresh = (uint32_t)h->nn_heavy_thresh;
+  return GLOC_OK;
+}
+
 // S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: write the (moved
 // source, matched target) pairs INSTEAD of the moments (the RANSAC stage refits from the pairs: accum_kernel<1>).  The culled search leaves the wave partials of the
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
@@ -149,6 +181,9 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
                          h->pairs.as<f32x4>());
   } else {
     const int cs = h->nn_src_per_lane;
+    const bool cold = want_pairs || !warm;
+    const NnHeavy hv = cold ? h->heavy : NnHeavy{};
+    if (hv.cap) GLOC_HIP(hipMemsetAsync(hv.count, 0, 4, h->stream));
     const uint32_t n_wg_job = (bd.max_groups + h->split.hx + NN_WPB - 1) / NN_WPB;  // helper waves first, then one per group
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
@@ -189,7 +224,7 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
                      bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
                      warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
                      h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
-                     gate2, h->split,                                                                    \
+                     gate2, h->split, hv,                                                                \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
 #define LAUNCH_COMPACT_CS(P_, W_)                                                                        \
@@ -202,6 +237,17 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       if (want_pairs) LAUNCH_COMPACT_CS(true, false);  // (the pass that writes the pairs is a batch's first)
       else if (warm) LAUNCH_COMPACT_CS(false, true);
       else LAUNCH_COMPACT_CS(false, false);
+      if (hv.cap) {  // the groups the cold pass's waves gave up: NN_HEAVY_PARTS waves each (the list's length stays on the device)
+#define LAUNCH_HEAVY(P_)                                                                                              \
+  hipLaunchKernelGGL((nn_compact_heavy_kernel<2, P_>), dim3(hv.cap * NN_HEAVY_PARTS), dim3(64), 0, h->stream, h->jobs.as<Job>(), \
+                     bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(), (const uint32_t*)nullptr, h->corr.as<uint32_t>(),       \
+                     h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
+                     gate2, h->split, hv,                                                                               \
+                     h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, (uint32_t*)nullptr)
+        if (want_pairs) LAUNCH_HEAVY(true);
+        else LAUNCH_HEAVY(false);
+#undef LAUNCH_HEAVY
+      }
     }
 #undef LAUNCH_COMPACT_CS
 #undef LAUNCH_COMPACT
@@ -268,6 +314,7 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
   GLOC_HIP(hipMemcpyAsync(h->jobs.p, jd, sizeof(Job) * n_jobs, hipMemcpyHostToDevice, s));
   GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states, sizeof(CandState) * n_jobs, hipMemcpyHostToDevice, s));
   GLOC_TRY(setup_split(h, bd, cs));
+  GLOC_TRY(setup_heavy(h, bd, cs));
   const bool culled = h->nn_mode != 1;
   const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
   bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
@@ -382,6 +429,12 @@ int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max
   h->last_final_step.assign(n_jobs, 0.f);
   if (n_jobs == 0) return GLOC_OK;
   GLOC_HIP(hipEventSynchronize(h->done_ev));
+  static const bool heavy_dbg = getenv("GLOC3D_NN_HEAVY_DEBUG") != nullptr;  // developer switch: the length of the last cold pass's list
+  if (heavy_dbg && h->heavy.cap) {
+    uint32_t cnt = 0;
+    (void)hipMemcpy(&cnt, h->heavy.count, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[gloc3d] cold pass of %u jobs: %u groups given up (list of %u)\n", n_jobs, cnt, h->heavy.cap);
+  }
   for (uint32_t c = 0; c < n_jobs; ++c) {
     const CandState& st = h->h_states[c];
     const size_t n_src = n_src_of[c];
@@ -547,7 +600,7 @@ int gloc_reg_destroy(gloc_reg* h) {
   if (h->own_store) (void)gloc_scan_store_destroy(h->own_store);
   h->prof.destroy();
   for (DevBuf* b : {&h->jobs, &h->states, &h->corr, &h->d2, &h->pairs, &h->Rt, &h->valid, &h->inliers,
-                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff, &h->alive})
+                    &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff, &h->alive, &h->heavy_buf})
     b->release();
   if (h->done_ev) (void)hipEventDestroy(h->done_ev);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -600,6 +653,11 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_SPLIT_HELPERS) {
     GLOC_REQUIRE(value >= -1 && value <= 4096, GLOC_ERR_INVALID, "must be in [-1, 4096]");
     h->nn_split_helpers = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_HEAVY_THRESH) {
+    GLOC_REQUIRE(value >= 0 && value <= 65535, GLOC_ERR_INVALID, "must be in [0, 65535]");
+    h->nn_heavy_thresh = (int)value;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_SPLIT_THRESH) {
@@ -922,6 +980,7 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
       hipMemcpyAsync(h->states.p, &st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess)
     return done(GLOC_ERR_HIP);
   h->split = NnSplit{};  // (one cold pass: there is no estimate to plan from)
+  if (int rc_h = setup_heavy(h, bd, cs)) return done(rc_h);
   int rc = launch_nn(h, bd, false, false, 0.f);
   if (rc != GLOC_OK) return done(rc);
   hipLaunchKernelGGL(export_corr_kernel, dim3((unsigned)((n_src + 255) / 256), 1), dim3(256), 0, s,

@@ -63,6 +63,28 @@ struct NnSplit {
   uint32_t hx;                // helper slots per job (0: no plan, the pointers are null)
   uint32_t thresh;            // estimate above which a group is split (cycles)
 };
+// Round 6 -- a COLD pass has no earlier pass to plan from, and some of its waves are heavy by the geometry, not by a loose
+// bound: a source on an object next to the sensor whose nearest target is 1.5 m off has 3 000 ground points inside that
+// ball, and 128 such sources made waves of 3 M cycles (1.4 ms -- the launch of 500 jobs waited 2.5 ms for the last of
+// them; one query alone waits for its slowest).  A cold wave that has processed `thresh` chunks therefore GIVES UP:
+// it appends (job, group) to a list and leaves without output; a second launch behind the pass (nn_compact_heavy_kernel)
+// searches every listed group again with NN_HEAVY_PARTS waves, candidate chunks dealt c mod parts, folded through
+// device-scope atomics as the planned split does (skey / ticket, self-resetting).  Same bits as the single wave.
+// The wave hands its bounds over (hkey): a part sees an eighth of the chunks, and left to its own finds would search with
+// the nearest point of ITS eighth as the bound -- on dense ground a ball as full as the whole wave's (measured: the second
+// launch took as long as the waves it replaced); with the bounds of the wave that gave up the parts only add what is
+// nearer, and skip the cold start's key search.
+struct NnHeavy {
+  uint32_t* count;            // entries appended (may exceed cap: the surplus went on by itself)
+  uint32_t* list;             // [cap][2]: job, group rank
+  unsigned long long* skey;   // [cap][64 * CS]; ~0 between passes
+  unsigned long long* hkey;   // [cap][64 * CS]: the search state of the wave that gave up -- per source (bits(best d2) << 32) |
+                              // tie flag << 31 | (sub-block << 2 | quarter) holding it: the parts START from these bounds
+  uint32_t* ticket;           // [cap]; 0 between passes
+  uint32_t cap;               // 0: off
+  uint32_t thresh;            // processed chunks at which a wave gives up
+};
+constexpr uint32_t NN_HEAVY_PARTS = 8;
 constexpr uint32_t NN_NO_HELPER = 0xFFFFFFFFu;
 constexpr uint32_t NN_MAX_PARTS = 8;
 // the estimate, from the trace's regression of wave cycles on its counts (tools/dev_nn_trace3.py)

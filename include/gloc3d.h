@@ -245,9 +245,12 @@ enum {
                                        64 jobs, 64 up to 256, else off); 0: off */
   GLOC_REG_OPT_NN_SPLIT_THRESH = 7,  /* the estimate (cycles of one wave) above which a group is split; default
                                        60000; 0: off */
-  GLOC_REG_OPT_NN_SUB_JOBS = 8       /* culled search tuning: interleaved shares of a job's work-groups that take a
+  GLOC_REG_OPT_NN_SUB_JOBS = 8,      /* culled search tuning: interleaved shares of a job's work-groups that take a
                                        slot of the launch order each (a slot stays on one XCD); 0 (default): 8 for
                                        batches under 48 jobs, which 8 XCDs cannot balance job by job, else 1 */
+  GLOC_REG_OPT_NN_HEAVY_THRESH = 9   /* culled search, first (cold) pass of a batch: a wave that has processed this many
+                                       target chunks hands its source group to a second launch, which searches it with
+                                       8 waves (identical results); default 32; 0: off */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

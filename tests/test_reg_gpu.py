@@ -595,6 +595,53 @@ def test_split_groups_change_no_bit_of_any_result(capi, scans):
     store.close()
 
 
+def test_cold_waves_that_give_up_change_no_bit(capi, scans):
+    """Round 6 (NnHeavy): a wave of a batch's first (cold) pass that has processed GLOC_REG_OPT_NN_HEAVY_THRESH target chunks
+    appends its source group to a list and leaves; a second launch searches every listed group with 8 waves (candidate
+    chunks dealt c mod 8, keys folded through device-scope atomics, the last part writes the outputs).  Whatever the
+    threshold -- off, the default, 1 (every wave that processes anything gives up: the list overflows its 16 entries per job
+    and the surplus goes on alone), 3 -- the pairs pass (RANSAC) and the moments pass (ICP only) and everything behind them
+    keep their bits; gloc_reg_nn (one cold pass) equals the brute-force kernel.  Full-size scans, both target orders."""
+    store = capi.ScanStore()
+    qid = store.add(scans["B"])
+    cids = [store.add(scans["A"]), store.add(scans["C"]), store.add(np.ascontiguousarray(scans["A"][::3]))]
+    store.build_target_index_batch(cids[:1])                    # one kd-ordered target, two in curve order
+
+    def run(thresh, ransac, icp, helpers=-1):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_HEAVY_THRESH, thresh)
+        r.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, helpers)
+        out = r.batch_ids(qid, cids, params=capi.default_reg_params(ransac_iters=ransac, icp_iters=icp))
+        corr = [r.debug_corr(j, len(scans["B"])) for j in range(3)]
+        r.close()
+        return out, corr
+
+    for ransac, icp in ((300, 0), (300, 3), (0, 1), (0, 4)):
+        ref, ref_corr = run(0, ransac, icp)
+        for thresh, helpers in ((32, -1), (1, -1), (3, -1), (1, 0), (5, 0)):
+            out, corr = run(thresh, ransac, icp, helpers)
+            what = (ransac, icp, thresh, helpers)
+            assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all(), what
+            assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all(), what
+            for j in range(3):
+                assert (corr[j][0] == ref_corr[j][0]).all() and (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), what
+    # one cold pass through the C ABI's 1-NN entry point: culled (giving up at once) == brute force, both target orders
+    sub = np.ascontiguousarray(scans["B"][::2])
+    ex = capi.Registrar()
+    ex.set_option(capi.REG_OPT_NN_MODE, capi.REG_NN_EXHAUSTIVE)
+    want = ex.nn(sub, scans["A"])
+    ex.close()
+    for kd in (0, 1):
+        for thresh in (1, 2, 32):
+            r = capi.Registrar()
+            r.set_option(capi.REG_OPT_TEMP_TARGET_INDEX, kd)
+            r.set_option(capi.REG_OPT_NN_HEAVY_THRESH, thresh)
+            idx, d2 = r.nn(sub, scans["A"])
+            assert (idx == want[0]).all() and (bits(d2) == bits(want[1])).all(), (kd, thresh)
+            r.close()
+    store.close()
+
+
 def test_split_groups_decide_ties_by_the_original_index(capi, oracle_mod):
     """Equidistant targets in DIFFERENT parts of a split group: the parts' keys are (distance, original index), so the
     smallest original index wins as in the single wave.  Lattice targets in shuffled order, sources on cell centres /

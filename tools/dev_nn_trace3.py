@@ -8,27 +8,30 @@ from gloc3d_amd import capi, synth
 W = 32  # NN_TRACE_WORDS
 icp = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-wa, wb = synth.make_world(1001), synth.make_world(2002)
+# round 6: the headline's data -- distinct device ray-casts along the loop (bench.headline_world); query q revisits place
+# 300 + 500 q, its 20 candidates are the places around it in index order (what the descriptor retrieval returns)
+traj, world_a, world_b = bench.headline_world(bench.N_PLACES_1GPU)
 store = capi.ScanStore()
-base_a = [store.add(np.ascontiguousarray(synth.lidar_scan(wa, bench.pool_pose(s), seed=3000 + s)[:, :3])) for s in range(0, 20)]
-base_b = [store.add(np.ascontiguousarray(synth.lidar_scan(wb, synth.se3(7.0 * s, (1.5 * s, -0.7 * s, 0.0)), seed=5000 + s)[:, :3])) for s in range(2)]
-qvs, qids = [], []
-for q in range(nq):
-    qv = np.ascontiguousarray(synth.lidar_scan(wa, bench.pool_pose(10) @ synth.se3(1.5 + 0.4 * q, (0.3 - 0.1 * q, -0.2 + 0.05 * q, 0.02)), seed=9000 + q)[:, :3])
-    qvs.append(qv)
-    qids.append(store.add(qv))
-qv, qid = qvs[0], qids[0]
-cands = []
-for c in range(20):
-    g = c
-    cands.append(store.add_variant(base_b[(g // 4) % 2] if g % 4 == 1 else base_a[g], bench.place_perturbation(g), 0.01, 7000 + g))
-store.build_target_index_batch(cands)
+g0 = [300 + 500 * q for q in range(nq)]
+qids = store.add_raycast(world_a, [traj[g] @ bench.query_offset(q) for q, g in enumerate(g0)], np.array([bench.QUERY_SEED + q for q in range(nq)], np.uint64))
+cands_all, cand_dist = [], []
+for q, g in enumerate(g0):
+    places = [g + d for d in (0, 1, -1, 2, -2, 3, -3, 4, -4, 5, -5, 6, -6, 7, -7, 8, -8, 9, -9, 10)]
+    row = []
+    for pl in places:
+        neg = pl % bench.NEG_EVERY == 1
+        row.append(store.add_raycast(world_b if neg else world_a, [traj[pl]], np.array([bench.PLACE_SEED + pl], np.uint64))[0])
+        cand_dist.append(-1.0 if neg else float(np.linalg.norm(traj[pl][:2, 3] - traj[g][:2, 3])))
+    cands_all.append(row)
+    store.build_target_index_batch(row)
+cands = cands_all[0]
+cand_dist = np.array(cand_dist)
 reg = capi.Registrar(store=store)
 L = capi.lib(); f = L.gloc_reg_debug_trace; f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 f(reg._h, 1, None, 0, None)
 prm = capi.default_reg_params(ransac_iters=3000, icp_iters=icp, max_rmse=1.0)
-r = reg.batch_multi(qids, [cands] * nq, params=prm)
+r = reg.batch_multi(qids, cands_all, params=prm)
 n = C.c_size_t(); f(reg._h, 1, None, 0, C.byref(n))
 tr = np.zeros((n.value, W), np.uint32); f(reg._h, 1, tr.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
 job = tr[:, 6]
@@ -44,7 +47,9 @@ cand_of = job % 20
 names = ["load+xform+box", "upper bounds", "chunk-box batches", "thinning", "candidate lane tests", "staging+listing",
          "sub-block tests", "evaluation rounds", "bound refresh", "(whole sweep)", "index recovery", "contested minima",
          "outputs+moments", "moment reduction"]
-for name, sel in (("all", np.ones_like(ok)), ("positives", cand_of % 4 != 1), ("negatives", cand_of % 4 == 1)):
+dist_of_job = cand_dist[np.minimum(job, len(cand_dist) - 1)]
+for name, sel in (("all", np.ones_like(ok)), ("same world <= 2.5 m", (dist_of_job >= 0) & (dist_of_job <= 2.5)),
+                  ("same world > 2.5 m", dist_of_job > 2.5), ("other world", dist_of_job < 0)):
     t = tr[ok & sel].astype(np.float64)
     tot = t[:, 0]
     w7 = tr[ok & sel][:, 7]
@@ -96,4 +101,4 @@ for x in range(8):
     m = xcc == x
     if m.any():
         jj = job[ok][m]
-        print(f"  XCD {x}: waves {m.sum():6d}  last start {st[m].max():7.1f}  last end {en[m].max():7.1f}  wave-time {(en[m] - st[m]).sum() / 1e3:7.1f} ms  jobs {len(set(jj.tolist()))}  negatives among them {len(set(j for j in jj.tolist() if (j % 20) % 4 == 1))}")
+        print(f"  XCD {x}: waves {m.sum():6d}  last start {st[m].max():7.1f}  last end {en[m].max():7.1f}  wave-time {(en[m] - st[m]).sum() / 1e3:7.1f} ms  jobs {len(set(jj.tolist()))}  other-world among them {len(set(j for j in jj.tolist() if cand_dist[j] < 0))}")

@@ -6,8 +6,7 @@ tag=$1; shift
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-python3 -c "import sys; sys.path.insert(0, '$R'); import bench; bench.build_views('/tmp/views.npz')"
-B="python3 $R/bench.py --no-cpu-baseline --no-legs --views-cache /tmp/views.npz $*"
+B="python3 $R/bench.py --no-cpu-baseline --no-legs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats -o bench -- $B > $O/${tag}_under_rocprof.json 2> $O/${tag}_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_fetch -o p -- $B > /dev/null 2> $O/${tag}_pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_write -o p -- $B > /dev/null 2> $O/${tag}_pmc_write.err

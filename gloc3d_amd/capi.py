@@ -98,6 +98,7 @@ _PROTOS = [
     ("gloc_abi_version", _i, []),
     ("gloc_device_count", _i, []),
     ("gloc_knn_create", _i, [_i, _sz, C.POINTER(_vp)]),
+    ("gloc_knn_create_view", _i, [_vp, C.POINTER(_vp)]),
     ("gloc_knn_destroy", _i, [_vp]),
     ("gloc_knn_set_stream", _i, [_vp, _vp]),
     ("gloc_knn_synchronize", _i, [_vp]),
@@ -281,8 +282,19 @@ class KnnIndex:
 
     def close(self):
         if self._h:
-            lib().gloc_knn_destroy(self._h)
+            check(lib().gloc_knn_destroy(self._h))
             self._h = C.c_void_p()
+            self._parent = None
+
+    def view(self):
+        """A second search handle over this index's rows (gloc_knn_create_view): own stream and workspace, so that a search
+        on it runs beside a search on this handle.  Close it before its parent."""
+        v = KnnIndex.__new__(KnnIndex)
+        v._h = C.c_void_p()
+        v.dim, v.device = self.dim, self.device
+        check(lib().gloc_knn_create_view(self._h, C.byref(v._h)))
+        v._parent = self          # (keeps the parent alive as long as the view)
+        return v
 
     def __del__(self):
         try:

@@ -24,6 +24,8 @@ struct gloc_knn {
   hipStream_t stream = nullptr;
   DevBuf rows;      // n x dim fp32, row-major, dense
   DevBuf norms;     // n fp32 (coarse form only)
+  DevBuf mirror;    // the rows again, split into two bf16 values and tiled by 64 rows (knn_kernels.hpp: mirror_rows_kernel) --
+                    // what the split-bf16 coarse pass streams; dim % 8 == 0 only; kept current by every add
   DevBuf dn_max;    // 1 x uint32 (bits of the largest row norm)
   DevBuf dist;      // exact: [nq][ld]; mfma: [splits][Qpad][ld]
   DevBuf keys;      // select output [nq][K]
@@ -55,14 +57,41 @@ struct gloc_knn {
   int candidates = 32;
   Profiler prof;
   gloc_knn_stats stats{};
+  // gloc_knn_create_view: a view searches its parent's rows / norms with its own stream and workspace (rows, norms, dn_max
+  // below are then ALIASES of the parent's buffers, refreshed at every search and never grown or freed through the view)
+  gloc_knn* parent = nullptr;
+  int views = 0;  // live views of this handle
 };
 
 namespace {
 
+#define GLOC_NOT_VIEW(h) \
+  GLOC_REQUIRE(!(h)->parent, GLOC_ERR_STATE, "a view (gloc_knn_create_view) searches its parent's rows: add / reserve / clear / load on the parent")
+
+// A view's rows are its parent's as of now (the parent may have grown since the view's last search).
+void view_sync(gloc_knn* h) {
+  if (!h->parent) return;
+  h->rows.p = h->parent->rows.p;
+  h->rows.cap = h->parent->rows.cap;
+  h->norms.p = h->parent->norms.p;
+  h->norms.cap = h->parent->norms.cap;
+  h->mirror.p = h->parent->mirror.p;
+  h->mirror.cap = h->parent->mirror.cap;
+  h->dn_max.p = h->parent->dn_max.p;
+  h->dn_max.cap = h->parent->dn_max.cap;
+  h->n = h->parent->n;
+}
+
 int ensure_rows(gloc_knn* h, size_t n_rows) {
+  GLOC_NOT_VIEW(h);
   GLOC_TRY(h->rows.ensure(n_rows * h->dim * sizeof(float), h->stream, true,
                           h->n * h->dim * sizeof(float)));
   GLOC_TRY(h->norms.ensure(n_rows * sizeof(float), h->stream, true, h->n * sizeof(float)));
+  if (h->dim % 8 == 0) {  // (whole tiles, and two more: the coarse kernel's last work-group may own a tile past the end)
+    const size_t tile_bytes = mirror_tile_u32x4((int)h->dim) * 16;
+    GLOC_TRY(h->mirror.ensure(((n_rows + MIR_ROWS - 1) / MIR_ROWS + 2) * tile_bytes, h->stream, true,
+                              (h->n + MIR_ROWS - 1) / MIR_ROWS * tile_bytes));
+  }
   if (!h->dn_max.p) {
     GLOC_TRY(h->dn_max.ensure(sizeof(uint32_t), h->stream));
     GLOC_HIP(hipMemsetAsync(h->dn_max.p, 0, sizeof(uint32_t), h->stream));
@@ -78,6 +107,12 @@ int update_norms(gloc_knn* h, size_t first, size_t count) {
                      h->rows.as<float>() + first * h->dim, count, (int)h->dim,
                      h->norms.as<float>() + first, h->dn_max.as<uint32_t>());
   GLOC_HIP(hipGetLastError());
+  if (h->dim % 8 == 0) {  // the coarse pass's mirror of the same rows
+    ProfScope pm(h->prof, "mirror", h->stream);
+    hipLaunchKernelGGL(mirror_rows_kernel, dim3((unsigned)((count + 63) / 64), (unsigned)((h->dim / 8 + 3) / 4)), dim3(256), 0, h->stream,
+                       h->rows.as<float>(), first, count, (int)h->dim, h->mirror.as<u32x4>());
+    GLOC_HIP(hipGetLastError());
+  }
   return GLOC_OK;
 }
 
@@ -374,6 +409,29 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     }
     ProfScope ps(h->prof, "dist_mfma", h->stream);
     const int kps3 = (((int)h->dim + p.KS - 1) / p.KS + 63) & ~63;
+    static const bool no_mirror = getenv("GLOC3D_KNN_NO_MIRROR") != nullptr;  // developer switch: the row-major kernel
+    if (!no_mirror && h->mirror.p) {
+      // the rows from their tiled, pre-split mirror: contiguous 8-KB runs per tile and step (round 6)
+      const dim3 tgrid((unsigned)((first % MIR_ROWS + (size_t)n_range + p.BN - 1) / p.BN), grid.y, grid.z);
+#define B3T(NT_, QR_)                                                                                                  \
+  do {                                                                                                                \
+    constexpr int lds_bytes = b3_lds_bytes<NT_, 4>();                                                                 \
+    static std::atomic<uint64_t> attr_set{0};                                                                         \
+    const uint64_t dev_bit = 1ull << (h->device & 63);                                                                \
+    if (lds_bytes > 48 * 1024 && !(attr_set.load(std::memory_order_relaxed) & dev_bit)) {                            \
+      GLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_bf16x3_tiled_kernel<NT_, QR_>),                \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                          \
+      attr_set.fetch_or(dev_bit, std::memory_order_relaxed);                                                          \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((dist_bf16x3_tiled_kernel<NT_, QR_>), tgrid, dim3(256), lds_bytes, h->stream,                  \
+                       h->mirror.as<u32x4>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld,   \
+                       strideP);                                                                                      \
+  } while (0)
+      if (p.NT == 1) { if (qraw) B3T(1, true); else B3T(1, false); }
+      else { if (qraw) B3T(2, true); else B3T(2, false); }
+#undef B3T
+      GLOC_HIP(hipGetLastError());
+    } else {
     static const int phase = getenv("GLOC3D_KNN_B3_PHASE") ? atoi(getenv("GLOC3D_KNN_B3_PHASE")) : 5;  // developer switch
 #define B3(NT_, QR_, KO_)                                                                                             \
   do {                                                                                                                \
@@ -403,6 +461,7 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
 #undef B3Q
 #undef B3
     GLOC_HIP(hipGetLastError());
+    }
   } else if (p.t32) {
     ProfScope ps(h->prof, "dist_mfma", h->stream);
     dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
@@ -546,6 +605,7 @@ int search_device_impl(gloc_knn* h, const float* d_q, size_t nq, size_t k, size_
   GLOC_REQUIRE(k >= 1 && k <= 256, GLOC_ERR_INVALID, "k = %zu outside [1,256]", k);
   GLOC_REQUIRE(nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "nq = %zu outside [1,2^20]", nq);
   GLOC_HIP(hipSetDevice(h->device));
+  view_sync(h);
   if (last_row > h->n) last_row = h->n;
   if (first_row > last_row) first_row = last_row;
   const size_t range = last_row - first_row;
@@ -646,13 +706,37 @@ int gloc_knn_create(int device, size_t dim, gloc_knn** out) {
   return GLOC_OK;
 }
 
+int gloc_knn_create_view(gloc_knn* parent, gloc_knn** out) {
+  GLOC_REQUIRE(parent && out, GLOC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  GLOC_REQUIRE(!parent->parent, GLOC_ERR_INVALID, "a view of a view: take it of the owning handle");
+  gloc_knn* v = nullptr;
+  GLOC_TRY(gloc_knn_create(parent->device, parent->dim, &v));
+  v->parent = parent;
+  v->algo = parent->algo;
+  v->candidates = parent->candidates;
+  parent->views++;
+  view_sync(v);
+  *out = v;
+  return GLOC_OK;
+}
+
 int gloc_knn_destroy(gloc_knn* h) {
   if (!h) return GLOC_OK;
+  GLOC_REQUIRE(h->views == 0, GLOC_ERR_STATE, "%d view(s) of this handle are still alive (gloc_knn_create_view): destroy them first", h->views);
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->prof.destroy();
+  if (h->parent) {  // the rows are the parent's
+    h->rows = DevBuf{};
+    h->norms = DevBuf{};
+    h->mirror = DevBuf{};
+    h->dn_max = DevBuf{};
+    h->parent->views--;
+  }
   h->rows.release();
   h->norms.release();
+  h->mirror.release();
   h->dn_max.release();
   h->dist.release();
   h->keys.release();
@@ -794,6 +878,7 @@ int gloc_synth_fill_device(int device, void* hip_stream, int kind, uint64_t seed
 
 int gloc_knn_clear(gloc_knn* h) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_NOT_VIEW(h);
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_HIP(hipStreamSynchronize(h->stream));
   h->n = 0;
@@ -803,7 +888,7 @@ int gloc_knn_clear(gloc_knn* h) {
 
 int gloc_knn_size(const gloc_knn* h, size_t* n_rows) {
   GLOC_REQUIRE(h && n_rows, GLOC_ERR_INVALID, "null argument");
-  *n_rows = h->n;
+  *n_rows = h->parent ? h->parent->n : h->n;
   return GLOC_OK;
 }
 
@@ -948,6 +1033,7 @@ int gloc_knn_search_sharded_host(gloc_knn* h, gloc_comm* comm, const float* quer
                                  uint64_t index_stride, uint64_t index_offset, uint64_t* out_idx, float* out_d2) {
   GLOC_REQUIRE(h && queries && out_idx && out_d2, GLOC_ERR_INVALID, "null argument");
   GLOC_REQUIRE(k >= 1 && k <= 256 && nq >= 1 && nq <= (1u << 20), GLOC_ERR_INVALID, "bad nq / k");
+  GLOC_NOT_VIEW(h);
   GLOC_HIP(hipSetDevice(h->device));
   GLOC_TRY(h->stage_q.ensure(nq * h->dim * sizeof(float), h->stream));
   GLOC_TRY(h->stage_idx.ensure(nq * k * sizeof(uint64_t), h->stream));

@@ -815,6 +815,189 @@ __global__ __launch_bounds__(256) void dist_bf16x3_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6 -- the coarse pass reads a MIRROR of the database: the rows already split into their two bf16 values and laid
+// out by TILES of 64 rows,  [tile][k / 8][h | m][row in tile][16 B = 8 bf16],  so that what a work-group needs for a step
+// of 32 k -- four planes of its tile -- is ONE contiguous run of 8 KB instead of 64 pieces of 128 B from rows 16 KB apart.
+// Why: the row-major kernel streams 5.0 - 5.3 TB/s however it walks (tools/dev_stream_pattern.hip, round 4: 128 rows per
+// work-group 5.1 - 5.6 TB/s whatever the piece per row, 8 rows per work-group 6.4 - 6.5): 768 resident work-groups x 128
+// row streams are ~100 000 open rows against the stacks' ~10 000 banks, 768 contiguous streams are not.  The mirror
+// costs the database's size again in HBM (16 GB at a million rows of 288 GB) and is kept current by every add
+// (mirror_rows_kernel); the fp32 rows stay what the exact kernels and the re-rank read.  The split (3 VALU per element per
+// SEARCH in the row-major kernel) moves to the add as well.
+constexpr int MIR_ROWS = 64;  // rows per tile
+__host__ __device__ __forceinline__ size_t mirror_tile_u32x4(int dim) { return (size_t)(dim / 8) * 2 * MIR_ROWS; }  // 16-B slots per tile
+
+// rows [first, first + count) of the fp32 database -> their places in the mirror.  One thread per (row, 8 k): rows fastest
+// (a wave writes 64 x 16 B = 1 KB contiguous of h and of m; its reads are 32-B pieces of 64 rows, once per row ever).
+__global__ __launch_bounds__(256) void mirror_rows_kernel(const float* __restrict__ db, size_t first, size_t count, int dim,
+                                                          u32x4* __restrict__ mirror) {
+  const size_t r_in = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int p = blockIdx.y * 4 + (threadIdx.x >> 6);  // plane: k / 8
+  if (r_in >= count || p >= dim / 8) return;
+  const size_t row = first + r_in;
+  const float* src = db + row * (size_t)dim + (size_t)p * 8;
+  const f4u a = *reinterpret_cast<const f4u*>(src), b = *reinterpret_cast<const f4u*>(src + 4);
+  u32x4 h, m;
+  bf16_split8(f32x4{a.x, a.y, a.z, a.w}, f32x4{b.x, b.y, b.z, b.w}, h, m);
+  u32x4* t = mirror + (row / MIR_ROWS) * mirror_tile_u32x4(dim) + (size_t)p * 2 * MIR_ROWS + (row % MIR_ROWS);
+  t[0] = h;
+  t[MIR_ROWS] = m;
+}
+
+// The coarse pass over the mirror: the arithmetic, the LDS image and the MFMA sequence of dist_bf16x3_kernel; only where
+// the rows come from differs.  Tiles are aligned to ABSOLUTE row numbers: a window that starts inside a tile computes the
+// tile's leading rows too and stores nothing for them (row - first_row < 0).
+template <int NT, bool QRAW>
+__global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __restrict__ mirror,
+                                                                const float* __restrict__ qsplit /* split_queries_kernel, or raw */,
+                                                                float* __restrict__ P, int dim, size_t first_row, int n_range,
+                                                                int nq, int k_per_split, size_t ldP, size_t strideP) {
+  constexpr int KO = 4;
+  constexpr int BQ = 64;
+  constexpr int BN = 64 * NT;
+  constexpr int ROWS = BQ + BN;
+  constexpr int PLANE = ROWS + 2;
+  constexpr int BK = 8 * KO;
+  constexpr int NQ = BQ * KO / 256;       // 8-float chunks of the queries per thread and step
+  constexpr int ND = NT * 2;              // 16-B slots of the rows per thread and step: NT tiles x 8 KB / (256 x 16 B)
+  extern __shared__ u32x4 lds[];          // [buffer][h | m][plane][row]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wq = w & 1, wn = w >> 1;
+  const size_t tile0 = first_row / MIR_ROWS + (size_t)blockIdx.x * NT;          // the work-group's first tile
+  const long long j0 = (long long)(tile0 * MIR_ROWS) - (long long)first_row;    // its first row, relative to the window (may be < 0)
+  const int q0 = blockIdx.y * BQ;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
+  const size_t tile_slots = mirror_tile_u32x4(dim);
+
+  const int ko8 = (tid % KO) * 8;
+  const float* qsrc[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int qq = q0 + (tid + 256 * i) / KO;
+    qsrc[i] = qsplit + (size_t)(qq < nq ? qq : 0) * dim;
+  }
+  // slot i of the thread: tile i / 2, then 16-B slot (i % 2) * 256 + tid of the step's 8-KB run = [plane][h | m][row]
+  struct Pre {
+    f32x4 q[NQ][2];
+    u32x4 d[ND];
+  };
+  auto gload = [&](Pre& pre, int k) {
+    const int kk = k + ko8;
+    const int kc = kk < dim - 8 ? kk : dim - 8;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const f4u a = *reinterpret_cast<const f4u*>(qsrc[i] + kc), b = *reinterpret_cast<const f4u*>(qsrc[i] + kc + 4);
+      pre.q[i][0] = f32x4{a.x, a.y, a.z, a.w};
+      pre.q[i][1] = f32x4{b.x, b.y, b.z, b.w};
+    }
+    const int kp = (k < dim ? k : dim - BK) / 8;  // (a prefetch past the end reads the last step again: never stored)
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      pre.d[i] = mirror[(tile0 + i / 2) * tile_slots + (size_t)kp * 2 * MIR_ROWS + (i % 2) * 256 + tid];
+  };
+  auto lstore = [&](const Pre& pre, int buf, int k) {
+    u32x4* Lh = lds + buf * 2 * KO * PLANE;
+    u32x4* Lm = Lh + KO * PLANE;
+    const int pl = (tid % KO) * PLANE;
+    const bool tail = k + BK > kend;
+    const bool out = tail && k + ko8 >= kend;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int row = (tid + 256 * i) / KO;
+      if constexpr (QRAW) {
+        u32x4 h, m;
+        bf16_split8(pre.q[i][0], pre.q[i][1], h, m);
+        Lh[pl + row] = out ? z : h;
+        Lm[pl + row] = out ? z : m;
+      } else {
+        Lh[pl + row] = out ? z : __builtin_bit_cast(u32x4, pre.q[i][0]);
+        Lm[pl + row] = out ? z : __builtin_bit_cast(u32x4, pre.q[i][1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int s = (i % 2) * 256 + tid;           // slot in the run: [plane 0..3][h | m][row 0..63]
+      const int p = s >> 7, hm = (s >> 6) & 1, r = s & 63;
+      const bool pout = tail && k + p * 8 >= kend;  // (the split's length is a multiple of 8: a plane is in or out whole)
+      (hm ? Lm : Lh)[p * PLANE + BQ + (i / 2) * MIR_ROWS + r] = pout ? z : pre.d[i];
+    }
+  };
+
+  f32x16 acc[NT], tot[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[t][r] = 0.f;
+  const int a_row = wq * 32 + (lane & 31);
+  const int b_row0 = BQ + wn * NT * 32 + (lane & 31);
+  auto compute = [&](int buf, auto opens) {
+    const u32x4* Lh = lds + buf * 2 * KO * PLANE;
+    const u32x4* Lm = Lh + KO * PLANE;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int pl = (ks * 2 + (lane >> 5)) * PLANE;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, Lh[pl + a_row]), am = __builtin_bit_cast(bf16x8, Lm[pl + a_row]);
+      bf16x8 bh[NT], bm[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bh[t] = __builtin_bit_cast(bf16x8, Lh[pl + b_row0 + t * 32]);
+        bm[t] = __builtin_bit_cast(bf16x8, Lm[pl + b_row0 + t * 32]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[t], (decltype(opens)::value && ks == 0) ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+    }
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tot[t] += acc[t];
+  };
+
+  Pre preA, preB;
+  gload(preA, kbeg);
+  lstore(preA, 0, kbeg);
+  gload(preA, kbeg + BK);
+  gload(preB, kbeg + 2 * BK);
+  __syncthreads();
+  for (int k = kbeg; k < kend; k += 2 * BK) {
+    compute(0, std::true_type{});
+    if (k + BK < kend) {
+      lstore(preA, 1, k + BK);
+      gload(preA, k + 3 * BK);
+      __syncthreads();
+      compute(1, std::false_type{});
+      if (k + 2 * BK < kend) {
+        lstore(preB, 0, k + 2 * BK);
+        gload(preB, k + 4 * BK);
+        __syncthreads();
+      }
+    }
+    flush();  // the group's 64 k (fewer at the end of the split)
+  }
+  // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* Pz = P + (size_t)blockIdx.z * strideP;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const long long j = j0 + (wn * NT + t) * 32 + (lane & 31);
+    if (j >= 0 && j < (long long)n_range) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Pz[(size_t)qq * ldP + (size_t)j] = tot[t][r];  // rows q >= nq land in the padded part of P
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1 (top-k part): per-query top-K of a distance row, LDS-staged, in two kernels.
 //
 // select_chunk_kernel: grid (chunks, nq), 256 threads, E elements per thread (chunk = 256 E).

@@ -71,6 +71,14 @@ enum {
 
 /* device: HIP ordinal.  dim: descriptor length (reference: k_dim_ = 512, loop_detector.h:97). */
 int gloc_knn_create(int device, size_t dim, gloc_knn** out);
+/* A second SEARCH handle over the same resident database (round 6): its own HIP stream and workspace, the parent's rows
+ * (no copy; rows the parent has added -- and finished adding: synchronize it -- are seen by the view's next search).
+ * Searches on the parent and on a view run side by side on the device: one's selection + re-rank (a work-group per query:
+ * 64 of 256 CUs at 64 queries) under the other's distance kernel -- back-to-back searches of DIFFERENT query batches then
+ * cost max(stage) instead of the sum (bench.py: knn_cfgB_pipelined_us).  nanoflann's query is const for the same reason
+ * (KDTreeVectorOfVectorsAdaptor.h:95-102).  A view cannot add / reserve / clear / load (GLOC_ERR_STATE); the parent cannot be
+ * destroyed while views live. */
+int gloc_knn_create_view(gloc_knn* parent, gloc_knn** out);
 int gloc_knn_destroy(gloc_knn* h);
 
 /* Use `hip_stream` (a hipStream_t created by the caller on the same device) for all work of this

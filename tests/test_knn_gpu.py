@@ -430,3 +430,54 @@ def test_handle_leaves_the_split_form_when_its_proofs_keep_failing(capi, oracle_
     ix.search(q, 5)
     assert ix.stats()["queries_fallback"] == 0
     ix.close()
+
+
+def test_a_view_searches_its_parents_rows_beside_it(capi):
+    """gloc_knn_create_view (round 6): a second search handle over the same resident rows, own stream and workspace.  Its
+    results are the parent's bit for bit -- alone, interleaved with the parent's searches (the two run side by side on the
+    device), after the parent has grown, on a row window -- and it cannot change the database."""
+    import torch
+    from gloc3d_amd import synth
+    dim, n = 512, 6000
+    db = synth.descriptors_traj(77, 0, n, dim)
+    ix = capi.KnnIndex(dim)
+    ix.add(db[:4000])
+    v = ix.view()
+    assert len(v) == 4000
+    qa = synth.queries_near(77, (np.arange(64) * 53 + 3) % 4000, dim)
+    qb = synth.queries_near(77, (np.arange(48) * 31 + 11) % 4000, dim)
+    wa, wb = ix.search(qa, 20), ix.search(qb, 20)
+    ga, gb = v.search(qa, 20), v.search(qb, 20)
+    for (gi, gd), (wi, wd) in ((ga, wa), (gb, wb)):
+        assert (gi == wi).all() and (bits(gd) == bits(wd)).all()
+    # interleaved on the device: parent and view each on its own stream, 20 searches in flight
+    dqa, dqb = torch.from_numpy(qa).cuda(), torch.from_numpy(qb).cuda()
+    oa = [(torch.empty((64, 20), dtype=torch.int64, device="cuda"), torch.empty((64, 20), dtype=torch.float32, device="cuda")) for _ in range(10)]
+    ob = [(torch.empty((48, 20), dtype=torch.int64, device="cuda"), torch.empty((48, 20), dtype=torch.float32, device="cuda")) for _ in range(10)]
+    torch.cuda.synchronize()
+    for i in range(10):
+        ix.search_device(dqa.data_ptr(), 64, 20, oa[i][0].data_ptr(), oa[i][1].data_ptr())
+        v.search_device(dqb.data_ptr(), 48, 20, ob[i][0].data_ptr(), ob[i][1].data_ptr())
+    ix.synchronize()
+    v.synchronize()
+    for i in range(10):
+        assert (oa[i][0].cpu().numpy().astype(np.uint64) == wa[0]).all() and (bits(oa[i][1].cpu().numpy()) == bits(wa[1])).all()
+        assert (ob[i][0].cpu().numpy().astype(np.uint64) == wb[0]).all() and (bits(ob[i][1].cpu().numpy()) == bits(wb[1])).all()
+    # the parent grows (its buffers may move): the view's next search sees all rows
+    ix.add(db[4000:])
+    ix.synchronize()
+    qc = synth.queries_near(77, np.array([4100, 5999, 17, 5000]), dim)
+    wi, wd = ix.search(qc, 20)
+    gi, gd = v.search(qc, 20)
+    assert len(v) == n and (gi == wi).all() and (bits(gd) == bits(wd)).all() and gi[1, 0] == 5999
+    gi, gd = v.search(qc, 20, first_row=100, last_row=4500)            # the SLAM window through a view
+    wi, wd = ix.search(qc, 20, first_row=100, last_row=4500)
+    assert (gi == wi).all() and (bits(gd) == bits(wd)).all()
+    for call in (lambda: v.add(db[:10]), lambda: v.reserve(10000), lambda: v.clear()):
+        with pytest.raises(capi.GlocError) as ei:
+            call()
+        assert ei.value.code == 5                                     # GLOC_ERR_STATE: a view cannot change the database
+    with pytest.raises(capi.GlocError):
+        ix.close()                                                    # not while a view lives
+    v.close()
+    ix.close()

@@ -17,7 +17,7 @@ ERR_NAMES = {1: "GLOC_ERR_INVALID", 2: "GLOC_ERR_HIP", 3: "GLOC_ERR_NOMEM", 4: "
 ALGO_AUTO, ALGO_EXACT, ALGO_MFMA, ALGO_MFMA_FP32 = 0, 1, 2, 3   # include/gloc3d.h GLOC_KNN_ALGO_*
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
 REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_JOB_GROUP, REG_OPT_TEMP_TARGET_INDEX = 1, 2, 3, 4, 5
-REG_OPT_NN_SPLIT_HELPERS, REG_OPT_NN_SPLIT_THRESH, REG_OPT_NN_SUB_JOBS, REG_OPT_NN_HEAVY_THRESH = 6, 7, 8, 9
+REG_OPT_NN_SPLIT_HELPERS, REG_OPT_NN_SPLIT_THRESH, REG_OPT_NN_SUB_JOBS, REG_OPT_NN_HEAVY_THRESH, REG_OPT_SUB_BATCHES = 6, 7, 8, 9, 10
 REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
 NO_SCAN = 0xFFFFFFFF
 SIZE_MAX = C.c_size_t(-1).value

@@ -38,6 +38,7 @@ struct gloc_knn {
   DevBuf qsplit;    // [nq][dim / 8][8 bf16 h, 8 bf16 m]: the queries of the split-bf16 coarse pass
   DevBuf dev_trace; // developer aid: phase stamps of the fused select + re-rank kernel (null unless enabled)
   DevBuf flags;     // [nq] int
+  DevBuf redo_tickets;  // [nq] u32: flagged_redo_kernel's tickets (0 between searches)
   DevBuf stage_q;   // host-API staging: queries
   DevBuf stage_idx, stage_d2;
   int* h_flags = nullptr;  // pinned
@@ -565,6 +566,28 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     // behind a host synchronisation, ~35 us of a 460-us search over a 125 000-row shard).
     // (The coarse partial dots in h->dist are dead by now: the exact distances of the flagged queries
     // reuse the buffer, row q at q * ld.)
+    static const bool no_redo1 = getenv("GLOC3D_KNN_NO_REDO1") != nullptr;  // developer switch: the three launches
+    if (fused && large && k <= 64 && !no_redo1) {
+      // ONE launch (round 6): every work-group walks the flags and leaves when none is set; a flagged query's exact
+      // distances, slice selections and final selection happen inside it (flagged_redo_kernel)
+      int S = std::max(1, (n_range + 2047) / 2048);
+      while ((long long)S * k > SELQ_MAX_ROWS) S = (S + 1) / 2;
+      int L = (((n_range + S - 1) / S) + 63) & ~63;
+      S = (n_range + L - 1) / L;  // (no empty slice)
+      if (L <= SELQ_MAX_ROWS) {
+        const size_t before = h->redo_tickets.cap;
+        GLOC_TRY(h->redo_tickets.ensure((size_t)nq * sizeof(unsigned int), h->stream));
+        if (h->redo_tickets.cap != before) GLOC_HIP(hipMemsetAsync(h->redo_tickets.p, 0, h->redo_tickets.cap, h->stream));
+        GLOC_TRY(h->klists.ensure((size_t)nq * S * k * sizeof(uint64_t), h->stream));
+        ProfScope ps(h->prof, "dist_exact", h->stream);
+        hipLaunchKernelGGL(flagged_redo_kernel, dim3((unsigned)S), dim3(SELQ_THREADS), 0, h->stream, h->rows.as<float>(), d_q,
+                           (int)h->dim, first, n_range, L, k, h->dist.as<float>(), ld, h->klists.as<uint64_t>(),
+                           h->redo_tickets.as<unsigned int>(), h->flags.as<int>(), nq, d_keys_out, fo);
+        GLOC_HIP(hipGetLastError());
+        *finalized = fo.idx != nullptr;
+        return GLOC_OK;
+      }
+    }
     GLOC_TRY(launch_dist_exact(h, d_q, nq, first, n_range, ld, h->flags.as<int>()));
     if (fused && large) {  // the fused kernel has written the result through `fo`: the flagged queries' is replaced
       bool fin = false;
@@ -750,6 +773,7 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->qsplit.release();
   h->dev_trace.release();
   h->flags.release();
+  h->redo_tickets.release();
   h->stage_q.release();
   h->stage_idx.release();
   h->stage_d2.release();

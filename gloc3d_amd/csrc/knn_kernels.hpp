@@ -1366,6 +1366,78 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_slices_kernel(
   }
 }
 
+// Round 6 -- the exact redo of the queries a LARGE window's proof has flagged, in ONE launch (three before: exact distances,
+// slices, the lists' selection -- always launched, each leaving at once when no flag is set, 5.3 us apiece = 16 us of a
+// 440-us search over a 125 000-row shard).  Work-group s owns rows [s L, s L + L) of the window.  Every work-group walks
+// the flags (one round trip per 1 024 of them; none set: it leaves); for a flagged query it
+//   A  computes the reference-order distances of ITS rows (16 waves x RW rows at a time: exact_pairs_wave, as
+//      dist_exact_kernel) into the query's row of the workspace,
+//   B  selects their K smallest keys (selq_select<0>) into the query's list s,
+//   C  draws the query's ticket: the LAST of the S work-groups selects the K smallest of the S x K keys (the K smallest of
+//      the window are among the slices' K smallest; keys are distinct) and writes the result over the unproven one.
+// No work-group waits for another (the ticket decides who goes on), so nothing can hang; a flagged query costs ~0.5 ms
+// (62 work-groups stream 2 GB between them) instead of three full-width launches -- it is the rare path (no query of any
+// bench or golden configuration is flagged), as the one-work-group redo of a window below 16 384 rows has been.
+constexpr int REDO_RW = 8;  // rows per wave and step
+__global__ __launch_bounds__(SELQ_THREADS) void flagged_redo_kernel(
+    const float* __restrict__ db, const float* __restrict__ queries, int dim, size_t first_row, int n_range, int L, int K,
+    float* __restrict__ dist, size_t ld, uint64_t* __restrict__ lists /* [nq][S][K] */, unsigned int* __restrict__ tickets /* [nq]: 0 between searches */,
+    const int* __restrict__ flags, int nq, uint64_t* __restrict__ out_keys /* [nq][K] */, FinalOut fo) {
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  __shared__ unsigned int arrived;
+  __shared__ __attribute__((aligned(16))) float S_all[(SELQ_THREADS / 64) * REDO_RW * S_PITCH];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int sl = blockIdx.x, S = gridDim.x;
+  const int j0 = sl * L;
+  const int n = n_range - j0 < L ? n_range - j0 : L;  // >= 1: the host launches no empty slice
+  float* Sw = S_all + w * REDO_RW * S_PITCH;
+  auto one = [&](int q) {
+    // A: this work-group's rows, REDO_RW per wave and step (the loop is uniform: exact_pairs_wave holds barriers)
+    const float* qp = queries + (size_t)q * dim;
+    float* drow = dist + (size_t)q * ld;
+    for (int r0 = 0; r0 < n; r0 += (SELQ_THREADS / 64) * REDO_RW) {
+      const int row0 = j0 + r0 + w * REDO_RW;
+      auto row_of = [&](int r) -> long long {
+        const int rr = row0 + r;
+        return rr < j0 + n ? (long long)(first_row + (size_t)rr) : -1;
+      };
+      const float acc = exact_pairs_wave<1>(db, qp, dim, REDO_RW, row_of, 1, Sw);
+      if (lane < REDO_RW && row0 + lane < j0 + n) drow[row0 + lane] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // B: the slice's K smallest
+    selq_select<0>(drow + j0, 0, 1, qp, dim, nullptr, first_row + (size_t)j0, n, K, buf, qred, &tau_s, &cnt);
+    if (tid < K) lists[((size_t)q * S + sl) * K + tid] = buf[tid];
+    // C: the last work-group of the query ends it
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) arrived = atomicAdd(&tickets[q], 1u);
+    __syncthreads();
+    if (arrived != (unsigned)(S - 1)) return;  // uniform over the work-group
+    __threadfence();
+    selq_select<2>(reinterpret_cast<const float*>(lists + (size_t)q * S * K), 0, 1, nullptr, dim, nullptr, 0, S * K, K, buf, qred,
+                   &tau_s, &cnt);
+    if (tid < K) {
+      out_keys[(size_t)q * K + tid] = buf[tid];
+      final_store(fo, (size_t)q * K + tid, buf[tid]);
+    }
+    if (tid == 0) tickets[q] = 0u;
+  };
+  for (int base = 0; base < nq; base += SELQ_THREADS) {
+    const int f = (base + tid < nq) ? flags[base + tid] : 0;
+    if (!__syncthreads_or(f)) continue;
+    for (int q = base; q < nq && q < base + SELQ_THREADS; ++q) {
+      if (!flags[q]) continue;  // uniform over the work-group
+      one(q);
+      __syncthreads();  // buf is the next query's
+    }
+  }
+}
+
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
 __global__ __launch_bounds__(256) void select_merge_kernel(const uint64_t* __restrict__ in_keys,
                                                            int nlists, int per_group, int K,

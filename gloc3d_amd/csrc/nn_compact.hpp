@@ -80,13 +80,18 @@ __device__ __forceinline__ float dpp_f32(float x) {
 // processed chunks -- 255 of the wave's 2 208 (ISA count).  v_min/v_max_f32 return the other operand when one is a NaN,
 // as fminf / fmaxf do; the hazard (a VALU write of a register two or fewer slots before a DPP read of it) is covered
 // by the s_nop the compiler cannot place inside an asm.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "wave_minmax / wave_box: hand-placed DPP hazards (row_bcast:15 / :31, s_nop padding) are written for gfx942 / gfx950 only"
+#endif
+// (the leading s_nop 4: five wait states cover a VALU write of EXEC right before the first DPP as well as a VALU write of
+// the operand -- the compiler cannot see into the asm; the later steps read what the previous DPP wrote: two states)
 template <bool MAX>
 __device__ __forceinline__ float wave_minmax(float x) {
   // across the four rows: row_bcast:15 hands a row's value (all its lanes hold it) to the next row -- rows 1 and 3
   // take it -- then row_bcast:31 hands rows 0-1's to rows 2 and 3; lanes left out keep x.
   // Lane 63 ends with the wave's value: one v_readlane instead of four plus three combines.
   if constexpr (MAX)
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 4\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
@@ -94,7 +99,7 @@ __device__ __forceinline__ float wave_minmax(float x) {
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
         : "+v"(x));
   else
-    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 4\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
@@ -110,7 +115,7 @@ __device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
   "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t" \
   "v_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\t" \
   "v_min_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
-  asm("s_nop 1\n\t"
+  asm("s_nop 4\n\t"
       GLOC_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
       GLOC_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
       GLOC_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
@@ -865,7 +870,9 @@ __device__ __forceinline__ void nn_compact_body(
       // A warm pass starts from bounds that are nearly final (the previous pass's neighbour): the WAVE's bound hardly moves,
       // and re-reducing it after every chunk cost more than the candidates it spared (round 5, same box: 38.16 -> 37.87 ms of
       // 1-NN per step; dropping the lanes' refresh as well: 38.30).  The stale value is still an upper bound: same result.
-      if constexpr (!WARM) {
+      // (A warm wave with a source that STARTED without a bound -- its previous correspondence invalid, a NaN point -- has a
+      // wave bound near FLT_MAX x KS and would cull no chunk at the wave level for the whole sweep: it refreshes as a cold wave does.)
+      if (!WARM || wmax_s > 1.0e30f) {
         if (__builtin_amdgcn_ballot_w64(changed) != 0ull) wmax_s = wave_max_best();
       }
       if constexpr (TRACE) {
@@ -888,6 +895,7 @@ __device__ __forceinline__ void nn_compact_body(
   uint32_t seed_c[NSEED];
 #pragma unroll
   for (int k = 0; k < NSEED; ++k) seed_c[k] = 0xFFFFFFFFu;
+#ifndef GLOC_NN_R5_COLD  // (-DGLOC_NN_R5_COLD: round 5's cold pass -- no seeds, no second launch -- for same-box A/Bs: tools/dev_ab.sh)
   if constexpr (!WARM) {
     if (parts == 1 && ix.nchunks) {
       bool pend[CS];
@@ -917,6 +925,7 @@ __device__ __forceinline__ void nn_compact_body(
       }
     }
   }
+#endif
 #if defined(GLOC_NN_RET) && GLOC_NN_RET == 6  // dev (timing only): no sweep at all -- prologue + epilogue
   for (uint32_t s0 = 0; s0 < (wmax_s > -2.f ? 0u : ix.nsup); s0 += 64) {
 #else

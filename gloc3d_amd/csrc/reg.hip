@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "common.hpp"
+#include <future>
+
 #include "nn_compact.hpp"
 #include "reg_kernels.hpp"
 #include "scan_store.hpp"
@@ -65,10 +67,16 @@ struct gloc_reg {
   NnSplit split{};                 // views into them for the batch being enqueued (hx = 0: off)
   // the groups a cold pass's waves give up and a second launch searches with NN_HEAVY_PARTS waves each (NnHeavy)
   int nn_heavy_thresh = 32;        // processed chunks at which a cold wave gives up (0: off)
-  DevBuf heavy_buf;                // [count | list | ticket | skey]
-  size_t heavy_cap = 0;            // entries the buffer holds (its ticket / skey parts are self-resetting)
-  NnHeavy heavy{};                 // the view for the batch being enqueued (cap = 0: off)
-  uint64_t nn_launches = 0;
+  static constexpr uint32_t MAX_SUB = 8;
+  DevBuf heavy_buf;                // per sub-batch a region [count | list | ticket | skey | hkey]
+  size_t heavy_cap = 0;            // entries a region holds (its ticket / skey parts are self-resetting)
+  size_t heavy_regions = 0;        // regions the buffer holds
+  NnHeavy heavy_of[MAX_SUB]{};     // the views for the batch being enqueued, one per sub-batch (cap = 0: off)
+  // sub-batches of a small batch, each on its own stream (enqueue_jobs): -1 by batch size (4 for 8 .. 64 jobs), 0 / 1 off
+  int sub_batches = -1;
+  hipStream_t sub_stream[MAX_SUB - 1] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[MAX_SUB - 1] = {};
+  std::atomic<uint64_t> nn_launches{0};
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
   Profiler prof;
@@ -104,6 +112,25 @@ struct BatchDims {
   size_t ld;
 };
 
+// A batch -- or, round 6, one of the sub-batches a small batch is cut into, each on its own stream -- as the launches see
+// it: its jobs' slices of the handle's workspaces (every per-job array offset by the sub-batch's first job; strides --
+// bd.ld, bd.n_part, the hypothesis count -- are the whole batch's).
+struct WsView {
+  hipStream_t s;
+  uint32_t job0, n_jobs;
+  Job* jobs;
+  CandState* states;
+  uint32_t* corr;
+  float* d2;
+  f32x4* pairs;
+  float* Rt;
+  uint32_t *valid, *inliers;
+  double* partials;
+  uint32_t *a_idx, *a_cnt;  // (ransac_alive_kernel's lists; set when they are allocated)
+  NnSplit split;
+  NnHeavy heavy;
+};
+
 // The split plan's buffers for a batch (NnSplit): everything starts as "no group is split"; the first pass of a batch
 // therefore runs one wave per group and leaves the estimates the first plan is made from.
 int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
@@ -134,64 +161,87 @@ int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
   return GLOC_OK;
 }
 
-// The list of a cold pass's heavy groups (NnHeavy): 16 entries per job, at most 16 384; only at two sources per lane.
-int setup_heavy(gloc_reg* h, const BatchDims& bd, int cs) {
-  h->heavy = NnHeavy{};
+// The lists of a cold pass's heavy groups (NnHeavy), one per sub-batch: 16 entries per job, at most 16 384; only at two
+// sources per lane.
+int setup_heavy(gloc_reg* h, const BatchDims& bd, int cs, uint32_t G = 1) {
+  for (uint32_t g = 0; g < gloc_reg::MAX_SUB; ++g) h->heavy_of[g] = NnHeavy{};
+#ifdef GLOC_NN_R5_COLD
+  static const bool off = true;
+#else
   static const bool off = getenv("GLOC3D_NN_NO_HEAVY") != nullptr;  // developer switch
+#endif
   if (h->nn_mode == 1 || cs != 2 || h->nn_heavy_thresh <= 0 || off || h->trace_on) return GLOC_OK;
-  const size_t cap = std::min<size_t>((size_t)bd.n_jobs * 16, 16384), S = 64 * (size_t)cs;
+  const size_t per = ((size_t)bd.n_jobs + G - 1) / G;
+  const size_t cap = std::min<size_t>(per * 16, 16384), S = 64 * (size_t)cs;
   hipStream_t s = h->stream;
-  if (cap > h->heavy_cap) {
-    const size_t cap2 = std::min<size_t>(std::max<size_t>(cap, 2 * h->heavy_cap), 16384);
-    const size_t head = 256 + cap2 * 8, keys_at = (head + cap2 * 4 + 255) & ~(size_t)255, bytes = keys_at + 2 * cap2 * S * 8;
-    GLOC_TRY(h->heavy_buf.ensure(bytes + 256, s));
-    GLOC_HIP(hipMemsetAsync(h->heavy_buf.p, 0, head + cap2 * 4, s));                                // count, list, tickets
-    GLOC_HIP(hipMemsetAsync(h->heavy_buf.as<char>() + keys_at, 0xFF, cap2 * S * 8, s));            // fold keys (hkey behind them: written before read)
+  auto region_bytes = [&](size_t c) { return ((256 + c * 8 + c * 4 + 255) & ~(size_t)255) + 2 * c * S * 8; };
+  if (cap > h->heavy_cap || G > h->heavy_regions) {
+    const size_t cap2 = std::min<size_t>(std::max<size_t>(cap, h->heavy_cap), 16384), R = std::max<size_t>(G, h->heavy_regions);
+    GLOC_TRY(h->heavy_buf.ensure(R * region_bytes(cap2) + 256, s));
+    for (size_t g = 0; g < R; ++g) {
+      char* b = h->heavy_buf.as<char>() + g * region_bytes(cap2);
+      const size_t keys_at = (256 + cap2 * 8 + cap2 * 4 + 255) & ~(size_t)255;
+      GLOC_HIP(hipMemsetAsync(b, 0, keys_at, s));                      // count, list, tickets
+      GLOC_HIP(hipMemsetAsync(b + keys_at, 0xFF, cap2 * S * 8, s));     // fold keys (hkey behind them: written before read)
+    }
     h->heavy_cap = cap2;
+    h->heavy_regions = R;
   }
-  char* b = h->heavy_buf.as<char>();
-  const size_t head = 256 + h->heavy_cap * 8, keys_at = (head + h->heavy_cap * 4 + 255) & ~(size_t)255;
-  h->heavy.count = reinterpret_cast<uint32_t*>(b);
-  h->heavy.list = reinterpret_cast<uint32_t*>(b + 256);
-  h->heavy.ticket = reinterpret_cast<uint32_t*>(b + head);
-  h->heavy.skey = reinterpret_cast<unsigned long long*>(b + keys_at);
-  h->heavy.hkey = h->heavy.skey + h->heavy_cap * S;
-  h->heavy.cap = (uint32_t)cap;
-  h->heavy.thresh = (uint32_t)h->nn_heavy_thresh;
+  for (uint32_t g = 0; g < G; ++g) {
+    char* b = h->heavy_buf.as<char>() + g * region_bytes(h->heavy_cap);
+    const size_t head = 256 + h->heavy_cap * 8, keys_at = (head + h->heavy_cap * 4 + 255) & ~(size_t)255;
+    NnHeavy& hv = h->heavy_of[g];
+    hv.count = reinterpret_cast<uint32_t*>(b);
+    hv.list = reinterpret_cast<uint32_t*>(b + 256);
+    hv.ticket = reinterpret_cast<uint32_t*>(b + head);
+    hv.skey = reinterpret_cast<unsigned long long*>(b + keys_at);
+    hv.hkey = hv.skey + h->heavy_cap * S;
+    hv.cap = (uint32_t)cap;
+    hv.thresh = (uint32_t)h->nn_heavy_thresh;
+  }
+  return GLOC_OK;
+}
+
+int ensure_sub_streams(gloc_reg* h, uint32_t G) {
+  if (!h->fork_ev) GLOC_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  for (uint32_t g = 1; g < G; ++g) {
+    if (!h->sub_stream[g - 1]) GLOC_HIP(hipStreamCreateWithFlags(&h->sub_stream[g - 1], hipStreamNonBlocking));
+    if (!h->join_ev[g - 1]) GLOC_HIP(hipEventCreateWithFlags(&h->join_ev[g - 1], hipEventDisableTiming));
+  }
   return GLOC_OK;
 }
 
 // S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: write the (moved
 // source, matched target) pairs INSTEAD of the moments (the RANSAC stage refits from the pairs: accum_kernel<1>).  The culled search leaves the wave partials of the
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
-int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, float gate2) {
-  ProfScope ps(h->prof, "nn", h->stream);
+int launch_nn(gloc_reg* h, const BatchDims& bd, const WsView& v, bool warm, bool want_pairs, float gate2) {
+  ProfScope ps(h->prof, "nn", v.s);
   // (the first pass of a batch -- no previous correspondence, or the pass that writes the pairs -- is another
   // instantiation and ~1.6 x a warm pass: also counted in its own family, so that "nn" - "nn_cold" is the warm passes alone)
   Profiler no_prof;
-  ProfScope ps_cold((want_pairs || !warm) ? h->prof : no_prof, "nn_cold", h->stream);
+  ProfScope ps_cold((want_pairs || !warm) ? h->prof : no_prof, "nn_cold", v.s);
   h->nn_launches++;
   if (h->nn_mode == 1) {
-    dim3 grid((bd.max_src + 256 * NN_S - 1) / (256 * NN_S), bd.n_jobs);
-    hipLaunchKernelGGL(nn_kernel, grid, dim3(256), 0, h->stream, h->jobs.as<Job>(), h->states.as<CandState>(),
-                       h->corr.as<uint32_t>(), h->d2.as<float>(), bd.ld);
+    dim3 grid((bd.max_src + 256 * NN_S - 1) / (256 * NN_S), v.n_jobs);
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(256), 0, v.s, v.jobs, v.states,
+                       v.corr, v.d2, bd.ld);
     if (want_pairs)
-      hipLaunchKernelGGL(gather_pairs_kernel, dim3((bd.max_src + 255) / 256, bd.n_jobs), dim3(256), 0, h->stream,
-                         h->jobs.as<Job>(), h->states.as<CandState>(), h->corr.as<uint32_t>(), bd.ld,
-                         h->pairs.as<f32x4>());
+      hipLaunchKernelGGL(gather_pairs_kernel, dim3((bd.max_src + 255) / 256, v.n_jobs), dim3(256), 0, v.s,
+                         v.jobs, v.states, v.corr, bd.ld,
+                         v.pairs);
   } else {
     const int cs = h->nn_src_per_lane;
     const bool cold = want_pairs || !warm;
-    const NnHeavy hv = cold ? h->heavy : NnHeavy{};
-    if (hv.cap) GLOC_HIP(hipMemsetAsync(hv.count, 0, 4, h->stream));
-    const uint32_t n_wg_job = (bd.max_groups + h->split.hx + NN_WPB - 1) / NN_WPB;  // helper waves first, then one per group
+    const NnHeavy hv = cold ? v.heavy : NnHeavy{};
+    if (hv.cap) GLOC_HIP(hipMemsetAsync(hv.count, 0, 4, v.s));
+    const uint32_t n_wg_job = (bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB;  // helper waves first, then one per group
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
     // (8 shares -- one per XCD -- since round 5: one query alone 105.4 -> 104.1 / 104.4 us per pass against 4)
-    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (bd.n_jobs < 48 ? 8u : 1u);
+    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
     // (one group of all the slots of a small batch, so that every job's helpers start at the head of the launch, was
     // tried: one query alone 0.115 ms per pass against 0.108 with groups of 24)
-    const uint32_t n_slots = bd.n_jobs * subs;
+    const uint32_t n_slots = v.n_jobs * subs;
     const uint32_t jg = (uint32_t)h->nn_job_group;
     const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
     const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
@@ -201,17 +251,17 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
                  (n_slots + jg - 1) / jg);
     if (h->trace_on) {
       h->trace_waves = (size_t)grid * NN_WPB;
-      if (h->trace.ensure(h->trace_waves * 4 * NN_TRACE_WORDS, h->stream)) return GLOC_ERR_NOMEM;
-      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 4 * NN_TRACE_WORDS, h->stream));
+      if (h->trace.ensure(h->trace_waves * 4 * NN_TRACE_WORDS, v.s)) return GLOC_ERR_NOMEM;
+      GLOC_HIP(hipMemsetAsync(h->trace.p, 0, h->trace_waves * 4 * NN_TRACE_WORDS, v.s));
     }
 // instantiations: sources per lane x (pairs | moments) x (first pass: cold start | later: warm) x (with the split plan);
 // the per-wave trace only at two sources per lane
 #define LAUNCH_COMPACT(CS_, P_, W_)                                                                      \
   do {                                                                                                  \
     if (h->trace_on && (CS_) == 2) {                                                                    \
-      if (h->split.hx) LAUNCH_COMPACT_T(2, P_, true, true, W_);                                         \
+      if (v.split.hx) LAUNCH_COMPACT_T(2, P_, true, true, W_);                                         \
       else LAUNCH_COMPACT_T(2, P_, true, false, W_);                                                    \
-    } else if (h->split.hx) {                                                                           \
+    } else if (v.split.hx) {                                                                           \
       if (!(P_) && (W_) && (CS_) == 2) LAUNCH_COMPACT_K((nn_compact_split_warm_kernel<2>), P_);         \
       else LAUNCH_COMPACT_T(CS_, P_, false, true, W_);                                                  \
     } else {                                                                                            \
@@ -220,11 +270,11 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
   } while (0)
 #define LAUNCH_COMPACT_T(CS_, P_, T_, S_, W_) LAUNCH_COMPACT_K((nn_compact_kernel<CS_, P_, T_, S_, W_>), P_)
 #define LAUNCH_COMPACT_K(K_, P_)                                                                         \
-  hipLaunchKernelGGL(K_, dim3(jg, n_wg, (n_slots + jg - 1) / jg), dim3(64 * NN_WPB), 0, h->stream, h->jobs.as<Job>(), \
-                     bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(),                               \
-                     warm ? h->corr.as<uint32_t>() : (const uint32_t*)nullptr, h->corr.as<uint32_t>(),   \
-                     h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
-                     gate2, h->split, hv,                                                                \
+  hipLaunchKernelGGL(K_, dim3(jg, n_wg, (n_slots + jg - 1) / jg), dim3(64 * NN_WPB), 0, v.s, v.jobs, \
+                     v.n_jobs, jg, n_wg, subs, v.states,                               \
+                     warm ? v.corr : (const uint32_t*)nullptr, v.corr,   \
+                     v.d2, v.pairs, (P_) ? (double*)nullptr : v.partials, bd.n_part, bd.ld, \
+                     gate2, v.split, hv,                                                                \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, \
                      h->trace_on ? h->trace.as<uint32_t>() : (uint32_t*)nullptr)
 #define LAUNCH_COMPACT_CS(P_, W_)                                                                        \
@@ -239,10 +289,10 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, bool warm, bool want_pairs, floa
       else LAUNCH_COMPACT_CS(false, false);
       if (hv.cap) {  // the groups the cold pass's waves gave up: NN_HEAVY_PARTS waves each (the list's length stays on the device)
 #define LAUNCH_HEAVY(P_)                                                                                              \
-  hipLaunchKernelGGL((nn_compact_heavy_kernel<2, P_>), dim3(hv.cap * NN_HEAVY_PARTS), dim3(64), 0, h->stream, h->jobs.as<Job>(), \
-                     bd.n_jobs, jg, n_wg, subs, h->states.as<CandState>(), (const uint32_t*)nullptr, h->corr.as<uint32_t>(),       \
-                     h->d2.as<float>(), h->pairs.as<f32x4>(), (P_) ? (double*)nullptr : h->partials.as<double>(), bd.n_part, bd.ld, \
-                     gate2, h->split, hv,                                                                               \
+  hipLaunchKernelGGL((nn_compact_heavy_kernel<2, P_>), dim3(hv.cap * NN_HEAVY_PARTS), dim3(64), 0, v.s, v.jobs, \
+                     v.n_jobs, jg, n_wg, subs, v.states, (const uint32_t*)nullptr, v.corr,       \
+                     v.d2, v.pairs, (P_) ? (double*)nullptr : v.partials, bd.n_part, bd.ld, \
+                     gate2, v.split, hv,                                                                               \
                      h->prof.enabled ? h->counters.as<unsigned long long>() : (unsigned long long*)nullptr, (uint32_t*)nullptr)
         if (want_pairs) LAUNCH_HEAVY(true);
         else LAUNCH_HEAVY(false);
@@ -270,6 +320,111 @@ int ensure_pinned(gloc_reg* h, uint32_t n_jobs) {
   }
   h->h_states = reinterpret_cast<CandState*>(h->pin);
   h->h_jobs = reinterpret_cast<Job*>(h->h_states + n_jobs);
+  return GLOC_OK;
+}
+
+// The launches of a batch -- or of one sub-batch on its own stream: S1 -> S2 (RANSAC + refit) -> S3 (ICP) over the view's jobs.
+int enqueue_pipeline(gloc_reg* h, const BatchDims& bd, const gloc_reg_params* prm, const WsView& v, bool can, bool any_tgt,
+                     uint32_t nblocks) {
+  const uint32_t n_jobs = v.n_jobs;
+  hipStream_t s = v.s;
+  const bool culled = h->nn_mode != 1;
+  const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
+  bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
+
+  if (can && any_tgt && prm->ransac_iters > 0) {
+    const uint32_t H = prm->ransac_iters;
+    GLOC_TRY(launch_nn(h, bd, v, false, true, 0.f));
+    have_corr = true;
+    // Phases of hypotheses, each generated, scored and scanned before the next: with the adaptive stop (the
+    // reference's call: confidence 0.99) and ~85 % inliers the iteration count drops to 5 - 8 at the first good
+    // hypothesis, so [0, 16) settles nearly every job, [16, 64) most of the rest; a job that is done is skipped by the
+    // later phases (its blocks exit at once).  The rule is sequential in h (ransac_scan_kernel), so the split does not
+    // change the result.  (Round 2 scored 64 first: 2.1 ms per step of 500 jobs, 0.6 with 16.)
+    const bool adaptive = prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f;
+    uint32_t bounds[4] = {0u, 0u, 0u, 0u};
+    int n_ph = 0;
+    for (uint32_t b : {adaptive ? 16u : 256u, adaptive ? 64u : H, H})
+      if (b <= H && b > bounds[n_ph]) bounds[++n_ph] = b;
+    if (bounds[n_ph] < H) bounds[++n_ph] = H;
+    GLOC_HIP(hipMemsetAsync(v.valid, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));  // never-generated = invalid
+    GLOC_HIP(hipMemsetAsync(v.inliers, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));
+    const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
+    const unsigned cchunks = (bd.max_src + SC_CHUNK - 1) / SC_CHUNK;
+    for (int ph = 0; ph < n_ph; ++ph) {
+      const uint32_t h0 = bounds[ph], h1 = bounds[ph + 1], len = h1 - h0;
+      const CandState* st = ph ? v.states : (const CandState*)nullptr;
+      {
+        ProfScope ps(h->prof, "ransac_hyp", s);
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((len + 127) / 128, n_jobs), dim3(128), 0, s, v.pairs, bd.ld,
+                           v.jobs, prm->seed, H, h0, h1, st, v.Rt, v.valid);
+        GLOC_HIP(hipGetLastError());
+      }
+      ProfScope ps(h->prof, "ransac_score", s);
+      // hypotheses per work-group: 16 / 64 (its four waves share them and split every staged tile) or thread <-> hypothesis
+      const uint32_t hpb = len <= 16 ? 16u : (len <= 64 ? 64u : 256u);
+      static const unsigned parts_env = getenv("GLOC3D_RANSAC_PARTS") ? (unsigned)atoi(getenv("GLOC3D_RANSAC_PARTS")) : 0u;  // developer override
+      const unsigned NP = parts_env ? parts_env : 8u;
+      if (!adaptive && ph > 0 && len >= 512 && cchunks >= NP) {
+        // every hypothesis scored, not every pair of every hypothesis: an eighth of the pairs at a time, the hypotheses
+        // that can no longer beat the first phase's winner dropped in between (ransac_alive_kernel)
+        uint32_t* a_idx = v.a_idx;
+        uint32_t* a_cnt = v.a_cnt;
+        for (unsigned q = 0; q < NP; ++q) {
+          const unsigned c0 = q * cchunks / NP, c1 = (q + 1) * cchunks / NP;
+          hipLaunchKernelGGL(ransac_alive_kernel, dim3(n_jobs), dim3(1024), 0, s, v.inliers, v.valid,
+                             H, h0, h1, v.jobs, v.states, (uint32_t)(c0 * SC_CHUNK), a_idx, a_cnt);
+          hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, c1 - c0, n_jobs), dim3(256), 0, s,
+                             v.pairs, bd.ld, v.jobs, H, h0, 256u, v.Rt,
+                             v.valid, thr2, st, v.inliers, a_idx, a_cnt, (uint32_t)c0);
+        }
+      } else {
+        hipLaunchKernelGGL(ransac_score_kernel, dim3((len + hpb - 1) / hpb, cchunks, n_jobs), dim3(256), 0, s,
+                           v.pairs, bd.ld, v.jobs, H, h0, hpb, v.Rt,
+                           v.valid, thr2, st, v.inliers, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, 0u);
+      }
+      if (ph + 1 < n_ph)
+        hipLaunchKernelGGL(ransac_scan_kernel<false>, dim3(n_jobs), dim3(64), 0, s, v.inliers,
+                           v.valid, v.Rt, H, h0, h1, v.jobs, prm->ransac_confidence,
+                           prm->min_inlier_ratio, v.states);
+      else
+        hipLaunchKernelGGL(ransac_scan_kernel<true>, dim3(n_jobs), dim3(64), 0, s, v.inliers,
+                           v.valid, v.Rt, H, h0, h1, v.jobs, prm->ransac_confidence,
+                           prm->min_inlier_ratio, v.states);
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "accum", s);  // refit on the best hypothesis' inliers
+      hipLaunchKernelGGL(accum_kernel<1>, dim3(nblocks, n_jobs), dim3(ACC_THREADS), 0, s, v.jobs,
+                         v.states, v.corr, v.d2,
+                         v.pairs, bd.ld, thr2, v.partials, bd.n_part);
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "solve", s);
+      hipLaunchKernelGGL(solve_kernel<1>, dim3(v.split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, v.partials,
+                         bd.n_part, false, v.jobs, v.states, v.split, n_jobs);
+      GLOC_HIP(hipGetLastError());
+    }
+  }
+  for (uint32_t it = 0; it < prm->icp_iters && can && any_tgt; ++it) {
+    GLOC_TRY(launch_nn(h, bd, v, have_corr, false, gate2));
+    have_corr = true;
+    if (!culled) {
+      ProfScope ps(h->prof, "accum", s);
+      hipLaunchKernelGGL(accum_kernel<0>, dim3(nblocks, n_jobs), dim3(ACC_THREADS), 0, s, v.jobs,
+                         v.states, v.corr, v.d2,
+                         (const f32x4*)nullptr, bd.ld, gate2, v.partials, bd.n_part);
+      GLOC_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(h->prof, "solve", s);
+      hipLaunchKernelGGL(solve_kernel<0>, dim3(v.split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, v.partials,
+                         bd.n_part, culled, v.jobs, v.states, v.split, n_jobs);
+      GLOC_HIP(hipGetLastError());
+    }
+  }
   return GLOC_OK;
 }
 
@@ -314,109 +469,98 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
   GLOC_HIP(hipMemcpyAsync(h->jobs.p, jd, sizeof(Job) * n_jobs, hipMemcpyHostToDevice, s));
   GLOC_HIP(hipMemcpyAsync(h->states.p, h->h_states, sizeof(CandState) * n_jobs, hipMemcpyHostToDevice, s));
   GLOC_TRY(setup_split(h, bd, cs));
-  GLOC_TRY(setup_heavy(h, bd, cs));
-  const bool culled = h->nn_mode != 1;
-  const float gate2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : 0.f;
-  bool have_corr = false;  // corr holds a previous pass's result: warm start for the next one
-
-  if (can && any_tgt && prm->ransac_iters > 0) {
-    const uint32_t H = prm->ransac_iters;
+  const bool ransac = can && any_tgt && prm->ransac_iters > 0;
+  const size_t H = prm->ransac_iters;
+  const bool adaptive = prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f;
+  if (ransac) {
     GLOC_TRY(h->pairs.ensure(sizeof(f32x4) * 2 * bd.ld * n_jobs, s));
-    GLOC_TRY(h->Rt.ensure(sizeof(float) * 12 * (size_t)H * n_jobs, s));
-    GLOC_TRY(h->valid.ensure(sizeof(uint32_t) * (size_t)H * n_jobs, s));
-    GLOC_TRY(h->inliers.ensure(sizeof(uint32_t) * (size_t)H * n_jobs, s));
-    GLOC_TRY(launch_nn(h, bd, false, true, 0.f));
-    have_corr = true;
-    // Phases of hypotheses, each generated, scored and scanned before the next: with the adaptive stop (the
-    // reference's call: confidence 0.99) and ~85 % inliers the iteration count drops to 5 - 8 at the first good
-    // hypothesis, so [0, 16) settles nearly every job, [16, 64) most of the rest; a job that is done is skipped by the
-    // later phases (its blocks exit at once).  The rule is sequential in h (ransac_scan_kernel), so the split does not
-    // change the result.  (Round 2 scored 64 first: 2.1 ms per step of 500 jobs, 0.6 with 16.)
-    const bool adaptive = prm->ransac_confidence > 0.f && prm->ransac_confidence < 1.f;
-    uint32_t bounds[4] = {0u, 0u, 0u, 0u};
-    int n_ph = 0;
-    for (uint32_t b : {adaptive ? 16u : 256u, adaptive ? 64u : H, H})
-      if (b <= H && b > bounds[n_ph]) bounds[++n_ph] = b;
-    if (bounds[n_ph] < H) bounds[++n_ph] = H;
-    GLOC_HIP(hipMemsetAsync(h->valid.p, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));  // never-generated = invalid
-    GLOC_HIP(hipMemsetAsync(h->inliers.p, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));
-    const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
-    const unsigned cchunks = (bd.max_src + SC_CHUNK - 1) / SC_CHUNK;
-    for (int ph = 0; ph < n_ph; ++ph) {
-      const uint32_t h0 = bounds[ph], h1 = bounds[ph + 1], len = h1 - h0;
-      const CandState* st = ph ? h->states.as<CandState>() : (const CandState*)nullptr;
-      {
-        ProfScope ps(h->prof, "ransac_hyp", s);
-        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((len + 127) / 128, n_jobs), dim3(128), 0, s, h->pairs.as<f32x4>(), bd.ld,
-                           h->jobs.as<Job>(), prm->seed, H, h0, h1, st, h->Rt.as<float>(), h->valid.as<uint32_t>());
-        GLOC_HIP(hipGetLastError());
+    GLOC_TRY(h->Rt.ensure(sizeof(float) * 12 * H * n_jobs, s));
+    GLOC_TRY(h->valid.ensure(sizeof(uint32_t) * H * n_jobs, s));
+    GLOC_TRY(h->inliers.ensure(sizeof(uint32_t) * H * n_jobs, s));
+    if (!adaptive) GLOC_TRY(h->alive.ensure(sizeof(uint32_t) * (H + 1) * n_jobs, s));
+  }
+  // Sub-batches (round 6): a SMALL batch -- one query alone: 20 jobs -- is cut into G runs of jobs, each enqueued on its
+  // own stream.  The jobs of a batch never depend on each other, but one stream makes all of them wait at every launch
+  // boundary: 21 x (search launch + solve) with the chip ramping up and draining 42 times (a pass of 20 jobs is 19 380
+  // waves over 6 144 slots: 69 us at full occupancy, 105 - 120 measured, + 14 us of solve with the chip idle).  With G
+  // streams one sub-batch's solve and ramp run under the others' searches.  Results are the same bits (a job's
+  // arithmetic never sees the batch).  Not with the per-kernel events on (they bracket launches on ONE stream), nor the trace.
+  static const int g_env = getenv("GLOC3D_REG_SUBBATCHES") ? atoi(getenv("GLOC3D_REG_SUBBATCHES")) : -1;  // developer override
+  uint32_t G = 1;
+  if (!h->prof.enabled && !h->trace_on && h->nn_mode != 1) {
+    if (g_env >= 1) G = (uint32_t)g_env;
+    else if (h->sub_batches > 0) G = (uint32_t)h->sub_batches;
+    // (-1, the default, is OFF: measured for one query alone -- 20 jobs -- 3.20 ms on one stream, 3.28 with 2 sub-batches,
+    // 3.9 with 4, 5.0 with 8, enqueued one after the other or from a host thread each: a search launch of even 5 jobs has
+    // 4 845 + helper waves for 6 144 slots, so the streams' kernels mostly run one after the other, each with its own ramp)
+  }
+  G = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(G, n_jobs), gloc_reg::MAX_SUB));
+  GLOC_TRY(setup_heavy(h, bd, cs, G));
+  std::vector<WsView> views(G);
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t j0 = (uint32_t)((uint64_t)n_jobs * g / G), j1 = (uint32_t)((uint64_t)n_jobs * (g + 1) / G);
+    WsView& v = views[g];
+    v = WsView{};
+    v.s = s;
+    v.job0 = j0;
+    v.n_jobs = j1 - j0;
+    v.jobs = h->jobs.as<Job>() + j0;
+    v.states = h->states.as<CandState>() + j0;
+    v.corr = h->corr.as<uint32_t>() + (size_t)j0 * bd.ld;
+    v.d2 = h->d2.as<float>() + (size_t)j0 * bd.ld;
+    v.partials = h->partials.as<double>() + (size_t)j0 * bd.n_part * ACC_NV;
+    if (ransac) {
+      v.pairs = h->pairs.as<f32x4>() + 2 * bd.ld * (size_t)j0;
+      v.Rt = h->Rt.as<float>() + 12 * H * j0;
+      v.valid = h->valid.as<uint32_t>() + H * j0;
+      v.inliers = h->inliers.as<uint32_t>() + H * j0;
+      if (!adaptive) {
+        v.a_idx = h->alive.as<uint32_t>() + H * j0;
+        v.a_cnt = h->alive.as<uint32_t>() + H * n_jobs + j0;
       }
-      ProfScope ps(h->prof, "ransac_score", s);
-      // hypotheses per work-group: 16 / 64 (its four waves share them and split every staged tile) or thread <-> hypothesis
-      const uint32_t hpb = len <= 16 ? 16u : (len <= 64 ? 64u : 256u);
-      static const unsigned parts_env = getenv("GLOC3D_RANSAC_PARTS") ? (unsigned)atoi(getenv("GLOC3D_RANSAC_PARTS")) : 0u;  // developer override
-      const unsigned NP = parts_env ? parts_env : 8u;
-      if (!adaptive && ph > 0 && len >= 512 && cchunks >= NP) {
-        // every hypothesis scored, not every pair of every hypothesis: an eighth of the pairs at a time, the hypotheses
-        // that can no longer beat the first phase's winner dropped in between (ransac_alive_kernel)
-        GLOC_TRY(h->alive.ensure(sizeof(uint32_t) * ((size_t)H + 1) * n_jobs, s));
-        uint32_t* a_idx = h->alive.as<uint32_t>();
-        uint32_t* a_cnt = a_idx + (size_t)H * n_jobs;
-        for (unsigned q = 0; q < NP; ++q) {
-          const unsigned c0 = q * cchunks / NP, c1 = (q + 1) * cchunks / NP;
-          hipLaunchKernelGGL(ransac_alive_kernel, dim3(n_jobs), dim3(1024), 0, s, h->inliers.as<uint32_t>(), h->valid.as<uint32_t>(),
-                             H, h0, h1, h->jobs.as<Job>(), h->states.as<CandState>(), (uint32_t)(c0 * SC_CHUNK), a_idx, a_cnt);
-          hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, c1 - c0, n_jobs), dim3(256), 0, s,
-                             h->pairs.as<f32x4>(), bd.ld, h->jobs.as<Job>(), H, h0, 256u, h->Rt.as<float>(),
-                             h->valid.as<uint32_t>(), thr2, st, h->inliers.as<uint32_t>(), a_idx, a_cnt, (uint32_t)c0);
-        }
-      } else {
-        hipLaunchKernelGGL(ransac_score_kernel, dim3((len + hpb - 1) / hpb, cchunks, n_jobs), dim3(256), 0, s,
-                           h->pairs.as<f32x4>(), bd.ld, h->jobs.as<Job>(), H, h0, hpb, h->Rt.as<float>(),
-                           h->valid.as<uint32_t>(), thr2, st, h->inliers.as<uint32_t>(), (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, 0u);
-      }
-      if (ph + 1 < n_ph)
-        hipLaunchKernelGGL(ransac_scan_kernel<false>, dim3(n_jobs), dim3(64), 0, s, h->inliers.as<uint32_t>(),
-                           h->valid.as<uint32_t>(), h->Rt.as<float>(), H, h0, h1, h->jobs.as<Job>(), prm->ransac_confidence,
-                           prm->min_inlier_ratio, h->states.as<CandState>());
-      else
-        hipLaunchKernelGGL(ransac_scan_kernel<true>, dim3(n_jobs), dim3(64), 0, s, h->inliers.as<uint32_t>(),
-                           h->valid.as<uint32_t>(), h->Rt.as<float>(), H, h0, h1, h->jobs.as<Job>(), prm->ransac_confidence,
-                           prm->min_inlier_ratio, h->states.as<CandState>());
-      GLOC_HIP(hipGetLastError());
     }
-    {
-      ProfScope ps(h->prof, "accum", s);  // refit on the best hypothesis' inliers
-      hipLaunchKernelGGL(accum_kernel<1>, dim3(nblocks, n_jobs), dim3(ACC_THREADS), 0, s, h->jobs.as<Job>(),
-                         h->states.as<CandState>(), h->corr.as<uint32_t>(), h->d2.as<float>(),
-                         h->pairs.as<f32x4>(), bd.ld, thr2, h->partials.as<double>(), bd.n_part);
-      GLOC_HIP(hipGetLastError());
+    v.split = h->split;
+    if (h->split.hx) {  // [job][...] arrays: the sub-batch's jobs
+      const size_t S = 64 * (size_t)cs;
+      v.split.work += (size_t)j0 * bd.n_part;
+      v.split.plan += (size_t)j0 * bd.n_part;
+      v.split.ticket += (size_t)j0 * h->split.hx;
+      v.split.helper += (size_t)j0 * h->split.hx;
+      v.split.skey += (size_t)j0 * h->split.hx * S;
     }
-    {
-      ProfScope ps(h->prof, "solve", s);
-      hipLaunchKernelGGL(solve_kernel<1>, dim3(h->split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, false, h->jobs.as<Job>(), h->states.as<CandState>(), h->split, n_jobs);
-      GLOC_HIP(hipGetLastError());
+    v.heavy = h->heavy_of[g];
+  }
+  if (G > 1) {
+    GLOC_TRY(ensure_sub_streams(h, G));
+    GLOC_HIP(hipEventRecord(h->fork_ev, s));  // uploads, memsets and everything earlier on the handle's stream
+    for (uint32_t g = 1; g < G; ++g) {
+      views[g].s = h->sub_stream[g - 1];
+      GLOC_HIP(hipStreamWaitEvent(views[g].s, h->fork_ev, 0));
     }
   }
-  for (uint32_t it = 0; it < prm->icp_iters && can && any_tgt; ++it) {
-    GLOC_TRY(launch_nn(h, bd, have_corr, false, gate2));
-    have_corr = true;
-    if (!culled) {
-      ProfScope ps(h->prof, "accum", s);
-      hipLaunchKernelGGL(accum_kernel<0>, dim3(nblocks, n_jobs), dim3(ACC_THREADS), 0, s, h->jobs.as<Job>(),
-                         h->states.as<CandState>(), h->corr.as<uint32_t>(), h->d2.as<float>(),
-                         (const f32x4*)nullptr, bd.ld, gate2, h->partials.as<double>(), bd.n_part);
-      GLOC_HIP(hipGetLastError());
+  int rc = GLOC_OK;
+  if (G > 1) {
+    // one host thread per sub-batch: 4 x 60 launches enqueued one stream after the other leave the later streams empty
+    // while the first runs (measured: 3.2 -> 3.9 ms for one query alone); side by side the streams fill together
+    std::vector<std::future<int>> fut;
+    for (uint32_t g = 1; g < G; ++g)
+      fut.push_back(std::async(std::launch::async, [&, g]() {
+        if (hipSetDevice(h->device) != hipSuccess) return (int)GLOC_ERR_HIP;
+        return enqueue_pipeline(h, bd, prm, views[g], can, any_tgt, nblocks);
+      }));
+    rc = enqueue_pipeline(h, bd, prm, views[0], can, any_tgt, nblocks);
+    for (auto& f : fut) {
+      const int r = f.get();
+      if (rc == GLOC_OK) rc = r;
     }
-    {
-      ProfScope ps(h->prof, "solve", s);
-      hipLaunchKernelGGL(solve_kernel<0>, dim3(h->split.hx ? 2 * n_jobs : n_jobs), dim3(SOLVE_THREADS), 0, s, h->partials.as<double>(),
-                         bd.n_part, culled, h->jobs.as<Job>(), h->states.as<CandState>(), h->split, n_jobs);
-      GLOC_HIP(hipGetLastError());
-    }
+  } else {
+    rc = enqueue_pipeline(h, bd, prm, views[0], can, any_tgt, nblocks);
   }
+  for (uint32_t g = 1; g < G; ++g) {  // (also after a failure part-way: whatever was launched is joined)
+    (void)hipEventRecord(h->join_ev[g - 1], views[g].s);
+    (void)hipStreamWaitEvent(s, h->join_ev[g - 1], 0);
+  }
+  GLOC_TRY(rc);
   GLOC_HIP(hipMemcpyAsync(h->h_states, h->states.p, sizeof(CandState) * n_jobs, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipEventRecord(h->done_ev, s));
   return GLOC_OK;
@@ -430,10 +574,10 @@ int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max
   if (n_jobs == 0) return GLOC_OK;
   GLOC_HIP(hipEventSynchronize(h->done_ev));
   static const bool heavy_dbg = getenv("GLOC3D_NN_HEAVY_DEBUG") != nullptr;  // developer switch: the length of the last cold pass's list
-  if (heavy_dbg && h->heavy.cap) {
+  if (heavy_dbg && h->heavy_of[0].cap) {
     uint32_t cnt = 0;
-    (void)hipMemcpy(&cnt, h->heavy.count, 4, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[gloc3d] cold pass of %u jobs: %u groups given up (list of %u)\n", n_jobs, cnt, h->heavy.cap);
+    (void)hipMemcpy(&cnt, h->heavy_of[0].count, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[gloc3d] cold pass of %u jobs: %u groups given up in the first sub-batch (list of %u)\n", n_jobs, cnt, h->heavy_of[0].cap);
   }
   for (uint32_t c = 0; c < n_jobs; ++c) {
     const CandState& st = h->h_states[c];
@@ -603,6 +747,11 @@ int gloc_reg_destroy(gloc_reg* h) {
                     &h->partials, &h->export_idx, &h->export_d2, &h->counters, &h->trace, &h->split_zero, &h->split_ff, &h->alive, &h->heavy_buf})
     b->release();
   if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  for (uint32_t g = 0; g + 1 < gloc_reg::MAX_SUB; ++g) {
+    if (h->join_ev[g]) (void)hipEventDestroy(h->join_ev[g]);
+    if (h->sub_stream[g]) (void)hipStreamDestroy(h->sub_stream[g]);
+  }
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -653,6 +802,11 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_SPLIT_HELPERS) {
     GLOC_REQUIRE(value >= -1 && value <= 4096, GLOC_ERR_INVALID, "must be in [-1, 4096]");
     h->nn_split_helpers = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_SUB_BATCHES) {
+    GLOC_REQUIRE(value >= -1 && value <= (int64_t)gloc_reg::MAX_SUB, GLOC_ERR_INVALID, "must be in [-1, %u]", gloc_reg::MAX_SUB);
+    h->sub_batches = (int)value;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_HEAVY_THRESH) {
@@ -981,7 +1135,16 @@ int gloc_reg_nn(gloc_reg* h, const float* src_xyz, size_t n_src, const float* tg
     return done(GLOC_ERR_HIP);
   h->split = NnSplit{};  // (one cold pass: there is no estimate to plan from)
   if (int rc_h = setup_heavy(h, bd, cs)) return done(rc_h);
-  int rc = launch_nn(h, bd, false, false, 0.f);
+  WsView v{};
+  v.s = s;
+  v.n_jobs = 1;
+  v.jobs = h->jobs.as<Job>();
+  v.states = h->states.as<CandState>();
+  v.corr = h->corr.as<uint32_t>();
+  v.d2 = h->d2.as<float>();
+  v.partials = h->partials.as<double>();
+  v.heavy = h->heavy_of[0];
+  int rc = launch_nn(h, bd, v, false, false, 0.f);
   if (rc != GLOC_OK) return done(rc);
   hipLaunchKernelGGL(export_corr_kernel, dim3((unsigned)((n_src + 255) / 256), 1), dim3(256), 0, s,
                      h->jobs.as<Job>(), h->corr.as<uint32_t>(), h->d2.as<float>(), bd.ld,

@@ -256,9 +256,15 @@ enum {
   GLOC_REG_OPT_NN_SUB_JOBS = 8,      /* culled search tuning: interleaved shares of a job's work-groups that take a
                                        slot of the launch order each (a slot stays on one XCD); 0 (default): 8 for
                                        batches under 48 jobs, which 8 XCDs cannot balance job by job, else 1 */
-  GLOC_REG_OPT_NN_HEAVY_THRESH = 9   /* culled search, first (cold) pass of a batch: a wave that has processed this many
+  GLOC_REG_OPT_NN_HEAVY_THRESH = 9,  /* culled search, first (cold) pass of a batch: a wave that has processed this many
                                        target chunks hands its source group to a second launch, which searches it with
                                        8 waves (identical results); default 32; 0: off */
+  GLOC_REG_OPT_SUB_BATCHES = 10      /* a small batch is cut into this many runs of jobs, each enqueued on its own internal
+                                       stream (forked from and joined back into the handle's stream), so that one
+                                       run's solve and ramp-up run under the others' searches: 2 .. 8; -1 (default), 0, 1: off --
+                                       measured SLOWER for one query alone (20 jobs: 3.2 ms on one stream, 3.9 with 4): a
+                                       search launch of 5 jobs already has more waves than the chip has slots.  Identical
+                                       results */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

@@ -642,6 +642,51 @@ def test_cold_waves_that_give_up_change_no_bit(capi, scans):
     store.close()
 
 
+def test_sub_batches_on_their_own_streams_change_no_bit(capi, scans):
+    """GLOC_REG_OPT_SUB_BATCHES (round 6): a small batch cut into runs of jobs, each enqueued on its own internal stream
+    (forked from and joined into the handle's): the same poses, rmse, inliers, ok and correspondences as one stream, bit
+    for bit -- with and without RANSAC, with the split plan and the cold pass's second launch in play, on a caller's stream,
+    twice in a row (the streams are reused), and through begin / end."""
+    import torch
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qid = store.add(np.ascontiguousarray(B[::4]))
+    cids = [store.add(np.ascontiguousarray(x)) for x in (A[::4], A[1::5], Cc[::4], A[2::6], Cc[1::5], A[3::7], A[::9], Cc[::7], A[5::8])]
+    store.build_target_index_batch(cids[:5])
+    n = len(B[::4])
+
+    def run(G, ransac, icp, stream=None, begin_end=False):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_SUB_BATCHES, G)
+        r.set_option(capi.REG_OPT_NN_HEAVY_THRESH, 3)
+        if stream is not None:
+            r.set_stream(stream.cuda_stream)
+        prm = capi.default_reg_params(ransac_iters=ransac, icp_iters=icp)
+        outs = []
+        for _ in range(2):
+            if begin_end:
+                r.batch_multi_begin([qid], np.array([cids], np.uint32), params=prm)
+                o = r.batch_multi_end()
+                outs.append({k: v[0] for k, v in o.items()})
+            else:
+                outs.append(r.batch_ids(qid, cids, params=prm))
+        corr = [r.debug_corr(j, n) for j in range(len(cids))]
+        r.close()
+        return outs, corr
+
+    for ransac, icp in ((200, 4), (0, 3), (200, 0)):
+        (ref, ref2), ref_corr = run(1, ransac, icp)
+        for G, stream, be in ((2, None, False), (4, None, False), (8, None, True), (-1, torch.cuda.Stream(), False), (3, torch.cuda.Stream(), True)):
+            outs, corr = run(G, ransac, icp, stream, be)
+            for out in outs:
+                what = (ransac, icp, G, be)
+                assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all(), what
+                assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all(), what
+            for j in range(len(cids)):
+                assert (corr[j][0] == ref_corr[j][0]).all() and (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), (ransac, icp, G, j)
+    store.close()
+
+
 def test_split_groups_decide_ties_by_the_original_index(capi, oracle_mod):
     """Equidistant targets in DIFFERENT parts of a split group: the parts' keys are (distance, original index), so the
     smallest original index wins as in the single wave.  Lattice targets in shuffled order, sources on cell centres /

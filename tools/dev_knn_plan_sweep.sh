@@ -1,2 +1,10 @@
-for cfg in "2,1" "2,2" "2,4" "1,1" "1,2" "1,4"; do for ph in 5 3 7; do echo -n "shard B3=$cfg phase=$ph: "; GLOC3D_KNN_PROF=1 GLOC3D_KNN_B3=$cfg GLOC3D_KNN_B3_PHASE=$ph timeout -k 5 60 python tools/bench_knn.py --algo 2 --reps 20 --n 125000 --kind 1 2>&1 | grep "kNN\|stage" | sed "s/.*algo=2: //; s/(wall.*//; s/.*'dist_mfma': /mfma /; s/, 'dist_exact.*//" | tr "\n" " "; echo; done; done
-for cfg in "1,4" "1,2" "1,8" "2,4" "2,2"; do for ph in 5 3; do echo -n "cfgB B3=$cfg phase=$ph: "; GLOC3D_KNN_PROF=1 GLOC3D_KNN_B3=$cfg GLOC3D_KNN_B3_PHASE=$ph timeout -k 5 60 python tools/bench_knn.py --algo 2 --reps 200 --kind 1 2>&1 | grep "kNN\|stage" | sed "s/.*algo=2: //; s/(wall.*//; s/.*'dist_mfma': /mfma /; s/, 'dist_exact.*//" | tr "\n" " "; echo; done; done
+# dev: the split-bf16 coarse kernel (round 6: over the tiled mirror) under every tile / split-K plan at the 125 000-row shard and cfg B
+cd $GRAFT_REPO_ROOT
+for plan in "" "1,1" "1,2" "2,1" "2,2" "2,4" "1,4"; do
+  if [ -n "$plan" ]; then export GLOC3D_KNN_B3=$plan; else unset GLOC3D_KNN_B3; fi
+  echo "B3=${plan:-default} shard: $(GLOC3D_KNN_PROF=1 python3 tools/bench_knn.py --kind 1 --n 125000 --reps 40 2>/dev/null | tr '\n' ' ' | sed 's/stats {[^}]*}//;s/(wall, device resident).*TB\/s;//' | cut -c1-230)"
+done
+for plan in "" "1,2" "1,4" "1,8" "2,4" "2,8"; do
+  if [ -n "$plan" ]; then export GLOC3D_KNN_B3=$plan; else unset GLOC3D_KNN_B3; fi
+  echo "B3=${plan:-default} cfgB : $(GLOC3D_KNN_PROF=1 python3 tools/bench_knn.py --kind 1 --reps 300 2>/dev/null | tr '\n' ' ' | sed 's/stats {[^}]*}//;s/(wall, device resident).*TB\/s;//' | cut -c1-230)"
+done

@@ -90,7 +90,8 @@ int ensure_rows(gloc_knn* h, size_t n_rows) {
   GLOC_TRY(h->norms.ensure(n_rows * sizeof(float), h->stream, true, h->n * sizeof(float)));
   if (h->dim % 8 == 0) {  // (whole tiles, and two more: the coarse kernel's last work-group may own a tile past the end)
     const size_t tile_bytes = mirror_tile_u32x4((int)h->dim) * 16;
-    GLOC_TRY(h->mirror.ensure(((n_rows + MIR_ROWS - 1) / MIR_ROWS + 2) * tile_bytes, h->stream, true,
+    // (+ 8 KB: a step's four planes of the last tile when dim / 8 is no multiple of four -- dist_bf16x3_tiled_kernel)
+    GLOC_TRY(h->mirror.ensure(((n_rows + MIR_ROWS - 1) / MIR_ROWS + 2) * tile_bytes + 8192, h->stream, true,
                               (h->n + MIR_ROWS - 1) / MIR_ROWS * tile_bytes));
   }
   if (!h->dn_max.p) {

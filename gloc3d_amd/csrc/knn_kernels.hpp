@@ -892,7 +892,11 @@ __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __r
       pre.q[i][0] = f32x4{a.x, a.y, a.z, a.w};
       pre.q[i][1] = f32x4{b.x, b.y, b.z, b.w};
     }
-    const int kp = (k < dim ? k : dim - BK) / 8;  // (a prefetch past the end reads the last step again: never stored)
+    // (a prefetch past the end reads the last step again -- never stored; a dim below one step: step 0.  The planes of a step
+    // that lie beyond dim / 8 -- dim no multiple of 32 -- are read from whatever follows the tile, the next tile or the
+    // allocation's padding, and zeroed at the store)
+    const int klast = dim - BK > 0 ? dim - BK : 0;
+    const int kp = (k < dim ? k : klast) / 8;
 #pragma unroll
     for (int i = 0; i < ND; ++i)
       pre.d[i] = mirror[(tile0 + i / 2) * tile_slots + (size_t)kp * 2 * MIR_ROWS + (i % 2) * 256 + tid];

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-PAYLOADS = ["profiles/r05_bench_n1.json", "profiles/r05_n2_rehearsal_gloo.json"]
+PAYLOADS = ["profiles/r05_bench_n1.json", "profiles/r05_n2_rehearsal_gloo.json", "profiles/r06_bench_detail.json", "profiles/r06_n2_rehearsal_gloo.json"]
 
 
 def strict(text):

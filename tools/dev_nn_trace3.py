@@ -9,10 +9,10 @@ W = 32  # NN_TRACE_WORDS
 icp = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 # round 6: the headline's data -- distinct device ray-casts along the loop (bench.headline_world); query q revisits place
-# 300 + 500 q, its 20 candidates are the places around it in index order (what the descriptor retrieval returns)
+# 300 + 170 q, its 20 candidates are the places around it in index order (what the descriptor retrieval returns)
 traj, world_a, world_b = bench.headline_world(bench.N_PLACES_1GPU)
 store = capi.ScanStore()
-g0 = [300 + 500 * q for q in range(nq)]
+g0 = [300 + 170 * q for q in range(nq)]
 qids = store.add_raycast(world_a, [traj[g] @ bench.query_offset(q) for q, g in enumerate(g0)], np.array([bench.QUERY_SEED + q for q in range(nq)], np.uint64))
 cands_all, cand_dist = [], []
 for q, g in enumerate(g0):

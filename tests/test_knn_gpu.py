@@ -481,3 +481,21 @@ def test_a_view_searches_its_parents_rows_beside_it(capi):
         ix.close()                                                    # not while a view lives
     v.close()
     ix.close()
+
+
+@pytest.mark.parametrize("D", [8, 16, 24, 40])
+def test_coarse_mirror_with_a_dim_below_one_step(capi, oracle_mod, D):
+    """Round 6: the split-bf16 coarse pass streams a tiled mirror in steps of 32 k.  A dim below one step (8, 16, 24) made its
+    prefetch index planes BELOW the mirror (a GPU memory fault in the long fuzz run); 40 = one step and a quarter.  Windows
+    that start inside a tile, a database that ends inside one."""
+    from gloc3d_amd import synth
+    N, Q = 1000 + D, 33
+    db = synth.descriptors_iid(300 + D, 0, N, D)
+    q = synth.descriptors_iid(400 + D, 0, Q, D)
+    ix = _index(capi, db, 2)
+    for first, last in ((0, N), (37, N - 5), (64, 65 + D)):
+        idx, d2 = ix.search(q, 5, first_row=first, last_row=last)
+        oi, od = oracle_mod.knn_search(db[first:last], q, 5)
+        oi = np.where(oi == np.iinfo(np.uint64).max, oi, oi + np.uint64(first))
+        assert (idx == oi).all() and (bits(d2) == bits(od)).all(), (first, last)
+    ix.close()

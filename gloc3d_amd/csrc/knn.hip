@@ -39,6 +39,8 @@ struct gloc_knn {
   DevBuf dev_trace; // developer aid: phase stamps of the fused select + re-rank kernel (null unless enabled)
   DevBuf flags;     // [nq] int
   DevBuf redo_tickets;  // [nq] u32: flagged_redo_kernel's tickets (0 between searches)
+  DevBuf bmin;          // [nq][blocks of 32 rows]: the coarse kernel's block minima (large windows, one K-split)
+  DevBuf force_flags;   // [nq] int: select_blocks_kernel's "more tied blocks than the list holds"
   DevBuf stage_q;   // host-API staging: queries
   DevBuf stage_idx, stage_d2;
   int* h_flags = nullptr;  // pinned
@@ -395,6 +397,8 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     GLOC_TRY(h->n_incomplete.ensure(sizeof(unsigned long long), h->stream));
     GLOC_HIP(hipMemsetAsync(h->n_incomplete.p, 0, sizeof(unsigned long long), h->stream));
   }
+  bool use_bmin = false;
+  int n_blocks = 0;
   if (p.b3) {
     // few work-groups: each splits its queries itself; many: once, ahead of the launch
     dim3 grid((unsigned)((n_range + p.BN - 1) / p.BN), (unsigned)((nq + p.BQ - 1) / p.BQ), (unsigned)p.KS);
@@ -415,6 +419,15 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     if (!no_mirror && h->mirror.p) {
       // the rows from their tiled, pre-split mirror: contiguous 8-KB runs per tile and step (round 6)
       const dim3 tgrid((unsigned)((first % MIR_ROWS + (size_t)n_range + p.BN - 1) / p.BN), grid.y, grid.z);
+      // a large window in one K-split: the epilogue leaves block minima for select_blocks_kernel (below)
+      static const bool no_bmin = getenv("GLOC3D_KNN_NO_BLOCKMIN") != nullptr;  // developer switch: the slices
+      n_blocks = (int)tgrid.x * (p.BN / 32);
+      use_bmin = !no_bmin && n_range > SELQ_MAX_ROWS && p.KS == 1 && n_blocks <= SELQ_MAX_ROWS && KC <= SRR_KC &&
+                 (int)h->dim <= 4 * SRR_G && !getenv("GLOC3D_KNN_NO_FUSED_RERANK");
+      if (use_bmin) {
+        GLOC_TRY(h->bmin.ensure((size_t)nq * n_blocks * sizeof(float), h->stream));
+        GLOC_TRY(h->force_flags.ensure((size_t)nq * sizeof(int), h->stream));
+      }
 #define B3T(NT_, QR_)                                                                                                  \
   do {                                                                                                                \
     constexpr int lds_bytes = b3_lds_bytes<NT_, 4>();                                                                 \
@@ -425,9 +438,21 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                          \
       attr_set.fetch_or(dev_bit, std::memory_order_relaxed);                                                          \
     }                                                                                                                 \
-    hipLaunchKernelGGL((dist_bf16x3_tiled_kernel<NT_, QR_>), tgrid, dim3(256), lds_bytes, h->stream,                  \
-                       h->mirror.as<u32x4>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld,   \
-                       strideP);                                                                                      \
+    if (use_bmin) {                                                                                                   \
+      static std::atomic<uint64_t> attr_set_b{0};                                                                     \
+      if (lds_bytes > 48 * 1024 && !(attr_set_b.load(std::memory_order_relaxed) & dev_bit)) {                         \
+        GLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_bf16x3_tiled_kernel<NT_, QR_, true>),        \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                        \
+        attr_set_b.fetch_or(dev_bit, std::memory_order_relaxed);                                                      \
+      }                                                                                                               \
+      hipLaunchKernelGGL((dist_bf16x3_tiled_kernel<NT_, QR_, true>), tgrid, dim3(256), lds_bytes, h->stream,          \
+                         h->mirror.as<u32x4>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, \
+                         strideP, h->norms.as<float>(), h->bmin.as<float>(), n_blocks);                               \
+    } else {                                                                                                          \
+      hipLaunchKernelGGL((dist_bf16x3_tiled_kernel<NT_, QR_>), tgrid, dim3(256), lds_bytes, h->stream,                \
+                         h->mirror.as<u32x4>(), qsrc, h->dist.as<float>(), (int)h->dim, first, n_range, nq, kps3, ld, \
+                         strideP, (const float*)nullptr, (float*)nullptr, 0);                                         \
+    }                                                                                                                 \
   } while (0)
       if (p.NT == 1) { if (qraw) B3T(1, true); else B3T(1, false); }
       else { if (qraw) B3T(2, true); else B3T(2, false); }
@@ -506,10 +531,17 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   static const bool no_fused = getenv("GLOC3D_KNN_NO_FUSED_RERANK") != nullptr;  // developer switch: the three launches
   const bool large = n_range > SELQ_MAX_ROWS;  // slices first; an incomplete query is flagged for the host
   SlicePlan sl{1, 0};
-  const bool fused = (!large || plan_slices(n_range, nq, KC, &sl)) && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
+  const bool fused = (!large || use_bmin || plan_slices(n_range, nq, KC, &sl)) && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
   if (fused) {
     // select + re-rank + completeness check in one launch, one work-group per query
-    if (large) {
+    if (large && use_bmin) {  // round 6: from the coarse kernel's block minima -- 32 x KC partial dots per query, not the window's
+      ProfScope ps(h->prof, "select", h->stream);
+      GLOC_TRY(h->klists.ensure((size_t)nq * SELB_LIST * sizeof(uint64_t), h->stream));
+      hipLaunchKernelGGL(select_blocks_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->bmin.as<float>(), n_blocks,
+                         h->dist.as<float>(), ld, d_q, (int)h->dim, h->norms.as<float>(), first, n_range, KC,
+                         h->klists.as<uint64_t>(), h->force_flags.as<int>());
+      GLOC_HIP(hipGetLastError());
+    } else if (large) {
       ProfScope ps(h->prof, "select", h->stream);
       GLOC_TRY(launch_slices<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, sl, nullptr));
     }
@@ -520,9 +552,10 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
       h->qnorm.as<float>(), d_keys_out, h->flags.as<int>(), h->n_incomplete.as<unsigned long long>(), fo,                \
       h->dist.as<float>(), h->dev_trace.as<unsigned long long>()
     if (large)
-      hipLaunchKernelGGL(select_rerank_kernel<true>, SRR_ARGS, h->klists.as<uint64_t>(), sl.S * KC);
+      hipLaunchKernelGGL(select_rerank_kernel<true>, SRR_ARGS, h->klists.as<uint64_t>(), use_bmin ? SELB_LIST : sl.S * KC,
+                         use_bmin ? h->force_flags.as<int>() : (const int*)nullptr);
     else
-      hipLaunchKernelGGL(select_rerank_kernel<false>, SRR_ARGS, (const uint64_t*)nullptr, 0);
+      hipLaunchKernelGGL(select_rerank_kernel<false>, SRR_ARGS, (const uint64_t*)nullptr, 0, (const int*)nullptr);
 #undef SRR_ARGS
     GLOC_HIP(hipGetLastError());
     // (incomplete queries -- rare -- are redone exactly by their own work-group inside the same launch: no
@@ -775,6 +808,8 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->dev_trace.release();
   h->flags.release();
   h->redo_tickets.release();
+  h->bmin.release();
+  h->force_flags.release();
   h->stage_q.release();
   h->stage_idx.release();
   h->stage_d2.release();

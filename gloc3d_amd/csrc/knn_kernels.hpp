@@ -847,11 +847,20 @@ __global__ __launch_bounds__(256) void mirror_rows_kernel(const float* __restric
 // The coarse pass over the mirror: the arithmetic, the LDS image and the MFMA sequence of dist_bf16x3_kernel; only where
 // the rows come from differs.  Tiles are aligned to ABSOLUTE row numbers: a window that starts inside a tile computes the
 // tile's leading rows too and stores nothing for them (row - first_row < 0).
-template <int NT, bool QRAW>
+// BMIN (round 6, one K-split, windows above 16 384 rows): the epilogue also leaves, per query and per BLOCK of 32 rows (a
+// wave's 32 x 32 accumulator), the minimum of  |d|^2 - 2 q.d  over the block's rows of the window -- the coarse distance
+// without the query's norm, which does not change an order.  The KC smallest coarse distances of the window lie in blocks
+// whose minimum is <= the KC-th smallest block minimum (that one is the minimum of KC distinct rows), so the selection that
+// follows reads 32 x KC partial dots per query instead of the window's (select_blocks_kernel): at 64 x 125 000, 1 MB instead
+// of 32 MB, one launch of 9 us instead of the slices' 28 - 34.
+template <int NT, bool QRAW, bool BMIN = false>
 __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __restrict__ mirror,
                                                                 const float* __restrict__ qsplit /* split_queries_kernel, or raw */,
                                                                 float* __restrict__ P, int dim, size_t first_row, int n_range,
-                                                                int nq, int k_per_split, size_t ldP, size_t strideP) {
+                                                                int nq, int k_per_split, size_t ldP, size_t strideP,
+                                                                const float* __restrict__ dn = nullptr /* BMIN: the rows' norms */,
+                                                                float* __restrict__ bmin = nullptr /* BMIN: [nq][n_blocks] */,
+                                                                int n_blocks = 0) {
   constexpr int KO = 4;
   constexpr int BQ = 64;
   constexpr int BN = 64 * NT;
@@ -870,6 +879,15 @@ __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __r
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = (kbeg + k_per_split) < dim ? (kbeg + k_per_split) : dim;
   const size_t tile_slots = mirror_tile_u32x4(dim);
+  float dn_pre[NT];  // BMIN: the norms of this lane's rows, fetched before the walk over k (their latency is then nobody's)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    dn_pre[t] = 0.f;
+    if constexpr (BMIN) {
+      const long long j = j0 + ((tid >> 7) * NT + t) * 32 + (tid & 31);  // (wn = tid >> 7, lane & 31 = tid & 31)
+      if (j >= 0 && j < (long long)n_range) dn_pre[t] = dn[first_row + (size_t)j];
+    }
+  }
 
   const int ko8 = (tid % KO) * 8;
   const float* qsrc[NQ];
@@ -996,6 +1014,43 @@ __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __r
       for (int r = 0; r < 16; ++r) {
         const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         Pz[(size_t)qq * ldP + (size_t)j] = tot[t][r];  // rows q >= nq land in the padded part of P
+      }
+    }
+    if constexpr (BMIN) {
+      const bool in = j >= 0 && j < (long long)n_range;
+      const float dnj = dn_pre[t];
+      const int b = blockIdx.x * (BN / 32) + wn * NT + t;
+      // the minimum over the 32 lanes that hold a query's 32 rows (lanes 0-31: one query, 32-63: another), for the 16
+      // accumulator registers at once: four DPP steps inside the rows of 16 lanes, then row 0 -> 1 and row 2 -> 3; lanes 31
+      // and 63 end with it.  The 16 chains are interleaved step by step, so a register is read by a DPP operand 15
+      // instructions after it was written: only the first step needs wait states (one chain at a time with its own s_nops:
+      // +9 us on the 378-us kernel at 64 x 125 000).
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = in ? dnj - 2.f * tot[t][r] : __builtin_inff();
+#define GLOC_BM_STEP(CTRL)                                                                                              \
+  "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL "\n\t"      \
+  "v_min_f32_dpp %3, %3, %3 " CTRL "\n\tv_min_f32_dpp %4, %4, %4 " CTRL "\n\tv_min_f32_dpp %5, %5, %5 " CTRL "\n\t"      \
+  "v_min_f32_dpp %6, %6, %6 " CTRL "\n\tv_min_f32_dpp %7, %7, %7 " CTRL "\n\tv_min_f32_dpp %8, %8, %8 " CTRL "\n\t"      \
+  "v_min_f32_dpp %9, %9, %9 " CTRL "\n\tv_min_f32_dpp %10, %10, %10 " CTRL "\n\tv_min_f32_dpp %11, %11, %11 " CTRL "\n\t" \
+  "v_min_f32_dpp %12, %12, %12 " CTRL "\n\tv_min_f32_dpp %13, %13, %13 " CTRL "\n\tv_min_f32_dpp %14, %14, %14 " CTRL "\n\t" \
+  "v_min_f32_dpp %15, %15, %15 " CTRL "\n\t"
+      asm("s_nop 4\n\t"
+          GLOC_BM_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+          GLOC_BM_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+          GLOC_BM_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+          GLOC_BM_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+          GLOC_BM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+          "s_nop 0"
+          : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+            "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#undef GLOC_BM_STEP
+      if ((lane & 31) == 31 && b < n_blocks) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (qq < nq) bmin[(size_t)qq * n_blocks + b] = v[r];
+        }
       }
     }
   }
@@ -1442,6 +1497,67 @@ __global__ __launch_bounds__(SELQ_THREADS) void flagged_redo_kernel(
   }
 }
 
+// Round 6 -- the selection over a LARGE window from the coarse kernel's block minima (dist_bf16x3_tiled_kernel<.., BMIN>):
+// one work-group per query finds the KC smallest block minima, takes EVERY block whose minimum is <= the KC-th (ties
+// included; more than SELB_MAX_BLOCKS of them: the query is flagged for the exact redo), and writes the coarse keys of
+// those blocks' rows -- (|q|^2 + |d|^2) - 2 q.d exactly as selq_select<1> forms them -- as a list of 32 x SELB_MAX_BLOCKS
+// ready keys for select_rerank_kernel<true>.  Replaces select_slices_kernel<1> there (which read the whole window again).
+constexpr int SELB_MAX_BLOCKS = 64;
+constexpr int SELB_LIST = 32 * SELB_MAX_BLOCKS;
+__global__ __launch_bounds__(SELQ_THREADS) void select_blocks_kernel(
+    const float* __restrict__ bmin /* [nq][NB] */, int NB, const float* __restrict__ P, size_t ld, const float* __restrict__ queries,
+    int dim, const float* __restrict__ dn, size_t first_row, int n_range, int KC, uint64_t* __restrict__ lists /* [nq][SELB_LIST] */,
+    int* __restrict__ force_flag /* [nq] */) {
+  __shared__ uint64_t buf[SEL_LIST];
+  __shared__ float qred[SELQ_THREADS / 64];
+  __shared__ uint64_t tau_s;
+  __shared__ int cnt;
+  __shared__ int blk[SELB_MAX_BLOCKS];
+  __shared__ int nblk;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int q = blockIdx.x;
+  const float* qp = queries + (size_t)q * dim;
+  const float* bq = bmin + (size_t)q * NB;
+  // the KC-th smallest block minimum (fewer blocks than KC: the last one).  (A cheaper bound from above -- each full wave's
+  // m-th smallest thread minimum, their maximum -- was tried: it lets ~100 blocks through, more than the list holds, and the
+  // exact selection had to run behind it most of the time: 14.9 -> 17.8 us.)
+  selq_select<0>(bq, 0, 1, qp, dim, nullptr, 0, NB, KC, buf, qred, &tau_s, &cnt);
+  const int kk = NB < KC ? NB : KC;
+  const uint32_t tau_ord = (uint32_t)(buf[kk - 1] >> 32);
+  if (tid == 0) nblk = 0;
+  __syncthreads();
+  for (int b = tid; b < NB; b += SELQ_THREADS)
+    if (f2ord(bq[b]) <= tau_ord) {
+      const int pos = atomicAdd(&nblk, 1);
+      if (pos < SELB_MAX_BLOCKS) blk[pos] = b;
+    }
+  // the query's norm, summed as selq_select sums it (the same bits in every kernel that forms it)
+  float sq = 0.f;
+  for (int d = tid; d < dim; d += SELQ_THREADS) sq += qp[d] * qp[d];
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) qred[w] = sq;
+  __syncthreads();
+  float qnv = 0.f;
+  for (int i = 0; i < SELQ_THREADS / 64; ++i) qnv += qred[i];
+  const int nb = nblk < SELB_MAX_BLOCKS ? nblk : SELB_MAX_BLOCKS;
+  if (tid == 0) force_flag[q] = nblk > SELB_MAX_BLOCKS ? 1 : 0;
+  const long long off = (long long)(first_row % MIR_ROWS);
+  const float* Pq = P + (size_t)q * ld;
+  uint64_t* out = lists + (size_t)q * SELB_LIST;
+  for (int i = tid; i < SELB_LIST; i += SELQ_THREADS) {
+    uint64_t key = KEY_SENTINEL;
+    const int bi = i >> 5;
+    if (bi < nb) {
+      const long long j = (long long)blk[bi] * 32 - off + (i & 31);
+      if (j >= 0 && j < (long long)n_range) {
+        const float d = (qnv + dn[first_row + (size_t)j]) - 2.f * Pq[j];  // as selq_select<1>
+        key = make_key(d, (uint32_t)(first_row + (size_t)j));
+      }
+    }
+    out[i] = key;
+  }
+}
+
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
 __global__ __launch_bounds__(256) void select_merge_kernel(const uint64_t* __restrict__ in_keys,
                                                            int nlists, int per_group, int K,
@@ -1725,7 +1841,8 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     float* __restrict__ qn_out, uint64_t* __restrict__ out_keys /* [nq][k] */, int* __restrict__ flags,
     unsigned long long* __restrict__ n_incomplete, FinalOut fo, float* __restrict__ dist_scratch /* = P: row q of split 0 is this query's */,
     unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */,
-    const uint64_t* __restrict__ lists = nullptr, int n_list = 0) {
+    const uint64_t* __restrict__ lists = nullptr, int n_list = 0,
+    const int* __restrict__ force_incomplete = nullptr /* LISTS: queries whose lists are known to be short (select_blocks_kernel) */) {
   const unsigned long long t_start = dev_trace ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ uint64_t buf[SEL_LIST];
   __shared__ float qred[SELQ_THREADS / 64];
@@ -1761,6 +1878,9 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     const float theta = rerank_theta(__shfl(dco, kk - 1), qnv, __uint_as_float(*dn_max_bits), eps_rel_d, eps_rel_n);
     m = __popcll(__builtin_amdgcn_ballot_w64(valid && dco <= theta));
     if (n_valid == KC && n_range > KC) complete = __shfl(dco, KC - 1) > theta;
+  }
+  if constexpr (LISTS) {
+    if (force_incomplete && force_incomplete[q]) complete = false;  // (uniform: one value per query)
   }
   if (w == 0 && lane < SRR_KC) rows_s[lane] = valid ? (uint32_t)ck : 0u;
   __syncthreads();  // every wave has its candidates in registers: buf is free and takes the query

@@ -1307,7 +1307,7 @@ def main():
                     "(fp32_mfma_roofline_us, kept beside it)"}
         sh = {}
         for nq in (1, 64):
-            us, kern, st_, _ = knn_record(KNN_SHARD_ROWS, nq, 20)
+            us, kern, st_, _ = knn_record(KNN_SHARD_ROWS, nq, 50)
             byts = 4.0 * KNN_SHARD_ROWS * DIM
             flop = 2.0 * nq * KNN_SHARD_ROWS * DIM
             roof_s, fp32_s = knn_roofline_s(KNN_SHARD_ROWS, nq, DIM)

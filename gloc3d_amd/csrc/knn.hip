@@ -40,7 +40,6 @@ struct gloc_knn {
   DevBuf flags;     // [nq] int
   DevBuf redo_tickets;  // [nq] u32: flagged_redo_kernel's tickets (0 between searches)
   DevBuf bmin;          // [nq][blocks of 32 rows]: the coarse kernel's block minima (large windows, one K-split)
-  DevBuf force_flags;   // [nq] int: select_blocks_kernel's "more tied blocks than the list holds"
   DevBuf stage_q;   // host-API staging: queries
   DevBuf stage_idx, stage_d2;
   int* h_flags = nullptr;  // pinned
@@ -419,14 +418,13 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
     if (!no_mirror && h->mirror.p) {
       // the rows from their tiled, pre-split mirror: contiguous 8-KB runs per tile and step (round 6)
       const dim3 tgrid((unsigned)((first % MIR_ROWS + (size_t)n_range + p.BN - 1) / p.BN), grid.y, grid.z);
-      // a large window in one K-split: the epilogue leaves block minima for select_blocks_kernel (below)
+      // a large window in one K-split: the epilogue leaves block minima for the selection (select_blocks_body)
       static const bool no_bmin = getenv("GLOC3D_KNN_NO_BLOCKMIN") != nullptr;  // developer switch: the slices
       n_blocks = (int)tgrid.x * (p.BN / 32);
       use_bmin = !no_bmin && n_range > SELQ_MAX_ROWS && p.KS == 1 && n_blocks <= SELQ_MAX_ROWS && KC <= SRR_KC &&
                  (int)h->dim <= 4 * SRR_G && !getenv("GLOC3D_KNN_NO_FUSED_RERANK");
       if (use_bmin) {
         GLOC_TRY(h->bmin.ensure((size_t)nq * n_blocks * sizeof(float), h->stream));
-        GLOC_TRY(h->force_flags.ensure((size_t)nq * sizeof(int), h->stream));
       }
 #define B3T(NT_, QR_)                                                                                                  \
   do {                                                                                                                \
@@ -534,13 +532,9 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
   const bool fused = (!large || use_bmin || plan_slices(n_range, nq, KC, &sl)) && KC <= SRR_KC && (int)h->dim <= 4 * SRR_G && !no_fused;
   if (fused) {
     // select + re-rank + completeness check in one launch, one work-group per query
-    if (large && use_bmin) {  // round 6: from the coarse kernel's block minima -- 32 x KC partial dots per query, not the window's
-      ProfScope ps(h->prof, "select", h->stream);
+    if (large && use_bmin) {  // round 6: from the coarse kernel's block minima -- 32 x KC partial dots per query, not the window's:
+      // inside the select + re-rank launch itself (select_blocks_body)
       GLOC_TRY(h->klists.ensure((size_t)nq * SELB_LIST * sizeof(uint64_t), h->stream));
-      hipLaunchKernelGGL(select_blocks_kernel, dim3(nq), dim3(SELQ_THREADS), 0, h->stream, h->bmin.as<float>(), n_blocks,
-                         h->dist.as<float>(), ld, d_q, (int)h->dim, h->norms.as<float>(), first, n_range, KC,
-                         h->klists.as<uint64_t>(), h->force_flags.as<int>());
-      GLOC_HIP(hipGetLastError());
     } else if (large) {
       ProfScope ps(h->prof, "select", h->stream);
       GLOC_TRY(launch_slices<1>(h, d_q, nq, KC, first, n_range, ld, strideP, p.KS, sl, nullptr));
@@ -553,9 +547,9 @@ int run_mfma(gloc_knn* h, const float* d_q, int nq, int k, size_t first, int n_r
       h->dist.as<float>(), h->dev_trace.as<unsigned long long>()
     if (large)
       hipLaunchKernelGGL(select_rerank_kernel<true>, SRR_ARGS, h->klists.as<uint64_t>(), use_bmin ? SELB_LIST : sl.S * KC,
-                         use_bmin ? h->force_flags.as<int>() : (const int*)nullptr);
+                         use_bmin ? h->bmin.as<float>() : (const float*)nullptr, n_blocks, h->klists.as<uint64_t>());
     else
-      hipLaunchKernelGGL(select_rerank_kernel<false>, SRR_ARGS, (const uint64_t*)nullptr, 0, (const int*)nullptr);
+      hipLaunchKernelGGL(select_rerank_kernel<false>, SRR_ARGS, (const uint64_t*)nullptr, 0, (const float*)nullptr, 0, (uint64_t*)nullptr);
 #undef SRR_ARGS
     GLOC_HIP(hipGetLastError());
     // (incomplete queries -- rare -- are redone exactly by their own work-group inside the same launch: no
@@ -809,7 +803,6 @@ int gloc_knn_destroy(gloc_knn* h) {
   h->flags.release();
   h->redo_tickets.release();
   h->bmin.release();
-  h->force_flags.release();
   h->stage_q.release();
   h->stage_idx.release();
   h->stage_d2.release();

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void mirror_rows_kernel(const float* __restric
 // wave's 32 x 32 accumulator), the minimum of  |d|^2 - 2 q.d  over the block's rows of the window -- the coarse distance
 // without the query's norm, which does not change an order.  The KC smallest coarse distances of the window lie in blocks
 // whose minimum is <= the KC-th smallest block minimum (that one is the minimum of KC distinct rows), so the selection that
-// follows reads 32 x KC partial dots per query instead of the window's (select_blocks_kernel): at 64 x 125 000, 1 MB instead
+// follows reads 32 x KC partial dots per query instead of the window's (select_blocks_body): at 64 x 125 000, 1 MB instead
 // of 32 MB, one launch of 9 us instead of the slices' 28 - 34.
 template <int NT, bool QRAW, bool BMIN = false>
 __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __restrict__ mirror,
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __r
                                                                 float* __restrict__ P, int dim, size_t first_row, int n_range,
                                                                 int nq, int k_per_split, size_t ldP, size_t strideP,
                                                                 const float* __restrict__ dn = nullptr /* BMIN: the rows' norms */,
-                                                                float* __restrict__ bmin = nullptr /* BMIN: [nq][n_blocks] */,
+                                                                float* __restrict__ bmin = nullptr /* BMIN: [n_blocks][nq] */,
                                                                 int n_blocks = 0) {
   constexpr int KO = 4;
   constexpr int BQ = 64;
@@ -1049,7 +1049,8 @@ __global__ __launch_bounds__(256) void dist_bf16x3_tiled_kernel(const u32x4* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qq = q0 + wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (qq < nq) bmin[(size_t)qq * n_blocks + b] = v[r];
+          if (qq < nq) bmin[(size_t)b * nq + qq] = v[r];  // block-major: a block's 64 queries are 256 contiguous bytes (query-major:
+                                                           // 250 000 scattered 4-byte writes a launch, each a partial line)
         }
       }
     }
@@ -1501,34 +1502,34 @@ __global__ __launch_bounds__(SELQ_THREADS) void flagged_redo_kernel(
 // one work-group per query finds the KC smallest block minima, takes EVERY block whose minimum is <= the KC-th (ties
 // included; more than SELB_MAX_BLOCKS of them: the query is flagged for the exact redo), and writes the coarse keys of
 // those blocks' rows -- (|q|^2 + |d|^2) - 2 q.d exactly as selq_select<1> forms them -- as a list of 32 x SELB_MAX_BLOCKS
-// ready keys for select_rerank_kernel<true>.  Replaces select_slices_kernel<1> there (which read the whole window again).
+// ready keys for the selection + re-rank that follows.  Replaces select_slices_kernel<1> there (which read the whole window again).
 constexpr int SELB_MAX_BLOCKS = 64;
 constexpr int SELB_LIST = 32 * SELB_MAX_BLOCKS;
-__global__ __launch_bounds__(SELQ_THREADS) void select_blocks_kernel(
-    const float* __restrict__ bmin /* [nq][NB] */, int NB, const float* __restrict__ P, size_t ld, const float* __restrict__ queries,
-    int dim, const float* __restrict__ dn, size_t first_row, int n_range, int KC, uint64_t* __restrict__ lists /* [nq][SELB_LIST] */,
-    int* __restrict__ force_flag /* [nq] */) {
-  __shared__ uint64_t buf[SEL_LIST];
-  __shared__ float qred[SELQ_THREADS / 64];
-  __shared__ uint64_t tau_s;
-  __shared__ int cnt;
-  __shared__ int blk[SELB_MAX_BLOCKS];
-  __shared__ int nblk;
+// (A device function of select_rerank_kernel<true> since the same round: as a kernel of its own it cost a launch floor and a
+// round trip of the list through memory -- 14.3 + 27.1 us in two launches against ~36 in one.)  Returns whether more blocks
+// tied at the threshold than the list holds (uniform over the work-group); ends with a barrier.
+__device__ __forceinline__ bool select_blocks_body(const float* __restrict__ bq /* this query's block minima: bq[b * es] */, size_t es, int NB,
+                                                   const float* __restrict__ Pq /* this query's partial dots */,
+                                                   const float* __restrict__ qp, int dim, const float* __restrict__ dn,
+                                                   size_t first_row, int n_range, int KC, uint64_t* __restrict__ out /* [SELB_LIST] */,
+                                                   uint64_t* buf, float* qred, uint64_t* tau_s, int* cnt, int* blk /* [SELB_MAX_BLOCKS] */,
+                                                   int* nblk, float* smin /* LDS scratch, >= NB floats */) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int q = blockIdx.x;
-  const float* qp = queries + (size_t)q * dim;
-  const float* bq = bmin + (size_t)q * NB;
+  // the query's minima are es floats apart in memory ([block][query]: the coarse kernel writes whole lines that way): ONE
+  // strided pass into LDS, the selection and the second look at them from there (two strided passes: +4 us)
+  for (int b = tid; b < NB; b += SELQ_THREADS) smin[b] = bq[(size_t)b * es];
+  __syncthreads();
   // the KC-th smallest block minimum (fewer blocks than KC: the last one).  (A cheaper bound from above -- each full wave's
   // m-th smallest thread minimum, their maximum -- was tried: it lets ~100 blocks through, more than the list holds, and the
   // exact selection had to run behind it most of the time: 14.9 -> 17.8 us.)
-  selq_select<0>(bq, 0, 1, qp, dim, nullptr, 0, NB, KC, buf, qred, &tau_s, &cnt);
+  selq_select<0>(smin, 0, 1, qp, dim, nullptr, 0, NB, KC, buf, qred, tau_s, cnt);
   const int kk = NB < KC ? NB : KC;
   const uint32_t tau_ord = (uint32_t)(buf[kk - 1] >> 32);
-  if (tid == 0) nblk = 0;
+  if (tid == 0) *nblk = 0;
   __syncthreads();
   for (int b = tid; b < NB; b += SELQ_THREADS)
-    if (f2ord(bq[b]) <= tau_ord) {
-      const int pos = atomicAdd(&nblk, 1);
+    if (f2ord(smin[b]) <= tau_ord) {
+      const int pos = atomicAdd(nblk, 1);
       if (pos < SELB_MAX_BLOCKS) blk[pos] = b;
     }
   // the query's norm, summed as selq_select sums it (the same bits in every kernel that forms it)
@@ -1539,11 +1540,9 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_blocks_kernel(
   __syncthreads();
   float qnv = 0.f;
   for (int i = 0; i < SELQ_THREADS / 64; ++i) qnv += qred[i];
-  const int nb = nblk < SELB_MAX_BLOCKS ? nblk : SELB_MAX_BLOCKS;
-  if (tid == 0) force_flag[q] = nblk > SELB_MAX_BLOCKS ? 1 : 0;
+  const int n_found = *nblk;
+  const int nb = n_found < SELB_MAX_BLOCKS ? n_found : SELB_MAX_BLOCKS;
   const long long off = (long long)(first_row % MIR_ROWS);
-  const float* Pq = P + (size_t)q * ld;
-  uint64_t* out = lists + (size_t)q * SELB_LIST;
   for (int i = tid; i < SELB_LIST; i += SELQ_THREADS) {
     uint64_t key = KEY_SENTINEL;
     const int bi = i >> 5;
@@ -1556,6 +1555,9 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_blocks_kernel(
     }
     out[i] = key;
   }
+  __threadfence_block();  // (the list is read back by other threads of this work-group: selq_select<2>)
+  __syncthreads();
+  return n_found > SELB_MAX_BLOCKS;
 }
 
 // in: [nq][nlists][K]; group g of `per_group` lists -> out [nq][ngroups][K].  grid (ngroups, nq).
@@ -1842,7 +1844,8 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     unsigned long long* __restrict__ n_incomplete, FinalOut fo, float* __restrict__ dist_scratch /* = P: row q of split 0 is this query's */,
     unsigned long long* __restrict__ dev_trace /* dev only: [nq][8] phase stamps, or null */,
     const uint64_t* __restrict__ lists = nullptr, int n_list = 0,
-    const int* __restrict__ force_incomplete = nullptr /* LISTS: queries whose lists are known to be short (select_blocks_kernel) */) {
+    const float* __restrict__ bmin = nullptr /* LISTS: != null -- the lists are made HERE from the coarse kernel's block minima [NB][nq] */,
+    int NB = 0, uint64_t* __restrict__ blist = nullptr /* [nq][SELB_LIST]: room for them */) {
   const unsigned long long t_start = dev_trace ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ uint64_t buf[SEL_LIST];
   __shared__ float qred[SELQ_THREADS / 64];
@@ -1855,10 +1858,22 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
   const int q = blockIdx.x;
   const float* qp = queries + (size_t)q * dim;
   float qnv;
-  if constexpr (LISTS)
-    qnv = selq_select<2>(reinterpret_cast<const float*>(lists + (size_t)q * n_list), 0, 1, qp, dim, dn, 0, n_list, KC, buf,
+  bool forced = false;  // (LISTS from block minima: more tied blocks than the list holds -- the query goes to the exact redo)
+  if constexpr (LISTS) {
+    __shared__ int blk[SELB_MAX_BLOCKS];
+    __shared__ int nblk;
+    const uint64_t* lq = lists + (size_t)q * n_list;
+    int nl = n_list;
+    if (bmin) {
+      uint64_t* mine = blist + (size_t)q * SELB_LIST;
+      forced = select_blocks_body(bmin + q, (size_t)gridDim.x, NB, P + (size_t)q * ld, qp, dim, dn, first_row, n_range, KC, mine, buf, qred,
+                                  &tau_s, &cnt, blk, &nblk, S);  // ([block][query]: gridDim.x = nq; S: the re-rank's scratch, free until then)
+      lq = mine;
+      nl = SELB_LIST;
+    }
+    qnv = selq_select<2>(reinterpret_cast<const float*>(lq), 0, 1, qp, dim, dn, 0, nl, KC, buf,
                          qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
-  else
+  } else
     qnv = selq_select<1>(P + (size_t)q * ld, strideP, n_splits, qp, dim, dn, first_row, n_range, KC, buf,
                          qred, &tau_s, &cnt, dev_trace ? dev_trace + q * 16 + 8 : nullptr);
   if (tid == 0) qn_out[q] = qnv;
@@ -1879,9 +1894,7 @@ __global__ __launch_bounds__(SELQ_THREADS) void select_rerank_kernel(
     m = __popcll(__builtin_amdgcn_ballot_w64(valid && dco <= theta));
     if (n_valid == KC && n_range > KC) complete = __shfl(dco, KC - 1) > theta;
   }
-  if constexpr (LISTS) {
-    if (force_incomplete && force_incomplete[q]) complete = false;  // (uniform: one value per query)
-  }
+  if (forced) complete = false;  // (uniform: one value per query)
   if (w == 0 && lane < SRR_KC) rows_s[lane] = valid ? (uint32_t)ck : 0u;
   __syncthreads();  // every wave has its candidates in registers: buf is free and takes the query
   float* qs = reinterpret_cast<float*>(buf);

@@ -1519,19 +1519,45 @@ __device__ __forceinline__ bool select_blocks_body(const float* __restrict__ bq 
   // strided pass into LDS, the selection and the second look at them from there (two strided passes: +4 us)
   for (int b = tid; b < NB; b += SELQ_THREADS) smin[b] = bq[(size_t)b * es];
   __syncthreads();
-  // the KC-th smallest block minimum (fewer blocks than KC: the last one).  (A cheaper bound from above -- each full wave's
-  // m-th smallest thread minimum, their maximum -- was tried: it lets ~100 blocks through, more than the list holds, and the
-  // exact selection had to run behind it most of the time: 14.9 -> 17.8 us.)
-  selq_select<0>(smin, 0, 1, qp, dim, nullptr, 0, NB, KC, buf, qred, tau_s, cnt);
-  const int kk = NB < KC ? NB : KC;
-  const uint32_t tau_ord = (uint32_t)(buf[kk - 1] >> 32);
-  if (tid == 0) *nblk = 0;
-  __syncthreads();
-  for (int b = tid; b < NB; b += SELQ_THREADS)
-    if (f2ord(smin[b]) <= tau_ord) {
-      const int pos = atomicAdd(nblk, 1);
-      if (pos < SELB_MAX_BLOCKS) blk[pos] = b;
+  // A threshold that is AT LEAST the KC-th smallest block minimum, and nearly always equal to it, without the full
+  // selection (its 16-wave tournament: 10 of this stage's 15 us): every thread's minimum over its blocks, each wave's FOUR
+  // smallest of those (one register sort), the KC-th smallest of the 64 (one more) -- 64 distinct blocks' values, so their
+  // KC-th smallest bounds the KC-th smallest of all from above, and it is the true one unless a wave holds more than four
+  // of the KC smallest.  (Each wave's m-th smallest and the MAXIMUM of those was tried first: sound, but ~100 blocks pass.)
+  // More blocks at or below it than the list holds (ties, or a loose bound): the exact KC-th smallest decides.
+  static_assert(SELQ_THREADS / 64 * 4 == 64, "four per wave: 64 values, one wave sorts them (KC <= 64)");
+  float mymin = __builtin_inff();
+  for (int b = tid; b < NB; b += SELQ_THREADS) mymin = fminf(mymin, smin[b]);
+  {
+    const uint64_t x = wave_sort_u64<true>(make_key(mymin, (uint32_t)tid), lane);
+    if (lane < 4) buf[w * 4 + lane] = x;
+    __syncthreads();
+    if (w == 0) {
+      const uint64_t y = wave_sort_u64<true>(buf[lane], lane);
+      if (lane == KC - 1) *tau_s = y;
     }
+    __syncthreads();
+  }
+  uint32_t tau_ord = (uint32_t)(*tau_s >> 32);
+  auto collect = [&]() {
+    if (tid == 0) *nblk = 0;
+    __syncthreads();
+    for (int b = tid; b < NB; b += SELQ_THREADS)
+      if (f2ord(smin[b]) <= tau_ord) {
+        const int pos = atomicAdd(nblk, 1);
+        if (pos < SELB_MAX_BLOCKS) blk[pos] = b;
+      }
+    __syncthreads();
+  };
+  collect();
+  if (*nblk > SELB_MAX_BLOCKS) {  // (uniform) the exact KC-th smallest block minimum (fewer blocks than KC: the last one)
+    __syncthreads();
+    selq_select<0>(smin, 0, 1, qp, dim, nullptr, 0, NB, KC, buf, qred, tau_s, cnt);
+    const int kk = NB < KC ? NB : KC;
+    tau_ord = (uint32_t)(buf[kk - 1] >> 32);
+    __syncthreads();
+    collect();
+  }
   // the query's norm, summed as selq_select sums it (the same bits in every kernel that forms it)
   float sq = 0.f;
   for (int d = tid; d < dim; d += SELQ_THREADS) sq += qp[d] * qp[d];

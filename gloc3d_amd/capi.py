@@ -18,6 +18,7 @@ ALGO_AUTO, ALGO_EXACT, ALGO_MFMA, ALGO_MFMA_FP32 = 0, 1, 2, 3   # include/gloc3d
 KNN_OPT_ALGO, KNN_OPT_CANDIDATES, KNN_OPT_PROFILE = 1, 2, 3
 REG_OPT_PROFILE, REG_OPT_NN_MODE, REG_OPT_NN_SRC_PER_LANE, REG_OPT_NN_JOB_GROUP, REG_OPT_TEMP_TARGET_INDEX = 1, 2, 3, 4, 5
 REG_OPT_NN_SPLIT_HELPERS, REG_OPT_NN_SPLIT_THRESH, REG_OPT_NN_SUB_JOBS, REG_OPT_NN_HEAVY_THRESH, REG_OPT_SUB_BATCHES = 6, 7, 8, 9, 10
+REG_OPT_NN_CHAIN = 11
 REG_NN_CULLED, REG_NN_EXHAUSTIVE = 0, 1
 NO_SCAN = 0xFFFFFFFF
 SIZE_MAX = C.c_size_t(-1).value
@@ -758,6 +759,22 @@ class Registrar:
         c, n = C.c_uint64(), C.c_uint64()
         check(lib().gloc_reg_nn_stats(self._h, C.byref(c), C.byref(n)))
         return c.value, n.value
+
+    def debug_chain(self):
+        """Test aid: (chained launches enqueued, chained launches that timed out) -- GLOC_REG_OPT_NN_CHAIN."""
+        f = lib().gloc_reg_debug_chain
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        n, t = C.c_uint64(), C.c_uint64()
+        check(f(self._h, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def debug_chain_stall(self, on):
+        """Test aid: make the chained launch's solvers wait for a wave that never comes (the bounded waits)."""
+        f = lib().gloc_reg_debug_chain_stall
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int]
+        check(f(self._h, 1 if on else 0))
 
     def debug_corr(self, job, n_src):
         """Test aid: correspondences of the last 1-NN pass of the last batch (caller's index space)."""

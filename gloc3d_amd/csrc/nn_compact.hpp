@@ -175,15 +175,217 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // WARM: every pass after a batch's first -- prev_corr holds the previous correspondences, and the cold start's code (a
 // search in the target's curve keys) is not in the kernel at all: measured, its mere presence cost the warm passes
 // -- 92 % of the 1-NN time -- 3 % (registers, code layout).
+// ---- the chained launch (NnChain, reg_kernels.hpp) -----------------------------------------------------------------
+// A bounded wait for *p >= need, by the whole wave (lane 0 polls).  false: a wait ran out somewhere (err is set).
+// FRESH: the word is at an address nobody reads before it can have its final value's predecessor written through -- the
+// first look is an ordinary load (served by the XCD's L2 to the 1 200 other waves of the job; a copy from before the
+// value was complete only sends the wave on to the loads past the caches).
+template <bool FRESH>
+__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t need, uint32_t* err) {
+  const int lane = threadIdx.x & 63;
+  uint32_t v = 0;
+  if constexpr (FRESH) {
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+    v = 0;
+  }
+  if (lane == 0) v = ld_u32<true>(p);
+  if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    __builtin_amdgcn_s_sleep(16);
+    uint32_t e = 0;
+    if (lane == 0) {
+      v = ld_u32<true>(p);
+      e = ld_u32<true>(err);
+    }
+    if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+    if (__builtin_amdgcn_readfirstlane(e) != 0u) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > NN_CHAIN_WAIT_TICKS) {
+      if (lane == 0) st_u32<true>(err, 1u);
+      return false;
+    }
+  }
+}
+
+// dev: a stamp of the 100 MHz clock in slot k of (pass, job) -- first / last writer as `mode` says
+__device__ __forceinline__ void chain_stamp(const NnChain& ch, uint32_t pass, uint32_t job, uint32_t n_jobs, int k, int mode /* 0 store, 1 min, 2 max */) {
+  if (ch.dbg && (threadIdx.x & 63) == 0) {
+    uint32_t* p = ch.dbg + ((size_t)pass * n_jobs + job) * 16 + k;
+    const uint32_t t = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (mode == 0) *p = t;
+    else if (mode == 1) atomicMin(p, t);
+    else atomicMax(p, t);
+  }
+}
+
+// everything this wave has stored or added is where the other XCDs see it (acknowledged), THEN the counter
+__device__ __forceinline__ uint32_t chain_arrive(uint32_t* counter) {
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("" ::: "memory");
+  uint32_t a = 0;
+  if ((threadIdx.x & 63) == 0) a = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_amdgcn_readfirstlane(a);
+}
+
+// Reducer r of a job (solve_kernel's wave r): the partials r * 64 + lane, + 1024, ... in that order, the xor butterfly,
+// the sub-sum stored; the reducer that arrives last adds the 16 sub-sums in order and solves -- the additions of
+// solve_kernel<0>, one for one.
+__device__ __forceinline__ void chain_reduce_solve(uint32_t job, uint32_t pass, uint32_t r, uint32_t n_jobs, const Job* __restrict__ jobs,
+                                                   CandState* states, const double* partials, uint32_t n_part, const NnChain& ch,
+                                                   double* ws /* LDS, this wave's */) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t cnt = jobs[job].n_groups;
+  const float* base = reinterpret_cast<const float*>(partials + (size_t)job * n_part * ACC_NV);
+  double v[ACC_NV];
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+  for (uint32_t g = r * 64u + (uint32_t)lane; g < cnt; g += SOLVE_THREADS) {
+    const unsigned long long* f2 = reinterpret_cast<const unsigned long long*>(base + (size_t)g * (2 * ACC_NV));
+    float f[WAVE_PARTIAL_FLOATS + 1];
+#pragma unroll
+    for (int i = 0; i < (WAVE_PARTIAL_FLOATS + 1) / 2; ++i) {
+      const unsigned long long t = ld_u64<true>(f2 + i);
+      f[2 * i] = __uint_as_float((uint32_t)t);
+      f[2 * i + 1] = __uint_as_float((uint32_t)(t >> 32));
+    }
+    add_wave_partial(f, v);
+  }
+  double* sub = ch.sub + ((size_t)job * NN_CHAIN_RED + r) * ACC_NV;
+#pragma unroll
+  for (int k = 0; k < ACC_NV; ++k) {
+    double x = v[k];
+    x += xor_lane<32>(x);
+    x += xor_lane<16>(x);
+    x += xor_lane<8>(x);
+    x += xor_lane<4>(x);
+    x += xor_lane<2>(x);
+    x += xor_lane<1>(x);
+    if (lane == 0) st_f64<true>(sub + k, x);
+  }
+  if (r == 0) chain_stamp(ch, pass, job, n_jobs, 5, 0);  // reducer 0 has stored its sub-sum
+  if (chain_arrive(ch.sdone + (size_t)pass * n_jobs + job) != NN_CHAIN_RED - 1u) return;
+  chain_stamp(ch, pass, job, n_jobs, 6, 0);  // the last reducer is in
+  // the 16 sub-sums in order, a lane per moment; the state's fp64 pose beside them (loads past the caches: all in flight together)
+  {
+    const double* all = ch.sub + (size_t)job * NN_CHAIN_RED * ACC_NV;
+    double acc = 0.0, td_in = 0.0;
+    uint32_t frozen = 0;
+    if (lane < ACC_NV) {
+      double x[NN_CHAIN_RED];
+#pragma unroll
+      for (uint32_t rr = 0; rr < NN_CHAIN_RED; ++rr) x[rr] = ld_f64<true>(all + (size_t)rr * ACC_NV + lane);
+#pragma unroll
+      for (uint32_t rr = 0; rr < NN_CHAIN_RED; ++rr) acc += x[rr];
+    } else if (lane < ACC_NV + 12) {
+      td_in = ld_f64<true>(&states[job].Td[lane - ACC_NV]);
+    } else if (lane == ACC_NV + 12) {
+      frozen = ld_u32<true>(reinterpret_cast<const uint32_t*>(&states[job].frozen));
+    }
+    if (lane < ACC_NV) ws[lane] = acc;
+    else if (lane < ACC_NV + 12) ws[lane] = td_in;
+    frozen = (uint32_t)__builtin_amdgcn_readlane((int)frozen, ACC_NV + 12);
+    __builtin_amdgcn_s_waitcnt(0);  // (the LDS stores before lane 0 reads them: one wave, in order -- the counter makes it explicit)
+    asm volatile("" ::: "memory");
+    chain_stamp(ch, pass, job, n_jobs, 7, 0);  // sums and pose loaded
+    // (the next pass's pose goes to its own address too: solve_compose's T_also -- a job whose pose does not change any
+    // more, frozen or short of correspondences, hands on the one it was given)
+    float* t_next = pass + 1u < ch.n_pass ? ch.Tp + ((size_t)(pass + 1u) * n_jobs + job) * NN_CHAIN_T_STRIDE : nullptr;
+    const float* t_now = pass ? ch.Tp + ((size_t)pass * n_jobs + job) * NN_CHAIN_T_STRIDE : states[job].Tf;
+    if (lane == 0) solve_compose<0, true, true>(ws, states + job, ws + ACC_NV, frozen, ws + ACC_NV + 12, t_next, t_now);
+    chain_stamp(ch, pass, job, n_jobs, 8, 0);  // solved
+  }
+  if (pass + 1u < ch.n_pass) (void)chain_arrive(ch.ready + ((size_t)(pass + 1u) * n_jobs + job) * NN_CHAIN_PAD);
+}
+
+// The plan of the job's NEXT pass by one wave: solve_kernel's planner, 64 groups at a time (the same table: first the
+// groups that get 4 or 8 waves, then those that get 2, each class in launch order).
+__device__ __forceinline__ void chain_plan(uint32_t job, uint32_t pass, uint32_t n_jobs, const Job* __restrict__ jobs, const NnSplit& sp,
+                                           uint32_t n_part, const NnChain& ch) {
+  const int lane = threadIdx.x & 63;
+  if (sp.hx) {
+    constexpr uint32_t REACH = 8 * SOLVE_THREADS;  // (solve_kernel's PLAN_TILES)
+    const uint32_t n_groups = jobs[job].n_groups, ng = n_groups < REACH ? n_groups : REACH;
+    uint32_t* work = sp.work + (size_t)job * n_part;
+    // (the tables of pass + 1, at their own addresses; behind the last pass nobody reads a plan: the batch's own arrays take it)
+    const bool last = pass + 1u >= ch.n_pass;
+    uint32_t* plan = (last ? sp.plan : ch.planp + (size_t)pass * n_jobs * n_part) + (size_t)job * n_part;
+    uint32_t* helper = (last ? sp.helper : ch.helperp + (size_t)pass * n_jobs * sp.hx) + (size_t)job * sp.hx;
+    // (the estimates of 1024 groups at a time, 16 loads a lane in flight together: one round trip a tile, not one per 64 groups)
+    uint32_t tot_h = 0, tot_gh = 0;
+    for (uint32_t t0 = 0; t0 < ng; t0 += SOLVE_THREADS) {
+      uint32_t wk[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t g = t0 + 64u * (uint32_t)c + (uint32_t)lane;
+        wk[c] = g < ng ? ld_u32<true>(work + g) : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t parts = nn_parts_for(wk[c], sp.thresh);  // (0 beyond ng: an estimate of 0)
+        const unsigned long long b4 = __ballot(parts == 4), b8 = __ballot(parts == 8);
+        tot_h += 4u * (uint32_t)__popcll(b4) + 8u * (uint32_t)__popcll(b8);
+        tot_gh += (uint32_t)__popcll(b4 | b8);
+      }
+    }
+    for (uint32_t e = (uint32_t)lane; e < sp.hx; e += 64) st_u32<true>(helper + e, NN_NO_HELPER);  // (slots nobody takes below)
+    __builtin_amdgcn_s_waitcnt(0);  // (before another lane's entry for the same slot)
+    asm volatile("" ::: "memory");
+    uint32_t run_h = 0, run_l = tot_h, run_gh = 0, run_gl = tot_gh;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t t0 = 0; t0 < ng; t0 += SOLVE_THREADS) {
+      uint32_t wk[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t g = t0 + 64u * (uint32_t)c + (uint32_t)lane;
+        wk[c] = g < ng ? ld_u32<true>(work + g) : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t g = t0 + 64u * (uint32_t)c + (uint32_t)lane;
+        const uint32_t parts = nn_parts_for(wk[c], sp.thresh);
+        if (g < ng) st_u32<true>(work + g, 0u);  // consumed
+        const unsigned long long b2 = __ballot(parts == 2), b4 = __ballot(parts == 4), b8 = __ballot(parts == 8);
+        const uint32_t pre = parts >= 4 ? 4u * (uint32_t)__popcll(b4 & below) + 8u * (uint32_t)__popcll(b8 & below) : 2u * (uint32_t)__popcll(b2 & below);
+        const uint32_t gpre = parts >= 4 ? (uint32_t)__popcll((b4 | b8) & below) : (uint32_t)__popcll(b2 & below);
+        const uint32_t first = (parts >= 4 ? run_h : run_l) + pre, hid = (parts >= 4 ? run_gh : run_gl) + gpre;
+        if (g < ng) {
+          uint32_t word = 0;
+          if (parts > 1 && first + parts <= sp.hx) {  // (groups past the last slot keep their one wave at their own rank)
+            for (uint32_t p = 0; p < parts; ++p) st_u32<true>(helper + first + p, g | (p << 20) | (parts << 24));
+            word = (hid << 8) | parts;
+          }
+          st_u32<true>(plan + g, word);
+        }
+        run_h += 4u * (uint32_t)__popcll(b4) + 8u * (uint32_t)__popcll(b8);
+        run_l += 2u * (uint32_t)__popcll(b2);
+        run_gh += (uint32_t)__popcll(b4 | b8);
+        run_gl += (uint32_t)__popcll(b2);
+      }
+    }
+    for (uint32_t g = ng + (uint32_t)lane; g < n_groups; g += 64) st_u32<true>(plan + g, 0u);  // (beyond the planner's reach)
+  }
+  if (pass + 1u < ch.n_pass) (void)chain_arrive(ch.ready + ((size_t)(pass + 1u) * n_jobs + job) * NN_CHAIN_PAD);
+}
+
+
+struct NnPos {
+  uint32_t grp, slot, wgv;
+  uint32_t role = 0, pass = 0, job = 0;  // chained launch only: 0 a search wave; 1 + r: reducer r of `job`; 1 + NN_CHAIN_RED: its planner
+};
+
 template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false /* with the plan for heavy groups (NnSplit; sp.hx > 0) */,
-          bool WARM = false, bool HEAVY = false /* the second launch of a cold pass: the groups its waves gave up (NnHeavy) */>
+          bool WARM = false, bool HEAVY = false /* the second launch of a cold pass: the groups its waves gave up (NnHeavy) */,
+          bool CHAIN = false /* a pass of the chained launch (NnChain): what other waves of the SAME launch wrote or will read goes past the caches */>
 __device__ __forceinline__ void nn_compact_body(
+    const NnPos pos /* the work-group's place in the launch order of ONE pass: blockIdx of the plain launch */,
     const Job* __restrict__ jobs, uint32_t n_jobs, uint32_t job_group, uint32_t n_wg /* per slot */, uint32_t subs,
     const CandState* __restrict__ states,
     const uint32_t* prev_corr /* may alias corr; null: cold start */, uint32_t* corr, float* __restrict__ d2out,
     f32x4* __restrict__ pairs, double* __restrict__ partials /* [job][n_part][ACC_NV] */, uint32_t n_part,
     size_t ld, float gate2, NnSplit sp, NnHeavy hv, unsigned long long* __restrict__ stat_pairs /* [NN_STAT_SLOTS] pairs evaluated, or null */,
-    uint32_t* __restrict__ trace /* dev only: [wave][NN_TRACE_WORDS]: counts in words 0-7, cycles per region in 8-19 (tools/dev_nn_trace3.py) */) {
+    uint32_t* __restrict__ trace /* dev only: [wave][NN_TRACE_WORDS]: counts in words 0-7, cycles per region in 8-19 (tools/dev_nn_trace3.py) */,
+    const NnChain ch = NnChain{}) {
   constexpr int S = 64 * CS;        // sources per wave
   constexpr int NSB = CH / SB;      // sub-blocks per chunk
   // The staged chunk is kept as PAIRS of targets, structure-of-arrays: pair i of a sub-block is
@@ -216,6 +418,19 @@ __device__ __forceinline__ void nn_compact_body(
   __shared__ WaveLds lds_all[NN_WPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   WaveLds& L = lds_all[w];
+  if constexpr (CHAIN) {
+    // a role wave of the chained launch: its arrays live in this wave's (otherwise unused) staging area -- the solve has
+    // to fit the search's register budget
+    static_assert(sizeof(L.stage) >= 160 * sizeof(double), "the solve's workspace");
+    if (pos.role != 0u) {
+      if (pos.role <= NN_CHAIN_RED)
+        chain_reduce_solve(pos.job, pos.pass, pos.role - 1u, n_jobs, jobs, const_cast<CandState*>(states), partials, n_part, ch,
+                           reinterpret_cast<double*>(L.stage));
+      else
+        chain_plan(pos.job, pos.pass, n_jobs, jobs, sp, n_part, ch);
+      return;
+    }
+  }
   // blockIdx -> (job, work-group of the job).  The launch order walks `job_group` SLOTS at a time, slot fastest, and
   // work-groups go to the XCDs round-robin (XCD = blockIdx % 8, every XCD working through its own share independently):
   // with job_group a multiple of 8 a slot stays on one XCD.  A slot holds one job -- or, with `subs` > 1 (few jobs:
@@ -237,7 +452,7 @@ __device__ __forceinline__ void nn_compact_body(
     if (heavy_e >= (n_listed < hv.cap ? n_listed : hv.cap)) return;
     job = ((CPTR(uint32_t))hv.list)[2 * heavy_e];
   } else {
-    const uint32_t grp = blockIdx.z, slot = blockIdx.x, wgv = blockIdx.y;
+    const uint32_t grp = pos.grp, slot = pos.slot, wgv = pos.wgv;
     lin_block = slot + job_group * (wgv + n_wg * grp);
     uint32_t vin = slot;  // the virtual job of the slot, within the group
     if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
@@ -302,7 +517,11 @@ __device__ __forceinline__ void nn_compact_body(
   GPTR(f32x4) src4 = (GPTR(f32x4))J.src_pts;
   float T[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = states[job].Tf[i];
+  for (int i = 0; i < 12; ++i) {
+    // (chained: the pose of THIS pass at an address nobody has read before its solve wrote it -- an ordinary load)
+    if constexpr (CHAIN) T[i] = pos.pass ? ((CPTR(float))ch.Tp)[((size_t)pos.pass * n_jobs + job) * NN_CHAIN_T_STRIDE + i] : states[job].Tf[i];
+    else T[i] = states[job].Tf[i];
+  }
 
   const uint32_t wave_base = ((CPTR(uint32_t))J.src_order)[gi] * S;
   if constexpr (SPLIT && !HEAVY) {
@@ -1017,7 +1236,7 @@ __device__ __forceinline__ void nn_compact_body(
   if (SPLIT && lane == 0 && (!HEAVY || sp.work != nullptr)) {
     const uint32_t wk = (part == 0 ? NN_W_FIXED : 0u) + NN_W_CAND * w_cand + NN_W_CHUNK * n_processed + NN_W_ITEM * (uint32_t)n_items;
     uint32_t* wp = sp.work + (size_t)job * n_part + gi;
-    if (parts == 1) *wp = wk; else atomicAdd(wp, wk);  // (the planner left a zero)
+    if (parts == 1) st_u32<CHAIN>(wp, wk); else atomicAdd(wp, wk);  // (the planner left a zero)
   }
   const unsigned long long t_sweep = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -1158,13 +1377,13 @@ __device__ __forceinline__ void nn_compact_body(
 #pragma unroll
     for (int s = 0; s < CS; ++s) {
       const unsigned long long k = __hip_atomic_load(sk + s * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sk[s * 64 + lane] = ~0ull;  // as the next pass expects it
+      st_u64<CHAIN>(sk + s * 64 + lane, ~0ull);  // as the next pass expects it
       if (k != ~0ull) {
         best[s] = __uint_as_float((uint32_t)(k >> 32));
         bpos[s] = ix.inv[(uint32_t)k];
       }
     }
-    if (lane == 0) *tick = 0u;
+    if (lane == 0) st_u32<CHAIN>(tick, 0u);
   }
   const unsigned long long t_tie = now();
   NN_MARK("outputs");
@@ -1187,8 +1406,8 @@ __device__ __forceinline__ void nn_compact_body(
   for (int s = 0; s < CS; ++s) {
     if (!valid[s]) continue;
     const size_t o = (size_t)job * ld + wave_base + s * 64 + lane;
-    corr[o] = bpos[s];
-    d2out[o] = best[s];
+    st_u32<CHAIN>(corr + o, bpos[s]);  // (chained: written through -- the group's next pass may run on another XCD)
+    st_f32<CHAIN>(d2out + o, best[s]);
     f32x4 q = {NN_FAR, NN_FAR, NN_FAR, 0.f};  // no correspondence (empty target): never an inlier
     if (bpos[s] != 0xFFFFFFFFu) {
       q = ix.pts[bpos[s]];  // just loaded above: an L1 hit
@@ -1250,14 +1469,14 @@ __device__ __forceinline__ void nn_compact_body(
     y += xor_lane<4>(y);
     y += xor_lane<2>(y);
     y += xor_lane<1>(y);
-    if ((lane & 3) == 0) out[(lane >> 2) & 15] = x;
+    if ((lane & 3) == 0) st_f32<CHAIN>(out + ((lane >> 2) & 15), x);
     if (lane == 0) {
-      out[16] = y;
-      out[17] = cen[0];
-      out[18] = cen[1];
-      out[19] = cen[2];
+      st_f32<CHAIN>(out + 16, y);
+      st_f32<CHAIN>(out + 17, cen[0]);
+      st_f32<CHAIN>(out + 18, cen[1]);
+      st_f32<CHAIN>(out + 19, cen[2]);
     }
-    if (lane == 32) out[20] = y;
+    if (lane == 32) st_f32<CHAIN>(out + 20, y);
   }
   NN_MARK("end");
   if (TRACE && trace && lane == 0) {
@@ -1305,13 +1524,13 @@ __device__ __forceinline__ void nn_compact_body(
 
 template <int CS, bool PAIRS, bool TRACE = false, bool SPLIT = false, bool WARM = false>
 __global__ __launch_bounds__(64 * NN_WPB) void nn_compact_kernel(NN_COMPACT_PARAMS) {
-  nn_compact_body<CS, PAIRS, TRACE, SPLIT, WARM>(NN_COMPACT_ARGS);
+  nn_compact_body<CS, PAIRS, TRACE, SPLIT, WARM>(NnPos{blockIdx.z, blockIdx.x, blockIdx.y}, NN_COMPACT_ARGS);
 }
 
 // The second launch of a cold pass: the groups its waves gave up, NN_HEAVY_PARTS waves each (NnHeavy).
 template <int CS, bool PAIRS>
 __global__ __launch_bounds__(64) void nn_compact_heavy_kernel(NN_COMPACT_PARAMS) {
-  nn_compact_body<CS, PAIRS, false, true, false, true>(NN_COMPACT_ARGS);
+  nn_compact_body<CS, PAIRS, false, true, false, true>(NnPos{0u, 0u, 0u}, NN_COMPACT_ARGS);
 }
 
 // The warm moments pass with the split plan in it -- what one query alone runs 20 times -- held to the register budget
@@ -1319,7 +1538,53 @@ __global__ __launch_bounds__(64) void nn_compact_heavy_kernel(NN_COMPACT_PARAMS)
 // kernel fits by itself.
 template <int CS>
 __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void nn_compact_split_warm_kernel(NN_COMPACT_PARAMS) {
-  nn_compact_body<CS, false, false, true, true>(NN_COMPACT_ARGS);
+  nn_compact_body<CS, false, false, true, true>(NnPos{blockIdx.z, blockIdx.x, blockIdx.y}, NN_COMPACT_ARGS);
+}
+
+// All warm moments passes of a small batch in ONE launch (NnChain): a one-dimensional grid of n_pass x pass_size
+// single-wave work-groups; a pass is `groups` runs of [job_group * n_wg searches | the group's roles | padding to a
+// multiple of 8, so that a slot keeps its XCD from pass to pass].  Held to six waves per SIMD like the warm kernel it chains.
+template <int CS>
+__global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void nn_chain_kernel(NN_COMPACT_PARAMS, NnChain ch) {
+  static_assert(NN_WPB == 1, "a work-group is a wave: the roles and the arrival counts are per wave");
+  const uint32_t b = blockIdx.x;
+  const uint32_t pass = b / ch.pass_size, r1 = b - pass * ch.pass_size;
+  const uint32_t grp = r1 / ch.grp_size, r2 = r1 - grp * ch.grp_size;
+  const uint32_t n_search = job_group * n_wg;
+  if (r2 >= n_search) {  // a role of one of the group's jobs
+    const uint32_t si = r2 - n_search, jl = si / NN_CHAIN_ROLES, role = si - jl * NN_CHAIN_ROLES;
+    const uint32_t job = grp * ch.jobs_per_grp + jl;
+    if (jl >= ch.jobs_per_grp || job >= n_jobs) return;  // padding
+    if (role == 0) chain_stamp(ch, pass, job, n_jobs, 3, 0);  // reducer 0 starts to wait
+    if (!chain_wait<false>(ch.go + ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD, 1u, ch.err)) return;
+    if (role == 0) chain_stamp(ch, pass, job, n_jobs, 4, 0);  // ... and sees the pass done
+    nn_compact_body<CS, false, false, true, true, false, true>(NnPos{0u, 0u, 0u, 1u + role, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states,
+                                                                corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, hv, stat_pairs, trace, ch);
+    return;
+  }
+  const uint32_t wgv = r2 / job_group, slot = r2 - wgv * job_group;
+  // (the body's own decoding of the slot -- only the job is needed here)
+  uint32_t vin = slot;
+  if ((job_group & 7u) == 0u) vin = (slot & ~7u) | ((slot - (slot >> 3) - grp) & 7u);
+  const uint32_t vjob = grp * job_group + vin;
+  if (vjob >= n_jobs * subs) return;
+  const uint32_t job = vjob / subs;
+  const bool first_wave = wgv == 0u && (slot & 7u) == 0u;  // (dev stamps: one wave of the job's first row)
+  if (first_wave) chain_stamp(ch, pass, job, n_jobs, 0, 0);  // a first search wave of the job's pass here
+  const size_t cell = ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD;
+  NnSplit spp = sp;  // the pass's own plan and helpers' table (pass 0: the batch's, written by the launch before)
+  if (pass > 0u) {
+    if (!chain_wait<true>(ch.ready + cell, 2u, ch.err)) return;
+    spp.plan = ch.planp + (size_t)(pass - 1u) * n_jobs * n_part;
+    spp.helper = ch.helperp + (size_t)(pass - 1u) * n_jobs * sp.hx;
+  }
+  if (first_wave) chain_stamp(ch, pass, job, n_jobs, 1, 0);  // ... and past the wait
+  nn_compact_body<CS, false, false, true, true, false, true>(NnPos{grp, slot, wgv, 0u, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states, corr, corr,
+                                                              d2out, pairs, partials, n_part, ld, gate2, spp, hv, stat_pairs, trace, ch);
+  if (chain_arrive(ch.done + cell) == ch.expected - 1u) {
+    if ((threadIdx.x & 63) == 0) st_u32<true>(ch.go + cell, 1u);
+    chain_stamp(ch, pass, job, n_jobs, 2, 0);  // the last search wave of the job's pass has left
+  }
 }
 #undef NN_COMPACT_PARAMS
 #undef NN_COMPACT_ARGS

@@ -77,6 +77,18 @@ struct gloc_reg {
   hipStream_t sub_stream[MAX_SUB - 1] = {};
   hipEvent_t fork_ev = nullptr, join_ev[MAX_SUB - 1] = {};
   std::atomic<uint64_t> nn_launches{0};
+  // the warm passes of a small batch chained in one launch (NnChain): 1 on (default), 0 off; stopped for good on a handle
+  // whose chain once ran out of time
+  int nn_chain = 1;
+  bool chain_broken = false;
+  bool chain_trace = false;       // dev (gloc_reg_debug_chain_trace): stamps per (pass, job)
+  DevBuf chain_dbg;
+  uint32_t chain_dbg_pass = 0, chain_dbg_jobs = 0;
+  bool chain_stall = false;       // test aid (gloc_reg_debug_chain_stall): the solvers wait for one wave more than there is
+  DevBuf chain_buf;               // [ready | done | sdone | err] then the reducers' sub-sums
+  uint32_t* h_chain_err = nullptr; // pinned: the batch's err word, copied behind the states
+  bool chain_in_batch = false;    // the batch enqueued last ran a chained launch
+  std::atomic<uint64_t> chain_launches{0}, chain_timeouts{0};
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
   Profiler prof;
@@ -308,8 +320,78 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, const WsView& v, bool warm, bool
   return GLOC_OK;
 }
 
+// The remaining warm moments passes of a small batch -- search, reduce, solve, plan, `n_pass` times -- in ONE launch
+// (NnChain, reg_kernels.hpp; nn_chain_kernel, nn_compact.hpp).  0 passes: the batch does not qualify (the caller goes on
+// launch by launch).
+uint32_t chain_passes(const gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t remaining) {
+  static const bool off = getenv("GLOC3D_NN_NO_CHAIN") != nullptr;  // developer switch
+  if (off || !h->nn_chain || h->chain_broken || h->nn_mode == 1 || h->nn_src_per_lane != 2 || !v.split.hx || h->trace_on ||
+      h->prof.enabled || remaining < 2 || NN_WPB != 1)
+    return 0;
+  const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
+  const uint32_t jg = (uint32_t)h->nn_job_group;
+  if (subs < 2 || (jg & 7u) || jg % subs) return 0;  // (small batches: the shares of a job fill a row of slots)
+  if ((bd.n_part & 31u) || (v.split.hx & 31u)) return 0;  // (a job's rows of the per-pass tables are whole cache lines)
+  const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
+  const uint32_t groups = (v.n_jobs * subs + jg - 1) / jg;
+  const uint64_t grp_size = ((uint64_t)jg * n_wg + (jg / subs) * NN_CHAIN_ROLES + 7) & ~7ull;
+  if (grp_size * groups * remaining >= (1ull << 31)) return 0;
+  return remaining;
+}
+
+int launch_nn_chain(gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t n_pass, float gate2) {
+  const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
+  const uint32_t jg = (uint32_t)h->nn_job_group;
+  const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
+  const uint32_t groups = (v.n_jobs * subs + jg - 1) / jg;
+  NnChain ch{};
+  ch.n_pass = n_pass;
+  ch.expected = subs * n_wg * NN_WPB + (h->chain_stall ? 1u : 0u);
+  ch.jobs_per_grp = jg / subs;
+  ch.grp_size = (jg * n_wg + ch.jobs_per_grp * NN_CHAIN_ROLES + 7u) & ~7u;
+  ch.pass_size = ch.grp_size * groups;
+  // [ready | done | go | sdone] a 256-byte line per (pass, job), the err word's line; then (never cleared: written before
+  // read) the per-pass poses, plans and helpers' tables, the reducers' sub-sums
+  const size_t cells = (size_t)n_pass * v.n_jobs, line = NN_CHAIN_PAD * 4;
+  const size_t head = (4 * cells + 1) * line;
+  const size_t t_bytes = cells * NN_CHAIN_T_STRIDE * 4;
+  const size_t plan_bytes = (size_t)(n_pass - 1) * v.n_jobs * bd.n_part * 4, help_bytes = (size_t)(n_pass - 1) * v.n_jobs * v.split.hx * 4;
+  const size_t sub_bytes = sizeof(double) * ACC_NV * NN_CHAIN_RED * v.n_jobs;
+  GLOC_TRY(h->chain_buf.ensure(head + t_bytes + plan_bytes + help_bytes + sub_bytes + 256, v.s));
+  GLOC_HIP(hipMemsetAsync(h->chain_buf.p, 0, head, v.s));
+  char* base = h->chain_buf.as<char>();
+  ch.ready = reinterpret_cast<uint32_t*>(base);
+  ch.done = reinterpret_cast<uint32_t*>(base + cells * line);
+  ch.go = reinterpret_cast<uint32_t*>(base + 2 * cells * line);
+  ch.sdone = reinterpret_cast<uint32_t*>(base + 3 * cells * line);
+  ch.err = reinterpret_cast<uint32_t*>(base + 4 * cells * line);
+  ch.Tp = reinterpret_cast<float*>(base + head);
+  ch.planp = reinterpret_cast<uint32_t*>(base + head + t_bytes);
+  ch.helperp = reinterpret_cast<uint32_t*>(base + head + t_bytes + plan_bytes);
+  ch.sub = reinterpret_cast<double*>(base + head + t_bytes + plan_bytes + help_bytes);
+  if (h->chain_trace) {
+    const size_t nb = (size_t)n_pass * v.n_jobs * 16 * 4;
+    GLOC_TRY(h->chain_dbg.ensure(nb, v.s));
+    GLOC_HIP(hipMemsetAsync(h->chain_dbg.p, 0, nb, v.s));
+    for (uint32_t q = 0; q < n_pass * v.n_jobs; ++q)  // (slots 0 and 1 take a minimum)
+      GLOC_HIP(hipMemsetAsync(h->chain_dbg.as<uint32_t>() + (size_t)q * 16, 0xFF, 8, v.s));
+    ch.dbg = h->chain_dbg.as<uint32_t>();
+    h->chain_dbg_pass = n_pass;
+    h->chain_dbg_jobs = v.n_jobs;
+  }
+  h->nn_launches += n_pass;
+  h->chain_launches++;
+  h->chain_in_batch = true;
+  hipLaunchKernelGGL((nn_chain_kernel<2>), dim3(ch.pass_size * n_pass), dim3(64 * NN_WPB), 0, v.s, v.jobs, v.n_jobs, jg, n_wg, subs,
+                     v.states, v.corr, v.corr, v.d2, v.pairs, v.partials, bd.n_part, bd.ld, gate2, v.split, NnHeavy{},
+                     (unsigned long long*)nullptr, (uint32_t*)nullptr, ch);
+  GLOC_HIP(hipGetLastError());
+  GLOC_HIP(hipMemcpyAsync(h->h_chain_err, ch.err, 4, hipMemcpyDeviceToHost, v.s));
+  return GLOC_OK;
+}
+
 int ensure_pinned(gloc_reg* h, uint32_t n_jobs) {
-  const size_t need = (sizeof(CandState) + sizeof(Job)) * (size_t)n_jobs;
+  const size_t need = (sizeof(CandState) + sizeof(Job)) * (size_t)n_jobs + 64;
   if (need > h->pin_cap) {
     if (h->pin) (void)hipHostFree(h->pin);
     h->pin = nullptr;
@@ -320,6 +402,7 @@ int ensure_pinned(gloc_reg* h, uint32_t n_jobs) {
   }
   h->h_states = reinterpret_cast<CandState*>(h->pin);
   h->h_jobs = reinterpret_cast<Job*>(h->h_states + n_jobs);
+  h->h_chain_err = reinterpret_cast<uint32_t*>(h->h_jobs + n_jobs);
   return GLOC_OK;
 }
 
@@ -409,6 +492,13 @@ int enqueue_pipeline(gloc_reg* h, const BatchDims& bd, const gloc_reg_params* pr
     }
   }
   for (uint32_t it = 0; it < prm->icp_iters && can && any_tgt; ++it) {
+    if (have_corr && v.job0 == 0 && v.n_jobs == bd.n_jobs) {
+      const uint32_t n_chain = chain_passes(h, bd, v, prm->icp_iters - it);
+      if (n_chain) {  // a small batch: all the passes that are left in one launch
+        GLOC_TRY(launch_nn_chain(h, bd, v, n_chain, gate2));
+        break;
+      }
+    }
     GLOC_TRY(launch_nn(h, bd, v, have_corr, false, gate2));
     have_corr = true;
     if (!culled) {
@@ -436,6 +526,8 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
   const int cs = h->nn_src_per_lane;
   BatchDims bd{n_jobs, 0, 0, 0, 0};
   GLOC_TRY(ensure_pinned(h, n_jobs));
+  h->chain_in_batch = false;
+  *h->h_chain_err = 0u;
   Job* jd = h->h_jobs;
   bool can = false, any_tgt = false;
   for (uint32_t c = 0; c < n_jobs; ++c) {
@@ -448,7 +540,7 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
     any_tgt |= t.n >= 1;
   }
   const uint32_t nblocks = (bd.max_src + ACC_PER_BLOCK - 1) / ACC_PER_BLOCK;
-  bd.n_part = std::max<uint32_t>(std::max(bd.max_groups, nblocks), 1);
+  bd.n_part = (std::max<uint32_t>(std::max(bd.max_groups, nblocks), 1) + 31u) & ~31u;  // (a job's row of a [job][n_part] table: whole 128-byte lines)
   bd.ld = ((size_t)bd.max_src + 127) & ~(size_t)127;
   h->last_ld = bd.ld;
   h->last_jobs = n_jobs;
@@ -573,6 +665,15 @@ int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max
   h->last_final_step.assign(n_jobs, 0.f);
   if (n_jobs == 0) return GLOC_OK;
   GLOC_HIP(hipEventSynchronize(h->done_ev));
+  if (h->chain_in_batch && *h->h_chain_err) {
+    // a wait inside the chained launch ran out (NN_CHAIN_WAIT_TICKS): its waves left without finishing the passes -- the
+    // poses are not results.  Reported, and the handle goes back to one launch per pass for good.
+    h->chain_broken = true;
+    h->chain_timeouts++;
+    set_err("the chained ICP passes of a batch of %u jobs timed out on the device (a wait for a job's solve ran out); "
+            "this handle now launches pass by pass -- run the batch again", n_jobs);
+    return GLOC_ERR_HIP;
+  }
   static const bool heavy_dbg = getenv("GLOC3D_NN_HEAVY_DEBUG") != nullptr;  // developer switch: the length of the last cold pass's list
   if (heavy_dbg && h->heavy_of[0].cap) {
     uint32_t cnt = 0;
@@ -807,6 +908,12 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_SUB_BATCHES) {
     GLOC_REQUIRE(value >= -1 && value <= (int64_t)gloc_reg::MAX_SUB, GLOC_ERR_INVALID, "must be in [-1, %u]", gloc_reg::MAX_SUB);
     h->sub_batches = (int)value;
+    return GLOC_OK;
+  }
+  if (option == GLOC_REG_OPT_NN_CHAIN) {
+    GLOC_REQUIRE(value == 0 || value == 1, GLOC_ERR_INVALID, "must be 0 or 1");
+    h->nn_chain = (int)value;
+    if (value) h->chain_broken = false;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_HEAVY_THRESH) {
@@ -1245,6 +1352,39 @@ int gloc_reg_debug_corr(gloc_reg* h, uint32_t job, uint32_t n_src, uint32_t* out
   GLOC_HIP(hipMemcpyAsync(out_d2, h->export_d2.as<float>() + (size_t)job * ld, sizeof(float) * n_src,
                           hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipStreamSynchronize(s));
+  return GLOC_OK;
+}
+
+// Developer / test aid (not part of include/gloc3d.h): chained launches enqueued and chained launches that timed out.
+int gloc_reg_debug_chain(gloc_reg* h, uint64_t* launches, uint64_t* timeouts) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  if (launches) *launches = h->chain_launches;
+  if (timeouts) *timeouts = h->chain_timeouts;
+  return GLOC_OK;
+}
+
+// Developer aid (not part of include/gloc3d.h): stamps of the last chained launch, [pass][job][16] words of the 100 MHz clock
+// (tools/dev_chain_trace.py): 0 first search wave arrives, 1 first one past its wait, 2 last one leaves, 3 reducer 0 starts
+// to wait, 4 sees the pass done, 5 has stored its sub-sum, 6 last reducer in, 7 sums loaded, 8 solved.
+int gloc_reg_debug_chain_trace(gloc_reg* h, int enable, uint32_t* out, size_t cap_words, uint32_t* n_pass, uint32_t* n_jobs) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  GLOC_HIP(hipSetDevice(h->device));
+  h->chain_trace = enable != 0;
+  if (n_pass) *n_pass = h->chain_dbg_pass;
+  if (n_jobs) *n_jobs = h->chain_dbg_jobs;
+  if (out && h->chain_dbg.p) {
+    const size_t n = std::min(cap_words, (size_t)h->chain_dbg_pass * h->chain_dbg_jobs * 16);
+    GLOC_HIP(hipStreamSynchronize(h->stream));
+    GLOC_HIP(hipMemcpy(out, h->chain_dbg.p, n * 4, hipMemcpyDeviceToHost));
+  }
+  return GLOC_OK;
+}
+
+// Test aid (not part of include/gloc3d.h): the next chained launches wait for a wave that never comes -- every wait runs
+// out, the launch ends by itself, the batch fails (tests/test_reg_gpu.py: the bounded waits).
+int gloc_reg_debug_chain_stall(gloc_reg* h, int on) {
+  GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
+  h->chain_stall = on != 0;
   return GLOC_OK;
 }
 

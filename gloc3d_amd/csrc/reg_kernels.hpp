@@ -85,6 +85,52 @@ struct NnHeavy {
   uint32_t thresh;            // processed chunks at which a wave gives up
 };
 constexpr uint32_t NN_HEAVY_PARTS = 8;
+// Round 6, late -- the ICP passes of a SMALL batch CHAINED in one launch (nn_chain_kernel, nn_compact.hpp).  One query
+// alone is 20 jobs x 21 passes: 21 x (a search launch of 19 380 waves over 6 144 slots that ramps up, drains and waits for
+// its slowest wave, + a solve launch with the chip idle) = 121 + 14 us per pass where the waves themselves need ~80.  The
+// jobs of a batch never depend on each other, only job j's pass p + 1 on job j's solve of pass p.  The chained launch is
+// the grid of ALL warm passes laid end to end -- pass-major, inside a pass the launch order of one pass, and behind
+// every group of jobs the few waves that reduce its moments, solve and plan ("roles") -- and a wave of pass p + 1
+// waits at its head until its job's pass p has been solved and planned (`ready`).  Work-groups of a launch are handed
+// out in index order (per XCD, each XCD walking its own eighth), and everything a wave waits for has a smaller index:
+// the wave with the smallest unfinished index never waits for anything unfinished, so the launch always advances, and
+// while one job's solve is under way the other jobs' waves fill the chip.  No host round trip, no launch boundary, no
+// ramp: the chip stays full from the first pass to the last.
+// What crosses from one wave to another inside the launch goes past the XCDs' caches (relaxed device-scope atomics:
+// T, the plan, the helpers' table, the work estimates, the fold keys and tickets, the moments; corr and d2 are written
+// through so that no XCD keeps a stale dirty line for the end of the launch) -- never a cache write-back.  A warm wave
+// that reads an OLDER pass's correspondence for its bound (a line its XCD still holds) searches from a looser, still valid,
+// bound: same bits.  Every wait is bounded (NN_CHAIN_WAIT_TICKS of the 100 MHz clock): a wave that runs out sets `err`,
+// every waiting wave leaves when it sees it, and the host reports the batch as failed and stops chaining on the handle.
+// Hot spots (measured, the first version: 21 ms for one query where launch by launch takes 3.2): 1 225 waves per job and
+// pass reading the SAME pose / plan / flag words past the caches are served one after the other where the line lives
+// (~50 ns each: 1 ms per pass), and counters of different jobs in one line serialise the jobs.  Hence: whatever a pass's
+// waves read lives at an address of ITS OWN per pass (pose, plan, helpers' table, the ready flag), written through
+// before the flag, and nobody reads it before that -- an ORDINARY load then finds no stale copy anywhere and the XCD's L2
+// serves the other 1 200 waves; only a wave that finds the flag not yet set polls past the caches.  Every counter and
+// flag has a 256-byte line to itself.
+struct NnChain {
+  uint32_t* ready;   // [pass][job] x NN_CHAIN_PAD: 2 when the pass before has been solved and planned for the job (pass 0: never read)
+  uint32_t* done;    // [pass][job] x NN_CHAIN_PAD: search waves of the pass that have left
+  uint32_t* go;      // [pass][job] x NN_CHAIN_PAD: set by the last of them (what the role waves poll: not the counters' line)
+  uint32_t* sdone;   // [pass][job] x NN_CHAIN_PAD: reducer waves that have stored their sub-sums
+  float* Tp;         // [pass][job][NN_CHAIN_T_STRIDE]: the pose the pass's waves move the sources by (pass 0: the state's)
+  uint32_t* planp;   // [pass - 1][job][n_part]: NnSplit::plan of passes 1 .. (pass 0: the batch's own)
+  uint32_t* helperp; // [pass - 1][job][hx]: NnSplit::helper of passes 1 ..
+  double* sub;       // [job][NN_CHAIN_RED][ACC_NV]: the reducers' sub-sums of the moments (solve_kernel's sub[][])
+  uint32_t* err;     // != 0: a wait ran out
+  uint32_t* dbg;     // dev (gloc_reg_debug_chain_trace): [pass][job][16] stamps of the 100 MHz clock, or null
+  uint32_t n_pass;
+  uint32_t expected;      // search waves per job and pass
+  uint32_t jobs_per_grp;  // jobs of a group of slots (job_group / subs)
+  uint32_t grp_size;      // work-groups of a group in one pass: job_group * n_wg searches + the roles, padded to a multiple of 8
+  uint32_t pass_size;     // work-groups of a pass
+};
+constexpr uint32_t NN_CHAIN_PAD = 64;        // words between two counters / flags (256 B)
+constexpr uint32_t NN_CHAIN_T_STRIDE = 32;   // floats per (pass, job) pose slot (128 B: a line of its own)
+constexpr uint32_t NN_CHAIN_RED = 16;                  // reducer waves per job: solve_kernel's 16 waves, one each
+constexpr uint32_t NN_CHAIN_ROLES = NN_CHAIN_RED + 1;  // + the planner
+constexpr unsigned long long NN_CHAIN_WAIT_TICKS = 100000000ull;  // 1 s of the 100 MHz clock
 constexpr uint32_t NN_NO_HELPER = 0xFFFFFFFFu;
 constexpr uint32_t NN_MAX_PARTS = 8;
 // the estimate, from the trace's regression of wave cycles on its counts (tools/dev_nn_trace3.py)
@@ -249,9 +295,17 @@ __global__ void export_corr_kernel(const Job* __restrict__ jobs, const uint32_t*
   out_d2[(size_t)job * ld + o] = d2in[(size_t)job * ld + i];
 }
 
-__device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
-                                       const double qbar[3], double R[9], double t[3]) {
-  double A[9], V[9];
+// The small arrays of the fp64 solve: registers -- or, WS, a workspace the caller hands in (LDS: the chained launch's
+// solver waves run inside the search kernel's register budget, nn_compact.hpp).  Same operations either way.
+#define GLOC_WS_ARR(name, n)          \
+  double name##_priv[WS ? 1 : (n)];   \
+  double* const name = WS ? ws : name##_priv; \
+  if (WS) ws += (n)
+template <bool WS>
+__device__ inline void kabsch_from_cov_t(const double* M /* [9] */, const double* pbar /* [3] */,
+                                                  const double* qbar /* [3] */, double* R /* [9] */, double* t /* [3] */, double* ws) {
+  GLOC_WS_ARR(A, 9);
+  GLOC_WS_ARR(V, 9);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)
       A[3 * i + j] = (M[0 + i] * M[0 + j] + M[3 + i] * M[3 + j]) + M[6 + i] * M[6 + j];
@@ -262,11 +316,15 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
   if (l2 > l1) { int ti = o1; o1 = o2; o2 = ti; double td = l1; l1 = l2; l2 = td; }
   if (l1 > l0) { int ti = o0; o0 = o1; o1 = ti; double td = l0; l0 = l1; l1 = td; }
   (void)o2; (void)l2;
-  double v1[3] = {V[0 + o0], V[3 + o0], V[6 + o0]};
-  double v2[3] = {V[0 + o1], V[3 + o1], V[6 + o1]};
-  double v3[3];
+  GLOC_WS_ARR(v1, 3);
+  GLOC_WS_ARR(v2, 3);
+  GLOC_WS_ARR(v3, 3);
+  v1[0] = V[0 + o0]; v1[1] = V[3 + o0]; v1[2] = V[6 + o0];
+  v2[0] = V[0 + o1]; v2[1] = V[3 + o1]; v2[2] = V[6 + o1];
   cross3(v1, v2, v3);
-  double u1[3], u2[3], u3[3];
+  GLOC_WS_ARR(u1, 3);
+  GLOC_WS_ARR(u2, 3);
+  GLOC_WS_ARR(u3, 3);
   for (int i = 0; i < 3; ++i) {
     u1[i] = (M[3 * i + 0] * v1[0] + M[3 * i + 1] * v1[1]) + M[3 * i + 2] * v1[2];
     u2[i] = (M[3 * i + 0] * v2[0] + M[3 * i + 1] * v2[1]) + M[3 * i + 2] * v2[2];
@@ -282,7 +340,8 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
   for (int i = 0; i < 3; ++i) u2[i] = u2[i] - d12 * u1[i];
   double n2 = sqrt((u2[0] * u2[0] + u2[1] * u2[1]) + u2[2] * u2[2]);
   if (!(n2 > 1e-300)) {
-    double ax[3] = {0, 0, 0};
+    GLOC_WS_ARR(ax, 3);
+    ax[0] = 0; ax[1] = 0; ax[2] = 0;
     const double a0 = u1[0] < 0 ? -u1[0] : u1[0], a1 = u1[1] < 0 ? -u1[1] : u1[1],
                  a2 = u1[2] < 0 ? -u1[2] : u1[2];
     ax[(a0 <= a1 && a0 <= a2) ? 0 : ((a1 <= a2) ? 1 : 2)] = 1.0;
@@ -295,6 +354,9 @@ __device__ inline void kabsch_from_cov(const double M[9], const double pbar[3],
     for (int j = 0; j < 3; ++j) R[3 * i + j] = (v1[i] * u1[j] + v2[i] * u2[j]) + v3[i] * u3[j];
   for (int i = 0; i < 3; ++i)
     t[i] = qbar[i] - ((R[3 * i + 0] * pbar[0] + R[3 * i + 1] * pbar[1]) + R[3 * i + 2] * pbar[2]);
+}
+__device__ inline void kabsch_from_cov(const double M[9], const double pbar[3], const double qbar[3], double R[9], double t[3]) {
+  kabsch_from_cov_t<false>(M, pbar, qbar, R, t, nullptr);
 }
 
 // K5a.  One thread per (job, hypothesis).  pairs: [job][ld][2] float4 by sorted slot; the three
@@ -693,6 +755,152 @@ constexpr int SOLVE_R = 56;  // (56 x 18 moments = 1008 threads)
 constexpr int SOLVE_THREADS = 1024;
 static_assert(SOLVE_R * ACC_NV <= SOLVE_THREADS, "a thread per (stride class, moment)");
 
+// memory that every XCD sees without a cache write-back or invalidate: relaxed device-scope atomics (loads and stores
+// that go past the XCD's own L2) -- what the chained passes (NnChain, nn_compact.hpp) hand from one wave to another
+// INSIDE a launch; COH = false: ordinary loads and stores (data crosses a launch boundary)
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_u32(uint32_t* p, uint32_t v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ double ld_f64(const double* p) {
+  return __builtin_bit_cast(double, ld_u64<COH>(reinterpret_cast<const unsigned long long*>(p)));
+}
+template <bool COH>
+__device__ __forceinline__ void st_f64(double* p, double v) {
+  st_u64<COH>(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v));
+}
+template <bool COH>
+__device__ __forceinline__ float ld_f32(const float* p) {
+  return __uint_as_float(ld_u32<COH>(reinterpret_cast<const uint32_t*>(p)));
+}
+template <bool COH>
+__device__ __forceinline__ void st_f32(float* p, float v) {
+  st_u32<COH>(reinterpret_cast<uint32_t*>(p), __float_as_uint(v));
+}
+
+// One wave partial of the culled search (nn_compact.hpp: fp32 moments about the wave's own centre, the centre, sum |p'|^2)
+// added to raw fp64 moments: sum p q^T = sum p' q'^T + c sum q'^T + sum p' c^T + n c c^T, every product of two fp32
+// values exact in fp64.
+__device__ __forceinline__ void add_wave_partial(const float* f /* [WAVE_PARTIAL_FLOATS + 1] */, double* v /* [ACC_NV] */) {
+  const double n = (double)f[0];
+  const double c[3] = {(double)f[17], (double)f[18], (double)f[19]};
+  v[0] += n;
+  v[16] += (double)f[16];
+  // sum |p|^2 = sum |p'|^2 + 2 c . sum p' + n |c|^2
+  v[17] += ((double)f[20] + 2.0 * ((c[0] * (double)f[1] + c[1] * (double)f[2]) + c[2] * (double)f[3])) +
+           n * ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    v[1 + a] += (double)f[1 + a] + n * c[a];
+    v[4 + a] += (double)f[4 + a] + n * c[a];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      v[7 + 3 * a + b] += (((double)f[7 + 3 * a + b] + c[a] * (double)f[4 + b]) + (double)f[1 + a] * c[b]) + n * (c[a] * c[b]);
+  }
+}
+
+// Kabsch from the raw moments and T <- dT * T (MODE 0: an ICP step) or T <- T_r * T0 (MODE 1: the RANSAC refit), by ONE
+// thread.  COH: the state is read and written past the caches (the chained passes: a wave on another XCD reads it in the
+// same launch).
+template <int MODE, bool COH, bool WS = false>
+__device__ __forceinline__ void solve_compose(const double* v /* [ACC_NV] */, CandState* st, const double* Td /* st->Td, or a copy of it */,
+                                              uint32_t frozen /* st->frozen */, double* ws = nullptr,
+                                              float* T_also = nullptr /* a second place for the new fp32 pose (the chained launch's next pass) ... */,
+                                              const float* T_was = nullptr /* ... and where the pose it was given is, should it stay */) {
+  GLOC_WS_ARR(Rd, 9);
+  GLOC_WS_ARR(td, 3);
+  bool have = false;
+  if (MODE == 0) {
+    if (frozen) {
+      if (T_also)
+        for (int i = 0; i < 12; ++i) st_f32<COH>(T_also + i, T_was[i]);
+      return;
+    }
+    st_f64<COH>(&st->sum_d2, v[16]);
+    if (v[0] < 3.0) {
+      st_u32<COH>(reinterpret_cast<uint32_t*>(&st->frozen), 1u);
+      st_f32<COH>(&st->last_step, __builtin_inff());  // an ICP that stopped for want of correspondences has not converged (max_final_step)
+      if (T_also)
+        for (int i = 0; i < 12; ++i) st_f32<COH>(T_also + i, T_was[i]);
+      return;
+    }
+  } else {
+    st_f64<COH>(&st->sum_d2, v[16]);
+    if (st->best_h == 0xFFFFFFFFu) return;  // keep T0
+    if (v[0] < 3.0) {
+      for (int i = 0; i < 9; ++i) Rd[i] = (double)st->bestRt[i];
+      for (int i = 0; i < 3; ++i) td[i] = (double)st->bestRt[9 + i];
+      have = true;
+    }
+  }
+  if (!have) {
+    const double cnt = v[0];
+    const double inv = 1.0 / cnt;
+    GLOC_WS_ARR(pbar, 3);
+    GLOC_WS_ARR(qbar, 3);
+    GLOC_WS_ARR(M, 9);
+    for (int a = 0; a < 3; ++a) {
+      pbar[a] = v[1 + a] * inv;
+      qbar[a] = v[4 + a] * inv;
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) M[3 * a + b] = v[7 + 3 * a + b] - cnt * (pbar[a] * qbar[b]);
+    kabsch_from_cov_t<WS>(M, pbar, qbar, Rd, td, ws);
+    if (MODE == 0) {
+      // how far this update moves the points it was fitted on, RMS: |R c + t - c|^2 + (|R - I|_F^2 / 2) tr cov
+      // (oracle/reg_oracle.c: kabsch_pairs) -- the ICP's convergence measure, read by the host after the last pass
+      double s2 = v[17] * inv - ((pbar[0] * pbar[0] + pbar[1] * pbar[1]) + pbar[2] * pbar[2]), dc2 = 0.0, f2 = 0.0;
+      if (s2 < 0.0) s2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double d = (((Rd[3 * a + 0] * pbar[0] + Rd[3 * a + 1] * pbar[1]) + Rd[3 * a + 2] * pbar[2]) + td[a]) - pbar[a];
+        dc2 += d * d;
+        for (int b = 0; b < 3; ++b) {
+          const double e = Rd[3 * a + b] - (a == b ? 1.0 : 0.0);
+          f2 += e * e;
+        }
+      }
+      st_f32<COH>(&st->last_step, (float)sqrt(dc2 + 0.5 * f2 * s2));
+    }
+  }
+  // (Rd,td) o (Td)
+  GLOC_WS_ARR(Rn, 9);
+  GLOC_WS_ARR(tn, 3);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      Rn[3 * i + j] = (Rd[3 * i + 0] * Td[0 + j] + Rd[3 * i + 1] * Td[3 + j]) +
+                      Rd[3 * i + 2] * Td[6 + j];
+    tn[i] = ((Rd[3 * i + 0] * Td[9] + Rd[3 * i + 1] * Td[10]) + Rd[3 * i + 2] * Td[11]) +
+            td[i];
+  }
+  for (int i = 0; i < 9; ++i) {
+    st_f64<COH>(&st->Td[i], Rn[i]);
+    st_f32<COH>(&st->Tf[i], (float)Rn[i]);
+    if (T_also) st_f32<COH>(T_also + i, (float)Rn[i]);
+  }
+  for (int i = 0; i < 3; ++i) {
+    st_f64<COH>(&st->Td[9 + i], tn[i]);
+    st_f32<COH>(&st->Tf[9 + i], (float)tn[i]);
+    if (T_also) st_f32<COH>(T_also + 9 + i, (float)tn[i]);
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,
                                                               uint32_t n_part, bool per_group,
@@ -804,21 +1012,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
         f[2 * i] = t.x;
         f[2 * i + 1] = t.y;
       }
-      const double n = (double)f[0];
-      const double c[3] = {(double)f[17], (double)f[18], (double)f[19]};
-      v[0] += n;
-      v[16] += (double)f[16];
-      // sum |p|^2 = sum |p'|^2 + 2 c . sum p' + n |c|^2
-      v[17] += ((double)f[20] + 2.0 * ((c[0] * (double)f[1] + c[1] * (double)f[2]) + c[2] * (double)f[3])) +
-               n * ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        v[1 + a] += (double)f[1 + a] + n * c[a];
-        v[4 + a] += (double)f[4 + a] + n * c[a];
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          v[7 + 3 * a + b] += (((double)f[7 + 3 * a + b] + c[a] * (double)f[4 + b]) + (double)f[1 + a] * c[b]) + n * (c[a] * c[b]);
-      }
+      add_wave_partial(f, v);
     }
 #pragma unroll
     for (int k = 0; k < ACC_NV; ++k) {  // (DPP / permlane exchanges: the LDS crossbar's __shfl_xor made this 8 us of chain)
@@ -860,70 +1054,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __re
   double v[ACC_NV];
 #pragma unroll
   for (int k = 0; k < ACC_NV; ++k) v[k] = tot[k];
-  CandState& st = states[cand];
-  double Rd[9], td[3];
-  bool have = false;
-  if (MODE == 0) {
-    if (st.frozen) return;
-    st.sum_d2 = v[16];
-    if (v[0] < 3.0) {
-      st.frozen = 1;
-      st.last_step = __builtin_inff();  // an ICP that stopped for want of correspondences has not converged (max_final_step)
-      return;
-    }
-  } else {
-    st.sum_d2 = v[16];
-    if (st.best_h == 0xFFFFFFFFu) return;  // keep T0
-    if (v[0] < 3.0) {
-      for (int i = 0; i < 9; ++i) Rd[i] = (double)st.bestRt[i];
-      for (int i = 0; i < 3; ++i) td[i] = (double)st.bestRt[9 + i];
-      have = true;
-    }
-  }
-  if (!have) {
-    const double cnt = v[0];
-    const double inv = 1.0 / cnt;
-    double pbar[3], qbar[3], M[9];
-    for (int a = 0; a < 3; ++a) {
-      pbar[a] = v[1 + a] * inv;
-      qbar[a] = v[4 + a] * inv;
-    }
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) M[3 * a + b] = v[7 + 3 * a + b] - cnt * (pbar[a] * qbar[b]);
-    kabsch_from_cov(M, pbar, qbar, Rd, td);
-    if (MODE == 0) {
-      // how far this update moves the points it was fitted on, RMS: |R c + t - c|^2 + (|R - I|_F^2 / 2) tr cov
-      // (oracle/reg_oracle.c: kabsch_pairs) -- the ICP's convergence measure, read by the host after the last pass
-      double s2 = v[17] * inv - ((pbar[0] * pbar[0] + pbar[1] * pbar[1]) + pbar[2] * pbar[2]), dc2 = 0.0, f2 = 0.0;
-      if (s2 < 0.0) s2 = 0.0;
-      for (int a = 0; a < 3; ++a) {
-        const double d = (((Rd[3 * a + 0] * pbar[0] + Rd[3 * a + 1] * pbar[1]) + Rd[3 * a + 2] * pbar[2]) + td[a]) - pbar[a];
-        dc2 += d * d;
-        for (int b = 0; b < 3; ++b) {
-          const double e = Rd[3 * a + b] - (a == b ? 1.0 : 0.0);
-          f2 += e * e;
-        }
-      }
-      st.last_step = (float)sqrt(dc2 + 0.5 * f2 * s2);
-    }
-  }
-  // (Rd,td) o (Td)
-  double Rn[9], tn[3];
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j)
-      Rn[3 * i + j] = (Rd[3 * i + 0] * st.Td[0 + j] + Rd[3 * i + 1] * st.Td[3 + j]) +
-                      Rd[3 * i + 2] * st.Td[6 + j];
-    tn[i] = ((Rd[3 * i + 0] * st.Td[9] + Rd[3 * i + 1] * st.Td[10]) + Rd[3 * i + 2] * st.Td[11]) +
-            td[i];
-  }
-  for (int i = 0; i < 9; ++i) {
-    st.Td[i] = Rn[i];
-    st.Tf[i] = (float)Rn[i];
-  }
-  for (int i = 0; i < 3; ++i) {
-    st.Td[9 + i] = tn[i];
-    st.Tf[9 + i] = (float)tn[i];
-  }
+  solve_compose<MODE, false>(v, &states[cand], states[cand].Td, (uint32_t)states[cand].frozen);
 }
 
 }  // namespace reg

@@ -259,12 +259,19 @@ enum {
   GLOC_REG_OPT_NN_HEAVY_THRESH = 9,  /* culled search, first (cold) pass of a batch: a wave that has processed this many
                                        target chunks hands its source group to a second launch, which searches it with
                                        8 waves (identical results); default 32; 0: off */
-  GLOC_REG_OPT_SUB_BATCHES = 10      /* a small batch is cut into this many runs of jobs, each enqueued on its own internal
+  GLOC_REG_OPT_SUB_BATCHES = 10,     /* a small batch is cut into this many runs of jobs, each enqueued on its own internal
                                        stream (forked from and joined back into the handle's stream), so that one
                                        run's solve and ramp-up run under the others' searches: 2 .. 8; -1 (default), 0, 1: off --
                                        measured SLOWER for one query alone (20 jobs: 3.2 ms on one stream, 3.9 with 4): a
                                        search launch of 5 jobs already has more waves than the chip has slots.  Identical
                                        results */
+  GLOC_REG_OPT_NN_CHAIN = 11         /* 1 (default): the warm ICP passes of a SMALL batch (fewer than 48 jobs: one query's
+                                       20 candidates) run as ONE launch -- every pass's searches, reductions, solves and
+                                       plans laid end to end, a wave of pass p + 1 waiting on the device for its own
+                                       job's solve of pass p -- instead of 2 launches per pass with the chip draining
+                                       in between; 0: launch by launch.  Identical results.  Every device-side wait is
+                                       bounded (1 s): a batch whose chain runs out fails with GLOC_ERR_HIP and the
+                                       handle stops chaining */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

@@ -687,6 +687,93 @@ def test_sub_batches_on_their_own_streams_change_no_bit(capi, scans):
     store.close()
 
 
+def test_passes_chained_in_one_launch_change_no_bit(capi, scans):
+    """GLOC_REG_OPT_NN_CHAIN (round 6): the warm ICP passes of a small batch as ONE launch -- searches, reductions, solves
+    and plans of every pass end to end, a wave waiting on the device for its own job's previous solve -- give the poses,
+    rmse, inliers, ok, final steps and correspondences of the launch-by-launch pipeline, bit for bit: with and without
+    RANSAC (the first ICP pass is then a cold launch of its own), with many groups split over helper waves (a low
+    threshold), a job with a one-point target, on a caller's stream, twice in a row, through begin / end."""
+    import torch
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qid = store.add(np.ascontiguousarray(B[::4]))
+    cids = [store.add(np.ascontiguousarray(x)) for x in (A[::4], A[1::5], Cc[::4], A[2::6], Cc[1::5], A[3::7], A[::9], Cc[::7], A[5::8], A[:1])]
+    store.build_target_index_batch(cids[:5])
+    n = len(B[::4])
+
+    def run(chain, ransac, icp, thresh, stream=None, begin_end=False):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_CHAIN, chain)
+        r.set_option(capi.REG_OPT_NN_SPLIT_THRESH, thresh)
+        if stream is not None:
+            r.set_stream(stream.cuda_stream)
+        prm = capi.default_reg_params(ransac_iters=ransac, icp_iters=icp)
+        outs = []
+        for _ in range(2):
+            if begin_end:
+                r.batch_multi_begin([qid], np.array([cids], np.uint32), params=prm)
+                o = r.batch_multi_end()
+                outs.append({k: v[0] for k, v in o.items()})
+            else:
+                outs.append(r.batch_ids(qid, cids, params=prm))
+            outs[-1]["steps"] = np.array(r.final_steps(len(cids)))
+        corr = [r.debug_corr(j, n) for j in range(len(cids))]
+        launches, timeouts = r.debug_chain()
+        r.close()
+        return outs, corr, launches, timeouts
+
+    for ransac, icp in ((200, 6), (0, 5), (200, 2), (0, 21), (200, 1)):
+        for thresh in (60000, 25000):
+            (ref, _), ref_corr, l0, _ = run(0, ransac, icp, thresh)
+            assert l0 == 0
+            for stream, be in ((None, False), (torch.cuda.Stream(), True)):
+                outs, corr, launches, timeouts = run(1, ransac, icp, thresh, stream, be)
+                what = (ransac, icp, thresh, be)
+                assert timeouts == 0, what
+                # (a chain needs two warm passes: with RANSAC every ICP pass is warm, without it the first is a cold launch)
+                assert launches == (2 if icp - (0 if ransac else 1) >= 2 else 0), (what, launches)
+                for out in outs:
+                    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all(), what
+                    assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all(), what
+                    assert (bits(out["steps"].astype(np.float32)) == bits(ref["steps"].astype(np.float32))).all(), what
+                for j in range(len(cids)):
+                    assert (corr[j][0] == ref_corr[j][0]).all() and (bits(corr[j][1]) == bits(ref_corr[j][1])).all(), (what, j)
+    store.close()
+
+
+def test_a_chained_launch_that_stalls_ends_by_itself(capi, scans):
+    """Every wait inside the chained launch is bounded: with solvers made to wait for a wave that never comes
+    (gloc_reg_debug_chain_stall) the launch ends by itself within its time limit, the batch FAILS (no pose of it is a result),
+    and the handle goes on launch by launch -- the next batch on it gives the unchained bits."""
+    import time
+    store = capi.ScanStore()
+    A, B = scans["A"], scans["B"]
+    qid = store.add(np.ascontiguousarray(B[::4]))
+    cids = [store.add(np.ascontiguousarray(x)) for x in (A[::4], A[1::5], A[2::6])]
+    prm = capi.default_reg_params(ransac_iters=100, icp_iters=4)
+    r0 = capi.Registrar(store=store)
+    r0.set_option(capi.REG_OPT_NN_CHAIN, 0)
+    ref = r0.batch_ids(qid, cids, params=prm)
+    r0.close()
+    r = capi.Registrar(store=store)
+    r.debug_chain_stall(True)
+    t0 = time.time()
+    with pytest.raises(capi.GlocError, match="timed out"):
+        r.batch_ids(qid, cids, params=prm)
+    assert time.time() - t0 < 5.0
+    assert r.debug_chain() == (1, 1)
+    out = r.batch_ids(qid, cids, params=prm)  # (the handle has stopped chaining)
+    assert r.debug_chain() == (1, 1)
+    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
+    r.debug_chain_stall(False)
+    r.set_option(capi.REG_OPT_NN_CHAIN, 1)  # (switched on again by hand)
+    out = r.batch_ids(qid, cids, params=prm)
+    assert r.debug_chain() == (2, 1)
+    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
+    r.close()
+    store.close()
+
+
 def test_split_groups_decide_ties_by_the_original_index(capi, oracle_mod):
     """Equidistant targets in DIFFERENT parts of a split group: the parts' keys are (distance, original index), so the
     smallest original index wins as in the single wave.  Lattice targets in shuffled order, sources on cell centres /

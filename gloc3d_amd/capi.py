@@ -769,6 +769,16 @@ class Registrar:
         check(f(self._h, C.byref(n), C.byref(t)))
         return n.value, t.value
 
+    def debug_needed_iters(self, inl, n, conf, max_iters):
+        """Test aid: the adaptive RANSAC stop's iteration count as the device computes it."""
+        f = lib().gloc_reg_debug_needed_iters
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p]
+        a, b = np.ascontiguousarray(inl, np.uint32), np.ascontiguousarray(n, np.uint32)
+        out = np.empty(a.shape[0], np.uint32)
+        check(f(self._h, _np_ptr(a), _np_ptr(b), a.shape[0], conf, max_iters, _np_ptr(out)))
+        return out
+
     def debug_chain_stall(self, on):
         """Test aid: make the chained launch's solvers wait for a wave that never comes (the bounded waits)."""
         f = lib().gloc_reg_debug_chain_stall

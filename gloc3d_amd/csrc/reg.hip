@@ -63,6 +63,7 @@ struct gloc_reg {
   // and the work estimate (cycles) above which a group is split
   int nn_split_helpers = -1;
   uint32_t nn_split_thresh = 60000;
+  bool nn_split_thresh_set = false;  // by the caller (GLOC_REG_OPT_NN_SPLIT_THRESH): else 60000, or 85000 where the passes are chained
   DevBuf split_zero, split_ff;     // [work | plan | ticket] and [skey | helper] of the batch
   NnSplit split{};                 // views into them for the batch being enqueued (hx = 0: off)
   // the groups a cold pass's waves give up and a second launch searches with NN_HEAVY_PARTS waves each (NnHeavy)
@@ -169,7 +170,11 @@ int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
   sp.skey = h->split_ff.as<unsigned long long>();
   sp.helper = reinterpret_cast<uint32_t*>(sp.skey + nj * hx * S);
   sp.hx = hx;
-  sp.thresh = h->nn_split_thresh;
+  // (the chained launch hides a job's longest wave behind the other jobs' work, so fewer groups need splitting: one query
+  // alone, registration of 20 jobs, threshold 45 / 60 / 75 / 90 / 120 thousand cycles: 2.92 / 2.89 / 2.79 / 2.78 / 3.03 ms)
+  const bool chains = h->nn_chain && !h->chain_broken && !h->prof.enabled && !h->trace_on && cs == 2 && bd.n_jobs < 48 &&
+                      getenv("GLOC3D_NN_NO_CHAIN") == nullptr;
+  sp.thresh = h->nn_split_thresh_set || !chains ? h->nn_split_thresh : 85000u;
   return GLOC_OK;
 }
 
@@ -433,7 +438,12 @@ int enqueue_pipeline(gloc_reg* h, const BatchDims& bd, const gloc_reg_params* pr
     GLOC_HIP(hipMemsetAsync(v.valid, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));  // never-generated = invalid
     GLOC_HIP(hipMemsetAsync(v.inliers, 0, sizeof(uint32_t) * (size_t)H * n_jobs, s));
     const float thr2 = prm->inlier_thresh * prm->inlier_thresh;
-    const unsigned cchunks = (bd.max_src + SC_CHUNK - 1) / SC_CHUNK;
+    // pairs per work-group of the scoring: 4096 -- or 1024 in a small batch (one query alone: 20 jobs x 31 chunks = 620
+    // work-groups for 256 CUs, each walking 16 tiles behind two barriers: 75 us for the first 16 hypotheses)
+    static const unsigned chunk_env = getenv("GLOC3D_RANSAC_CHUNK") ? (unsigned)atoi(getenv("GLOC3D_RANSAC_CHUNK")) : 0u;  // developer override
+    const uint32_t chunk_len = chunk_env ? chunk_env : ((size_t)n_jobs * ((bd.max_src + SC_CHUNK - 1) / SC_CHUNK) >= 2048 ? (uint32_t)SC_CHUNK : 1024u);
+    static_assert(1024 % SC_STAGE == 0 && SC_CHUNK % SC_STAGE == 0, "whole tiles");
+    const unsigned cchunks = (bd.max_src + chunk_len - 1) / chunk_len;
     for (int ph = 0; ph < n_ph; ++ph) {
       const uint32_t h0 = bounds[ph], h1 = bounds[ph + 1], len = h1 - h0;
       const CandState* st = ph ? v.states : (const CandState*)nullptr;
@@ -456,16 +466,16 @@ int enqueue_pipeline(gloc_reg* h, const BatchDims& bd, const gloc_reg_params* pr
         for (unsigned q = 0; q < NP; ++q) {
           const unsigned c0 = q * cchunks / NP, c1 = (q + 1) * cchunks / NP;
           hipLaunchKernelGGL(ransac_alive_kernel, dim3(n_jobs), dim3(1024), 0, s, v.inliers, v.valid,
-                             H, h0, h1, v.jobs, v.states, (uint32_t)(c0 * SC_CHUNK), a_idx, a_cnt);
+                             H, h0, h1, v.jobs, v.states, (uint32_t)(c0 * chunk_len), a_idx, a_cnt);
           hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, c1 - c0, n_jobs), dim3(256), 0, s,
                              v.pairs, bd.ld, v.jobs, H, h0, 256u, v.Rt,
-                             v.valid, thr2, st, v.inliers, a_idx, a_cnt, (uint32_t)c0);
+                             v.valid, thr2, st, v.inliers, a_idx, a_cnt, (uint32_t)c0, chunk_len);
         }
       } else {
         hipLaunchKernelGGL(ransac_score_kernel, dim3((len + hpb - 1) / hpb, cchunks, n_jobs), dim3(256), 0, s,
                            v.pairs, bd.ld, v.jobs, H, h0, hpb, v.Rt,
                            v.valid, thr2, st, v.inliers, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, 0u);
+                           (const uint32_t*)nullptr, 0u, chunk_len);
       }
       if (ph + 1 < n_ph)
         hipLaunchKernelGGL(ransac_scan_kernel<false>, dim3(n_jobs), dim3(64), 0, s, v.inliers,
@@ -924,6 +934,7 @@ int gloc_reg_set_option(gloc_reg* h, int option, int64_t value) {
   if (option == GLOC_REG_OPT_NN_SPLIT_THRESH) {
     GLOC_REQUIRE(value >= 0 && value <= 0x3FFFFFFF, GLOC_ERR_INVALID, "must be in [0, 2^30)");
     h->nn_split_thresh = (uint32_t)value;
+    h->nn_split_thresh_set = true;
     return GLOC_OK;
   }
   if (option == GLOC_REG_OPT_NN_SRC_PER_LANE) {
@@ -1305,7 +1316,7 @@ int gloc_reg_ransac_hypotheses(gloc_reg* h, const float* src_xyz, const float* t
   hipLaunchKernelGGL(ransac_score_kernel, grid, dim3(256), 0, s, h->pairs.as<f32x4>(), ld,
                      h->jobs.as<Job>(), n_hyp, 0u, 256u /* thread <-> hypothesis */, h->Rt.as<float>(),
                      h->valid.as<uint32_t>(), inlier_thresh * inlier_thresh, (const CandState*)nullptr,
-                     h->inliers.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                     h->inliers.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t)SC_CHUNK);
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipMemcpyAsync(out_Rt, h->Rt.p, sizeof(float) * 12 * (size_t)n_hyp,
                           hipMemcpyDeviceToHost, s));
@@ -1377,6 +1388,25 @@ int gloc_reg_debug_chain_trace(gloc_reg* h, int enable, uint32_t* out, size_t ca
     GLOC_HIP(hipStreamSynchronize(h->stream));
     GLOC_HIP(hipMemcpy(out, h->chain_dbg.p, n * 4, hipMemcpyDeviceToHost));
   }
+  return GLOC_OK;
+}
+
+// Test aid (not part of include/gloc3d.h): the adaptive stop's iteration count as the DEVICE computes it, for `count`
+// (inliers, points) pairs -- compared with the oracle's loop in tests/test_reg_gpu.py.
+int gloc_reg_debug_needed_iters(gloc_reg* h, const uint32_t* inl, const uint32_t* n, uint32_t count, float conf, uint32_t max_iters,
+                                uint32_t* out) {
+  GLOC_REQUIRE(h && inl && n && out, GLOC_ERR_INVALID, "null argument");
+  GLOC_HIP(hipSetDevice(h->device));
+  GLOC_NOT_PENDING(h);
+  hipStream_t s = h->stream;
+  GLOC_TRY(h->export_idx.ensure(sizeof(uint32_t) * 3 * (size_t)count, s));
+  uint32_t* d = h->export_idx.as<uint32_t>();
+  GLOC_HIP(hipMemcpyAsync(d, inl, 4 * (size_t)count, hipMemcpyHostToDevice, s));
+  GLOC_HIP(hipMemcpyAsync(d + count, n, 4 * (size_t)count, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(needed_iters_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d, d + count, conf, max_iters, d + 2 * (size_t)count, count);
+  GLOC_HIP(hipGetLastError());
+  GLOC_HIP(hipMemcpyAsync(out, d + 2 * (size_t)count, 4 * (size_t)count, hipMemcpyDeviceToHost, s));
+  GLOC_HIP(hipStreamSynchronize(s));
   return GLOC_OK;
 }
 

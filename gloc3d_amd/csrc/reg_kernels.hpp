@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                                                            const CandState* __restrict__ states,
                                                            uint32_t* __restrict__ inliers,
                                                            const uint32_t* __restrict__ alive_idx /* [cand][n_hyp] or null */,
-                                                           const uint32_t* __restrict__ alive_cnt, uint32_t chunk0) {
+                                                           const uint32_t* __restrict__ alive_cnt, uint32_t chunk0,
+                                                           uint32_t chunk_len /* pairs per work-group: a multiple of SC_STAGE (SC_CHUNK; less in small batches) */) {
   // staged pairs, two correspondences per entry, structure-of-arrays: (px0 px1 py0 py1)(pz0 pz1 qx0 qx1)(qy0 qy1 qz0 qz1)
   // so that one packed fp32 instruction moves / measures two correspondences.
   //
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
   if (states && states[cand].ransac_done) return;  // adaptive stop reached in an earlier phase
   const uint32_t n = jobs[cand].n_src;
   const uint32_t chunk = blockIdx.y + chunk0;
-  if (chunk * SC_CHUNK >= n) return;
+  if (chunk * chunk_len >= n) return;
   // hyp_per_block = 256: thread <-> hypothesis.  64 / 16: the four waves share that many hypotheses, each thread taking
   // a quarter / a sixteenth of every staged tile (the first phases of the adaptive RANSAC need few hypotheses).
   const uint32_t sub = threadIdx.x / hyp_per_block, nsub = 256 / hyp_per_block;
@@ -474,8 +475,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
                           fabsf(T[6]) + fabsf(T[7]) + fabsf(T[8]));
   const float tmax = fmaxf(fmaxf(fabsf(T[9]), fabsf(T[10])), fabsf(T[11]));
   const float thr = sqrtf(thr2);
-  const uint32_t i0 = chunk * SC_CHUNK;
-  const uint32_t i1 = (i0 + SC_CHUNK) < n ? (i0 + SC_CHUNK) : n;
+  const uint32_t i0 = chunk * chunk_len;
+  const uint32_t i1 = (i0 + chunk_len) < n ? (i0 + chunk_len) : n;
   uint32_t cnt = 0;
   float* spf = reinterpret_cast<float*>(sp);
   for (uint32_t b = i0; b < i1; b += SC_STAGE) {
@@ -527,6 +528,24 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const f32x4* __restri
         cnt += (un1 && d2.y < thr2) ? 1u : 0u;
       }
     }
+  }
+  if (hyp_per_block < 256u) {  // (uniform; every early return above is the whole work-group's)
+    // The threads that share a hypothesis add up first: one atomic per hypothesis and work-group, not one per thread
+    // (16 hypotheses: 16 threads each -- 256 atomics on one 64-byte line per work-group, and the line serves them one
+    // after the other: the first phase of one query's 20 jobs took 75 us, 620 work-groups x 256).
+    __shared__ uint32_t red[4][64];
+    uint32_t c = hv ? cnt : 0u;
+    if (hyp_per_block == 16u) {
+      c += xor_lane_u32<16>(c);
+      c += xor_lane_u32<32>(c);
+    }
+    red[threadIdx.x >> 6][threadIdx.x & 63] = c;
+    __syncthreads();
+    if (threadIdx.x < hyp_per_block) {
+      const uint32_t tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      if (hv && tot) atomicAdd(&inliers[(size_t)cand * n_hyp + h], tot);
+    }
+    return;
   }
   if (hv && cnt) atomicAdd(&inliers[(size_t)cand * n_hyp + h], cnt);
 }
@@ -580,7 +599,19 @@ __device__ inline uint32_t ransac_needed_iters(uint32_t inl, uint32_t n, float c
   // dependent fp64 multiplications in one lane (3000: 17 us, and a job sees several such records -- the scan of the
   // first 64 hypotheses took 111 us of a 4 ms query).  q^max_iters above the target by a margin no rounding of the
   // loop can bridge (each product is within 2^-53 of exact: 3000 of them, 4e-13) says so without running it.
-  if (q > 0.0 && (double)max_iters * log(q) > log(target) + 1.0e-6) return max_iters;
+  const double lq = q > 0.0 ? log(q) : 0.0, lt = log(target);
+  if (q > 0.0 && (double)max_iters * lq > lt + 1.0e-6) return max_iters;
+  // Round 6: the count without the loop where no rounding can make it differ.  The loop returns the smallest k whose running
+  // product fl(q^k) is <= target; the exact answer is ceil(ln target / ln q).  The running product is within k 2^-53 of
+  // q^k, the quotient of the two logarithms within 1e-9 of its value for k <= 2^20 (check_params), and a relative error e
+  // of the product moves the threshold in k by e / |ln q| <= e k / |ln target| -- under 3e-5 for a million iterations: a
+  // quotient further than 1e-3 from the next integer decides.  (A record with a fifth of the points as inliers took 570
+  // dependent multiplications, 5 us in one lane, and the different-world candidates of a query see several: the scan of
+  // the first 16 hypotheses of one query's 20 jobs was 54 us.)
+  if (q > 0.0 && q < 1.0 && target > 0.0 && target < 1.0) {
+    const double ke = lt / lq, kc = ceil(ke);
+    if (kc - ke > 1.0e-3 && kc - ke < 1.0 - 1.0e-3 && kc >= 1.0 && kc < (double)max_iters) return (uint32_t)kc;
+  }
   double pw = 1.0;
   uint32_t k = 0;
   while (pw > target && k < max_iters) {
@@ -588,6 +619,13 @@ __device__ inline uint32_t ransac_needed_iters(uint32_t inl, uint32_t n, float c
     k++;
   }
   return k;
+}
+
+// test aid (gloc_reg_debug_needed_iters): the device's count for arrays of (inliers, points)
+__global__ void needed_iters_kernel(const uint32_t* __restrict__ inl, const uint32_t* __restrict__ n, float conf, uint32_t max_iters,
+                                    uint32_t* __restrict__ out, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = ransac_needed_iters(inl[i], n[i], conf, max_iters);
 }
 
 // K5c.  The sequential RANSAC rule over hypotheses [h0, h1): best = first hypothesis with strictly

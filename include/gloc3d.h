@@ -252,7 +252,7 @@ enum {
                                        identical results).  -1 (default): by batch size (256 up to
                                        64 jobs, 64 up to 256, else off); 0: off */
   GLOC_REG_OPT_NN_SPLIT_THRESH = 7,  /* the estimate (cycles of one wave) above which a group is split; default
-                                       60000; 0: off */
+                                       60000 (85000 for the batches whose passes are chained: GLOC_REG_OPT_NN_CHAIN); 0: off */
   GLOC_REG_OPT_NN_SUB_JOBS = 8,      /* culled search tuning: interleaved shares of a job's work-groups that take a
                                        slot of the launch order each (a slot stays on one XCD); 0 (default): 8 for
                                        batches under 48 jobs, which 8 XCDs cannot balance job by job, else 1 */

@@ -687,6 +687,44 @@ def test_sub_batches_on_their_own_streams_change_no_bit(capi, scans):
     store.close()
 
 
+def test_adaptive_stop_count_on_the_device_equals_the_oracles_loop(capi, oracle_mod):
+    """The adaptive RANSAC stop's iteration count (OpenCV's rule: the smallest k with (1 - w^3)^k <= 1 - confidence, by
+    repeated multiplication in the oracle) as the device computes it -- from the two logarithms where no rounding can
+    change the answer, by the loop otherwise: equal for 200 000 random (inliers, points) pairs, for every inlier count of
+    a few scan sizes, and for the pairs whose exact quotient lies closest to an integer; confidences 0.5 .. 0.9999, caps
+    3000 and 2^20."""
+    import ctypes
+    L = oracle_mod.lib()
+    L.oracle_ransac_needed_iters.restype = ctypes.c_uint32
+    L.oracle_ransac_needed_iters.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint32]
+    rng = np.random.default_rng(77)
+    n = rng.integers(3, 200000, 200000).astype(np.uint32)
+    inl = (rng.random(200000) ** 2 * (n + 1)).astype(np.uint32)
+    inl = np.minimum(inl, n)
+    # every inlier count of small scans, and of a full-size one the counts nearest an integer quotient
+    extra_n, extra_i = [], []
+    for m in (3, 10, 97, 1000, 4096):
+        extra_n += [m] * (m + 1)
+        extra_i += list(range(m + 1))
+    m = 123675
+    w = np.arange(1, m, dtype=np.float64) / m
+    with np.errstate(divide="ignore"):
+        ke = np.log(0.01) / np.log1p(-w ** 3)
+    near = (np.argsort(np.abs(ke - np.rint(ke)))[:3000] + 1)[::-1]  # (the closest last)
+    extra_n += [m] * len(near)
+    extra_i += list(near)
+    n = np.concatenate([n, np.array(extra_n, np.uint32)])
+    inl = np.concatenate([inl, np.array(extra_i, np.uint32)])
+    r = capi.Registrar()
+    for conf, cap in ((0.99, 3000), (0.999, 3000), (0.5, 3000), (0.9999, 1 << 20), (0.99, 1 << 20), (0.99, 7)):
+        got = r.debug_needed_iters(inl, n, conf, cap)
+        sel = np.arange(len(n)) if cap <= 3000 else np.concatenate([np.arange(0, 200000, 130), np.arange(len(n) - 1000, len(n))])  # (the loop on the host: up to a million steps each)
+        ref = np.array([L.oracle_ransac_needed_iters(int(inl[i]), int(n[i]), conf, cap) for i in sel], np.uint32)
+        bad = np.nonzero(got[sel] != ref)[0]
+        assert bad.size == 0, (conf, cap, [(int(inl[sel[i]]), int(n[sel[i]]), int(got[sel[i]]), int(ref[i])) for i in bad[:5]])
+    r.close()
+
+
 def test_passes_chained_in_one_launch_change_no_bit(capi, scans):
     """GLOC_REG_OPT_NN_CHAIN (round 6): the warm ICP passes of a small batch as ONE launch -- searches, reductions, solves
     and plans of every pass end to end, a wave waiting on the device for its own job's previous solve -- give the poses,

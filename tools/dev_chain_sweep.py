@@ -1,0 +1,40 @@
+"""dev: one query alone (registration of 20 jobs) with the chained launch under split thresholds / helper slots, same box.
+usage: dev_chain_sweep.py"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from gloc3d_amd import capi
+traj, world_a, world_b = bench.headline_world(bench.N_PLACES_1GPU)
+store = capi.ScanStore()
+rows, qids = [], []
+for q, g in enumerate((300, 1500, 2900)):
+    qids.append(store.add_raycast(world_a, [traj[g] @ bench.query_offset(q)], np.array([bench.QUERY_SEED + q], np.uint64))[0])
+    places = [g + d for d in (0, 1, -1, 2, -2, 3, -3, 4, -4, 5, -5, 6, -6, 7, -7, 8, -8, 9, -9, 10)]
+    row = [store.add_raycast(world_b if pl % bench.NEG_EVERY == 1 else world_a, [traj[pl]], np.array([bench.PLACE_SEED + pl], np.uint64))[0] for pl in places]
+    store.build_target_index_batch(row)
+    rows.append(row)
+prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
+
+def run(chain, thresh, helpers, sub=0, reps=7):
+    reg = capi.Registrar(store=store)
+    reg.set_option(capi.REG_OPT_NN_CHAIN, chain)
+    reg.set_option(capi.REG_OPT_NN_SPLIT_THRESH, thresh)
+    reg.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, helpers)
+    if sub:
+        reg.set_option(capi.REG_OPT_NN_SUB_JOBS, sub)
+    ts = []
+    for _ in range(reps):
+        for qid, row in zip(qids, rows):
+            t0 = time.time()
+            reg.batch_multi([qid], [row], params=prm)
+            ts.append(time.time() - t0)
+    reg.close()
+    return float(np.median(ts[3:])) * 1e3
+
+print("plain  thresh  60000 helpers 256: %.3f ms" % run(0, 60000, 256))
+for thresh in (20000, 30000, 45000, 60000, 75000, 90000):
+    for helpers in (512, 256, 128):
+        print("chain  thresh %6d helpers %3d: %.3f ms" % (thresh, helpers, run(1, thresh, helpers)))
+print("chain  no split plan (helpers 0 -> launch by launch):  %.3f ms" % run(1, 60000, 0))
+print("plain  thresh  60000 helpers 256: %.3f ms" % run(0, 60000, 256))

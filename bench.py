@@ -1066,6 +1066,11 @@ def main():
         # its 3), then the stage times with them on
         reg.set_option(capi.REG_OPT_PROFILE, 0)
         t_lone = lone_pass(10)
+        # ... and the same ten queries launch by launch (GLOC_REG_OPT_NN_CHAIN 0: round 5's pipeline, 2 launches per ICP pass)
+        reg.set_option(capi.REG_OPT_NN_CHAIN, 0)
+        t_unchained = lone_pass(10)
+        reg.set_option(capi.REG_OPT_NN_CHAIN, 1)
+        n_chain, n_chain_timeouts = reg.debug_chain()
         reg.set_option(capi.REG_OPT_PROFILE, 1)
         prof_reset()
         t_prof = lone_pass(8)
@@ -1075,6 +1080,10 @@ def main():
         roofline["launch_ms_one_query_20_jobs"] = (ms1 - msc) / max(n1 - nc, 1)
         t_med = float(np.median([a for a, _ in t_lone[2:]]))
         lone = {"ms_per_query": t_med * 1e3, "queries_per_s": 1.0 / t_med,
+                "ms_per_query_launch_by_launch": float(np.median([a for a, _ in t_unchained[2:]])) * 1e3,
+                "chained_launches": int(n_chain), "chained_launches_timed_out": int(n_chain_timeouts),
+                "icp_passes": "one chained launch for the 20 warm ICP passes of the query's 20 jobs (GLOC_REG_OPT_NN_CHAIN; the stage times below "
+                              "are of the launch-by-launch pipeline: the per-kernel events switch the chain off)",
                 "prep_ms": float(np.median([b for _, b in t_lone[2:]])) * 1e3,
                 "ms_per_query_with_stage_events": float(np.median([a for a, _ in t_prof[2:]])) * 1e3,
                 "nn_launch_ms": (ms1 - msc) / max(n1 - nc, 1), "nn_cold_launch_ms": msc / max(nc, 1), "nn_ms_per_query": ms1 / 8,
@@ -1459,7 +1468,8 @@ def main():
         flat.update(knn_shard125k_q64_us=sr["knn_shard_125k"]["q64"]["us_per_search"], knn_shard125k_q64_frac=sr["knn_shard_125k"]["q64"]["frac_of_roofline"],
                     knn_shard125k_q1_us=sr["knn_shard_125k"]["q1"]["us_per_search"])
     if sr.get("cfgC_lone_query"):
-        flat.update(lone_query_ms=sr["cfgC_lone_query"]["ms_per_query"], lone_query_nn_launch_ms=sr["cfgC_lone_query"]["nn_launch_ms"],
+        flat.update(lone_query_ms=sr["cfgC_lone_query"]["ms_per_query"], lone_query_ms_launch_by_launch=sr["cfgC_lone_query"]["ms_per_query_launch_by_launch"],
+                    lone_query_nn_launch_ms=sr["cfgC_lone_query"]["nn_launch_ms"],
                     lone_query_nn_cold_launch_ms=sr["cfgC_lone_query"]["nn_cold_launch_ms"])
     if "knn_cfgE_sharded" in sr:
         flat.update(knn_cfgE_q64_us=sr["knn_cfgE_sharded"]["q64"]["us_per_search"], knn_cfgE_q1_us=sr["knn_cfgE_sharded"]["q1"]["us_per_search"],

@@ -180,17 +180,18 @@ __device__ __forceinline__ float exchange_add(float x, float y) {
 // FRESH: the word is at an address nobody reads before it can have its final value's predecessor written through -- the
 // first look is an ordinary load (served by the XCD's L2 to the 1 200 other waves of the job; a copy from before the
 // value was complete only sends the wave on to the loads past the caches).
+// Returns 0: a wait ran out; 1: the ordinary look sufficed; 2: the first look past the caches; 3: after polling.
 template <bool FRESH>
-__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t need, uint32_t* err) {
+__device__ __forceinline__ int chain_wait(const uint32_t* p, uint32_t need, uint32_t* err) {
   const int lane = threadIdx.x & 63;
   uint32_t v = 0;
   if constexpr (FRESH) {
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+    if (__builtin_amdgcn_readfirstlane(v) >= need) return 1;
     v = 0;
   }
   if (lane == 0) v = ld_u32<true>(p);
-  if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
+  if (__builtin_amdgcn_readfirstlane(v) >= need) return 2;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     __builtin_amdgcn_s_sleep(16);
@@ -199,11 +200,11 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t need, uin
       v = ld_u32<true>(p);
       e = ld_u32<true>(err);
     }
-    if (__builtin_amdgcn_readfirstlane(v) >= need) return true;
-    if (__builtin_amdgcn_readfirstlane(e) != 0u) return false;
+    if (__builtin_amdgcn_readfirstlane(v) >= need) return 3;
+    if (__builtin_amdgcn_readfirstlane(e) != 0u) return 0;
     if (__builtin_amdgcn_s_memrealtime() - t0 > NN_CHAIN_WAIT_TICKS) {
       if (lane == 0) st_u32<true>(err, 1u);
-      return false;
+      return 0;
     }
   }
 }
@@ -1556,7 +1557,17 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
     const uint32_t job = grp * ch.jobs_per_grp + jl;
     if (jl >= ch.jobs_per_grp || job >= n_jobs) return;  // padding
     if (role == 0) chain_stamp(ch, pass, job, n_jobs, 3, 0);  // reducer 0 starts to wait
-    if (!chain_wait<false>(ch.go + ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD, 1u, ch.err)) return;
+    // The search waves only add to `done` and leave (they do not wait for the sum to come back: 2 us of a slot, 8 % of
+    // a wave); ONE wave per job, its planner, polls the counter and raises `go` for the reducers, who poll that -- a line
+    // the 1 225 additions do not go through.
+    const size_t cell = ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD;
+    if (role == NN_CHAIN_RED) {
+      if (!chain_wait<false>(ch.done + cell, ch.expected, ch.err)) return;
+      if ((threadIdx.x & 63) == 0) st_u32<true>(ch.go + cell, 1u);
+      chain_stamp(ch, pass, job, n_jobs, 2, 0);  // the job's pass is seen complete
+    } else if (!chain_wait<false>(ch.go + cell, 1u, ch.err)) {
+      return;
+    }
     if (role == 0) chain_stamp(ch, pass, job, n_jobs, 4, 0);  // ... and sees the pass done
     nn_compact_body<CS, false, false, true, true, false, true>(NnPos{0u, 0u, 0u, 1u + role, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states,
                                                                 corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, hv, stat_pairs, trace, ch);
@@ -1574,17 +1585,19 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
   const size_t cell = ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD;
   NnSplit spp = sp;  // the pass's own plan and helpers' table (pass 0: the batch's, written by the launch before)
   if (pass > 0u) {
-    if (!chain_wait<true>(ch.ready + cell, 2u, ch.err)) return;
+    const int how = chain_wait<true>(ch.ready + cell, 2u, ch.err);
+    if (!how) return;
+    if (ch.dbg && (threadIdx.x & 63) == 0) atomicAdd(ch.dbg + ((size_t)pass * n_jobs + job) * 16 + 8 + how, 1u);  // dev: slots 9, 10, 11
     spp.plan = ch.planp + (size_t)(pass - 1u) * n_jobs * n_part;
     spp.helper = ch.helperp + (size_t)(pass - 1u) * n_jobs * sp.hx;
   }
   if (first_wave) chain_stamp(ch, pass, job, n_jobs, 1, 0);  // ... and past the wait
   nn_compact_body<CS, false, false, true, true, false, true>(NnPos{grp, slot, wgv, 0u, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states, corr, corr,
                                                               d2out, pairs, partials, n_part, ld, gate2, spp, hv, stat_pairs, trace, ch);
-  if (chain_arrive(ch.done + cell) == ch.expected - 1u) {
-    if ((threadIdx.x & 63) == 0) st_u32<true>(ch.go + cell, 1u);
-    chain_stamp(ch, pass, job, n_jobs, 2, 0);  // the last search wave of the job's pass has left
-  }
+  // (this wave's stores acknowledged, then its count -- not waited for)
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(ch.done + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #undef NN_COMPACT_PARAMS
 #undef NN_COMPACT_ARGS

@@ -130,7 +130,7 @@ constexpr uint32_t NN_CHAIN_PAD = 64;        // words between two counters / fla
 constexpr uint32_t NN_CHAIN_T_STRIDE = 32;   // floats per (pass, job) pose slot (128 B: a line of its own)
 constexpr uint32_t NN_CHAIN_RED = 16;                  // reducer waves per job: solve_kernel's 16 waves, one each
 constexpr uint32_t NN_CHAIN_ROLES = NN_CHAIN_RED + 1;  // + the planner
-constexpr unsigned long long NN_CHAIN_WAIT_TICKS = 100000000ull;  // 1 s of the 100 MHz clock
+constexpr unsigned long long NN_CHAIN_WAIT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 constexpr uint32_t NN_NO_HELPER = 0xFFFFFFFFu;
 constexpr uint32_t NN_MAX_PARTS = 8;
 // the estimate, from the trace's regression of wave cycles on its counts (tools/dev_nn_trace3.py)

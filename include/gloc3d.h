@@ -270,7 +270,7 @@ enum {
                                        plans laid end to end, a wave of pass p + 1 waiting on the device for its own
                                        job's solve of pass p -- instead of 2 launches per pass with the chip draining
                                        in between; 0: launch by launch.  Identical results.  Every device-side wait is
-                                       bounded (1 s): a batch whose chain runs out fails with GLOC_ERR_HIP and the
+                                       bounded (3 s): a batch whose chain runs out fails with GLOC_ERR_HIP and the
                                        handle stops chaining */
 };
 enum {

@@ -798,7 +798,7 @@ def test_a_chained_launch_that_stalls_ends_by_itself(capi, scans):
     t0 = time.time()
     with pytest.raises(capi.GlocError, match="timed out"):
         r.batch_ids(qid, cids, params=prm)
-    assert time.time() - t0 < 5.0
+    assert time.time() - t0 < 10.0
     assert r.debug_chain() == (1, 1)
     out = r.batch_ids(qid, cids, params=prm)  # (the handle has stopped chaining)
     assert r.debug_chain() == (1, 1)

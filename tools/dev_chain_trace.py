@@ -40,6 +40,9 @@ for j in (0, 1, 10, 19):
     print("job", j)
     for p in range(min(npass.value, 6)):
         print("  pass", p, " ".join(f"{names[k]} {us[p, j, k]:8.1f}" for k in range(9)))
+print("search waves past their wait at the ordinary look / the first look past the caches / after polling, per pass (all jobs):")
+for p in range(npass.value):
+    print("  pass", p, tr[p, :, 9].sum(), tr[p, :, 10].sum(), tr[p, :, 11].sum())
 print("per pass, over jobs (us):")
 for p in range(npass.value):
     print(f"  pass {p:2d}: first wave {us[p,:,0].min():8.1f}  last leaves {us[p,:,2].max():8.1f}  solved {us[p,:,8].min():8.1f} .. {us[p,:,8].max():8.1f}   "

@@ -8,7 +8,7 @@ import bench
 from gloc3d_amd import capi
 traj, world_a, world_b = bench.headline_world(bench.N_PLACES_1GPU)
 store = capi.ScanStore()
-g = 300
+g = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 places = [g + d for d in (0, 1, -1, 2, -2, 3, -3, 4, -4, 5, -5, 6, -6, 7, -7, 8, -8, 9, -9, 10)]
 row = [store.add_raycast(world_b if pl % bench.NEG_EVERY == 1 else world_a, [traj[pl]], np.array([bench.PLACE_SEED + pl], np.uint64))[0] for pl in places]
 store.build_target_index_batch(row)

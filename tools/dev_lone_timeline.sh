@@ -3,7 +3,7 @@ set -e
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rm -rf $O/lone_tl
-rocprofv3 --kernel-trace --output-format csv -d $O/lone_tl -o t -- python3 $R/tools/dev_lone_timeline.py > $O/lone_tl.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/lone_tl -o t -- python3 $R/tools/dev_lone_timeline.py $1 > $O/lone_tl.txt 2>&1
 tail -1 $O/lone_tl.txt
 python3 - <<P
 import csv, glob

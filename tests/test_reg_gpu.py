@@ -779,6 +779,61 @@ def test_passes_chained_in_one_launch_change_no_bit(capi, scans):
     store.close()
 
 
+def test_chained_batches_of_unequal_jobs_and_two_chains_at_once(capi, scans):
+    """The chained launch with (1) jobs of DIFFERENT sizes in one batch -- three queries of 31 k, 12 k and 700 points (a job's
+    waves beyond its own groups only count), a NO_SCAN cell, 47 jobs (the largest batch that chains) -- and (2) two handles on
+    two streams driven by two host threads, each chaining batch after batch at the same time: the poses, rmse, inliers and
+    ok of the launch-by-launch pipeline, no wait runs out."""
+    import threading
+    import torch
+    store = capi.ScanStore()
+    A, B, Cc = scans["A"], scans["B"], scans["C"]
+    qids = [store.add(np.ascontiguousarray(x)) for x in (B[::4], B[1::10], B[:700])]
+    cids = [store.add(np.ascontiguousarray(x)) for x in (A[::4], A[1::5], Cc[::4], A[2::6], Cc[1::5], A[3::7], A[::9], Cc[::7], A[5::8], A[4::11],
+                                                         A[::13], Cc[::6], A[6::7], A[1::9], Cc[2::9], A[7::10])]
+    store.build_target_index_batch(cids[:6])
+    prm = capi.default_reg_params(ransac_iters=150, icp_iters=5)
+    grid = np.array([cids[:15] + [capi.NO_SCAN], cids[1:16] + [cids[0]], cids[::-1][:15] + [cids[3]]], np.uint32)  # 47 jobs + an empty cell
+
+    def run(chain, q, ids, stream=None, reps=1):
+        r = capi.Registrar(store=store)
+        r.set_option(capi.REG_OPT_NN_CHAIN, chain)
+        if stream is not None:
+            r.set_stream(stream.cuda_stream)
+        outs = [r.batch_multi(q, ids, params=prm) for _ in range(reps)]
+        st = r.debug_chain()
+        r.close()
+        return outs, st
+
+    (ref,), _ = run(0, qids, grid)
+    (out,), (launches, timeouts) = run(1, qids, grid)
+    assert (launches, timeouts) == (1, 0)
+    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
+    assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all()
+
+    # two chains at once
+    (ref_a,), _ = run(0, qids[:1], grid[:1])
+    (ref_b,), _ = run(0, qids[1:2], grid[1:2])
+    res = {}
+
+    def worker(name, q, ids):
+        try:
+            res[name] = run(1, q, ids, torch.cuda.Stream(), reps=12)
+        except Exception as e:  # (reported below: an exception in a thread would otherwise pass silently)
+            res[name] = e
+    ta = threading.Thread(target=worker, args=("a", qids[:1], grid[:1]))
+    tb = threading.Thread(target=worker, args=("b", qids[1:2], grid[1:2]))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for name, refx in (("a", ref_a), ("b", ref_b)):
+        assert not isinstance(res[name], Exception), res[name]
+        outs, (launches, timeouts) = res[name]
+        assert (launches, timeouts) == (12, 0), (name, launches, timeouts)
+        for o in outs:
+            assert (bits(o["T"]) == bits(refx["T"])).all() and (bits(o["rmse"]) == bits(refx["rmse"])).all(), name
+            assert (o["inliers"] == refx["inliers"]).all() and (o["ok"] == refx["ok"]).all(), name
+    store.close()
+
+
 def test_a_chained_launch_that_stalls_ends_by_itself(capi, scans):
     """Every wait inside the chained launch is bounded: with solvers made to wait for a wave that never comes
     (gloc_reg_debug_chain_stall) the launch ends by itself within its time limit, the batch FAILS (no pose of it is a result),

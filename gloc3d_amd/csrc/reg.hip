@@ -335,7 +335,7 @@ uint32_t chain_passes(const gloc_reg* h, const BatchDims& bd, const WsView& v, u
     return 0;
   const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
   const uint32_t jg = (uint32_t)h->nn_job_group;
-  if (subs < 2 || (jg & 7u) || jg % subs) return 0;  // (small batches: the shares of a job fill a row of slots)
+  if (v.n_jobs >= 48 || (jg & 7u) || jg % subs) return 0;  // (small batches; a group of slots holds whole jobs)
   if ((bd.n_part & 31u) || (v.split.hx & 31u)) return 0;  // (a job's rows of the per-pass tables are whole cache lines)
   const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
   const uint32_t groups = (v.n_jobs * subs + jg - 1) / jg;

@@ -795,9 +795,10 @@ def test_chained_batches_of_unequal_jobs_and_two_chains_at_once(capi, scans):
     prm = capi.default_reg_params(ransac_iters=150, icp_iters=5)
     grid = np.array([cids[:15] + [capi.NO_SCAN], cids[1:16] + [cids[0]], cids[::-1][:15] + [cids[3]]], np.uint32)  # 47 jobs + an empty cell
 
-    def run(chain, q, ids, stream=None, reps=1):
+    def run(chain, q, ids, stream=None, reps=1, shares=0):
         r = capi.Registrar(store=store)
         r.set_option(capi.REG_OPT_NN_CHAIN, chain)
+        r.set_option(capi.REG_OPT_NN_SUB_JOBS, shares)
         if stream is not None:
             r.set_stream(stream.cuda_stream)
         outs = [r.batch_multi(q, ids, params=prm) for _ in range(reps)]
@@ -806,10 +807,11 @@ def test_chained_batches_of_unequal_jobs_and_two_chains_at_once(capi, scans):
         return outs, st
 
     (ref,), _ = run(0, qids, grid)
-    (out,), (launches, timeouts) = run(1, qids, grid)
-    assert (launches, timeouts) == (1, 0)
-    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
-    assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all()
+    for shares in (0, 1, 2, 4):  # (GLOC_REG_OPT_NN_SUB_JOBS: interleaved shares of a job in the launch order; 0 = 8 in a small batch)
+        (out,), (launches, timeouts) = run(1, qids, grid, shares=shares)
+        assert (launches, timeouts) == (1, 0), shares
+        assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all(), shares
+        assert (out["inliers"] == ref["inliers"]).all() and (out["ok"] == ref["ok"]).all(), shares
 
     # two chains at once
     (ref_a,), _ = run(0, qids[:1], grid[:1])

@@ -32,9 +32,10 @@ def run(chain, thresh, helpers, sub=0, reps=7):
     reg.close()
     return float(np.median(ts[3:])) * 1e3
 
-print("plain  thresh  60000 helpers 256: %.3f ms" % run(0, 60000, 256))
-for thresh in (20000, 30000, 45000, 60000, 75000, 90000):
-    for helpers in (512, 256, 128):
-        print("chain  thresh %6d helpers %3d: %.3f ms" % (thresh, helpers, run(1, thresh, helpers)))
-print("chain  no split plan (helpers 0 -> launch by launch):  %.3f ms" % run(1, 60000, 0))
-print("plain  thresh  60000 helpers 256: %.3f ms" % run(0, 60000, 256))
+print("plain  (8 shares): %.3f ms" % run(0, 60000, 256))
+for sub in (8, 4, 2, 1, 8, 4, 2, 1):
+    print("chain  thresh 85000 helpers 256 shares of a job %d: %.3f ms" % (sub, run(1, 85000, 256, sub)))
+for sub in (4, 2):
+    for thresh in (60000, 110000):
+        print("chain  thresh %6d helpers 256 shares of a job %d: %.3f ms" % (thresh, sub, run(1, thresh, 256, sub)))
+print("plain  shares 4: %.3f ms;  2: %.3f ms" % (run(0, 60000, 256, 4), run(0, 60000, 256, 2)))

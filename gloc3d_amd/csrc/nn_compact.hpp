@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
 // All warm moments passes of a small batch in ONE launch (NnChain): a one-dimensional grid of n_pass x pass_size
 // single-wave work-groups; a pass is `groups` runs of [job_group * n_wg searches | the group's roles | padding to a
 // multiple of 8, so that a slot keeps its XCD from pass to pass].  Held to six waves per SIMD like the warm kernel it chains.
-template <int CS>
+template <int CS, bool SPLIT = true>
 __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void nn_chain_kernel(NN_COMPACT_PARAMS, NnChain ch) {
   static_assert(NN_WPB == 1, "a work-group is a wave: the roles and the arrival counts are per wave");
   const uint32_t b = blockIdx.x;
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
       return;
     }
     if (role == 0) chain_stamp(ch, pass, job, n_jobs, 4, 0);  // ... and sees the pass done
-    nn_compact_body<CS, false, false, true, true, false, true>(NnPos{0u, 0u, 0u, 1u + role, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states,
+    nn_compact_body<CS, false, false, SPLIT, true, false, true>(NnPos{0u, 0u, 0u, 1u + role, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states,
                                                                 corr, corr, d2out, pairs, partials, n_part, ld, gate2, sp, hv, stat_pairs, trace, ch);
     return;
   }
@@ -1588,11 +1588,13 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
     const int how = chain_wait<true>(ch.ready + cell, 2u, ch.err);
     if (!how) return;
     if (ch.dbg && (threadIdx.x & 63) == 0) atomicAdd(ch.dbg + ((size_t)pass * n_jobs + job) * 16 + 8 + how, 1u);  // dev: slots 9, 10, 11
-    spp.plan = ch.planp + (size_t)(pass - 1u) * n_jobs * n_part;
-    spp.helper = ch.helperp + (size_t)(pass - 1u) * n_jobs * sp.hx;
+    if constexpr (SPLIT) {
+      spp.plan = ch.planp + (size_t)(pass - 1u) * n_jobs * n_part;
+      spp.helper = ch.helperp + (size_t)(pass - 1u) * n_jobs * sp.hx;
+    }
   }
   if (first_wave) chain_stamp(ch, pass, job, n_jobs, 1, 0);  // ... and past the wait
-  nn_compact_body<CS, false, false, true, true, false, true>(NnPos{grp, slot, wgv, 0u, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states, corr, corr,
+  nn_compact_body<CS, false, false, SPLIT, true, false, true>(NnPos{grp, slot, wgv, 0u, pass, job}, jobs, n_jobs, job_group, n_wg, subs, states, corr, corr,
                                                               d2out, pairs, partials, n_part, ld, gate2, spp, hv, stat_pairs, trace, ch);
   // (this wave's stores acknowledged, then its count -- not waited for)
   __builtin_amdgcn_s_waitcnt(0);

@@ -330,12 +330,12 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, const WsView& v, bool warm, bool
 // launch by launch).
 uint32_t chain_passes(const gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t remaining) {
   static const bool off = getenv("GLOC3D_NN_NO_CHAIN") != nullptr;  // developer switch
-  if (off || !h->nn_chain || h->chain_broken || h->nn_mode == 1 || h->nn_src_per_lane != 2 || !v.split.hx || h->trace_on ||
-      h->prof.enabled || remaining < 2 || NN_WPB != 1)
-    return 0;
+  static const bool force = getenv("GLOC3D_NN_CHAIN_FORCE") != nullptr;  // developer switch: any batch size, with or without the plan, under the per-kernel events
+  if (off || !h->nn_chain || h->chain_broken || h->nn_mode == 1 || h->nn_src_per_lane != 2 || h->trace_on || remaining < 2 || NN_WPB != 1) return 0;
+  if (!force && (!v.split.hx || h->prof.enabled)) return 0;
   const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
   const uint32_t jg = (uint32_t)h->nn_job_group;
-  if (v.n_jobs >= 48 || (jg & 7u) || jg % subs) return 0;  // (small batches; a group of slots holds whole jobs)
+  if ((!force && v.n_jobs >= 48) || (jg & 7u) || jg % subs) return 0;  // (small batches; a group of slots holds whole jobs)
   if ((bd.n_part & 31u) || (v.split.hx & 31u)) return 0;  // (a job's rows of the per-pass tables are whole cache lines)
   const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
   const uint32_t groups = (v.n_jobs * subs + jg - 1) / jg;
@@ -387,9 +387,17 @@ int launch_nn_chain(gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t 
   h->nn_launches += n_pass;
   h->chain_launches++;
   h->chain_in_batch = true;
-  hipLaunchKernelGGL((nn_chain_kernel<2>), dim3(ch.pass_size * n_pass), dim3(64 * NN_WPB), 0, v.s, v.jobs, v.n_jobs, jg, n_wg, subs,
-                     v.states, v.corr, v.corr, v.d2, v.pairs, v.partials, bd.n_part, bd.ld, gate2, v.split, NnHeavy{},
-                     (unsigned long long*)nullptr, (uint32_t*)nullptr, ch);
+  {
+    ProfScope ps(h->prof, "nn", v.s);  // (only with GLOC3D_NN_CHAIN_FORCE: the events otherwise switch the chain off)
+    if (v.split.hx)
+      hipLaunchKernelGGL((nn_chain_kernel<2, true>), dim3(ch.pass_size * n_pass), dim3(64 * NN_WPB), 0, v.s, v.jobs, v.n_jobs, jg, n_wg, subs,
+                         v.states, v.corr, v.corr, v.d2, v.pairs, v.partials, bd.n_part, bd.ld, gate2, v.split, NnHeavy{},
+                         (unsigned long long*)nullptr, (uint32_t*)nullptr, ch);
+    else
+      hipLaunchKernelGGL((nn_chain_kernel<2, false>), dim3(ch.pass_size * n_pass), dim3(64 * NN_WPB), 0, v.s, v.jobs, v.n_jobs, jg, n_wg, subs,
+                         v.states, v.corr, v.corr, v.d2, v.pairs, v.partials, bd.n_part, bd.ld, gate2, v.split, NnHeavy{},
+                         (unsigned long long*)nullptr, (uint32_t*)nullptr, ch);
+  }
   GLOC_HIP(hipGetLastError());
   GLOC_HIP(hipMemcpyAsync(h->h_chain_err, ch.err, 4, hipMemcpyDeviceToHost, v.s));
   return GLOC_OK;

@@ -497,7 +497,7 @@ __device__ __forceinline__ void nn_compact_body(
   }
   // candidate chunks of this part: bit b of a batch of 64 chunk boxes (the batch starts at a multiple of 64)
   const unsigned long long pmask =
-      !SPLIT || parts == 1 ? ~0ull : ((parts == 2 ? 0x5555555555555555ull : (parts == 4 ? 0x1111111111111111ull : 0x0101010101010101ull)) << part);
+      !SPLIT || parts == 1 ? ~0ull : ((parts == 2 ? 0x5555555555555555ull : (parts == 4 ? 0x1111111111111111ull : (parts == 8 ? 0x0101010101010101ull : 0x0001000100010001ull))) << part);
   uint32_t w_cand = 0;
   struct IndexView {
     GPTR(f32x4) pts; GPTR(f32x4) box_lo; GPTR(f32x4) box_hi; GPTR(f32x4) sb2;

@@ -172,8 +172,8 @@ int setup_split(gloc_reg* h, const BatchDims& bd, int cs) {
   sp.hx = hx;
   // (the chained launch hides a job's longest wave behind the other jobs' work, so fewer groups need splitting: one query
   // alone, registration of 20 jobs, threshold 45 / 60 / 75 / 90 / 120 thousand cycles: 2.92 / 2.89 / 2.79 / 2.78 / 3.03 ms)
-  const bool chains = h->nn_chain && !h->chain_broken && !h->prof.enabled && !h->trace_on && cs == 2 && bd.n_jobs < 48 &&
-                      getenv("GLOC3D_NN_NO_CHAIN") == nullptr;
+  static const bool chain_off = getenv("GLOC3D_NN_NO_CHAIN") != nullptr;  // developer switch (chain_passes)
+  const bool chains = h->nn_chain && !h->chain_broken && !h->prof.enabled && !h->trace_on && cs == 2 && bd.n_jobs < 48 && !chain_off;
   sp.thresh = h->nn_split_thresh_set || !chains ? h->nn_split_thresh : 85000u;
   return GLOC_OK;
 }

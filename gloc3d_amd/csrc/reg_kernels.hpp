@@ -84,7 +84,10 @@ struct NnHeavy {
   uint32_t cap;               // 0: off
   uint32_t thresh;            // processed chunks at which a wave gives up
 };
-constexpr uint32_t NN_HEAVY_PARTS = 8;
+#ifndef GLOC_NN_HEAVY_PARTS
+#define GLOC_NN_HEAVY_PARTS 8  // 2, 4, 8 or 16
+#endif
+constexpr uint32_t NN_HEAVY_PARTS = GLOC_NN_HEAVY_PARTS;
 // Round 6, late -- the ICP passes of a SMALL batch CHAINED in one launch (nn_chain_kernel, nn_compact.hpp).  One query
 // alone is 20 jobs x 21 passes: 21 x (a search launch of 19 380 waves over 6 144 slots that ramps up, drains and waits for
 // its slowest wave, + a solve launch with the chip idle) = 121 + 14 us per pass where the waves themselves need ~80.  The
@@ -938,6 +941,8 @@ __device__ __forceinline__ void solve_compose(const double* v /* [ACC_NV] */, Ca
     if (T_also) st_f32<COH>(T_also + 9 + i, (float)tn[i]);
   }
 }
+
+#undef GLOC_WS_ARR
 
 template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const double* __restrict__ partials,

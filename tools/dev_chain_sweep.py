@@ -16,26 +16,27 @@ for q, g in enumerate((300, 1500, 2900)):
     rows.append(row)
 prm = capi.default_reg_params(ransac_iters=3000, icp_iters=20, max_rmse=1.0)
 
-def run(chain, thresh, helpers, sub=0, reps=7):
+def run(chain, thresh, helpers, sub=0, reps=7, jg=0):
     reg = capi.Registrar(store=store)
     reg.set_option(capi.REG_OPT_NN_CHAIN, chain)
     reg.set_option(capi.REG_OPT_NN_SPLIT_THRESH, thresh)
     reg.set_option(capi.REG_OPT_NN_SPLIT_HELPERS, helpers)
     if sub:
         reg.set_option(capi.REG_OPT_NN_SUB_JOBS, sub)
+    if jg:
+        reg.set_option(capi.REG_OPT_NN_JOB_GROUP, jg)
     ts = []
     for _ in range(reps):
         for qid, row in zip(qids, rows):
             t0 = time.time()
             reg.batch_multi([qid], [row], params=prm)
             ts.append(time.time() - t0)
+    n, t = reg.debug_chain()
     reg.close()
-    return float(np.median(ts[3:])) * 1e3
+    return float(np.median(ts[3:])) * 1e3, n
 
-print("plain  (8 shares): %.3f ms" % run(0, 60000, 256))
-for sub in (8, 4, 2, 1, 8, 4, 2, 1):
-    print("chain  thresh 85000 helpers 256 shares of a job %d: %.3f ms" % (sub, run(1, 85000, 256, sub)))
-for sub in (4, 2):
-    for thresh in (60000, 110000):
-        print("chain  thresh %6d helpers 256 shares of a job %d: %.3f ms" % (thresh, sub, run(1, thresh, 256, sub)))
-print("plain  shares 4: %.3f ms;  2: %.3f ms" % (run(0, 60000, 256, 4), run(0, 60000, 256, 2)))
+print("plain  (8 shares, groups of 24 slots): %.3f ms" % run(0, 60000, 256)[0])
+for rep in range(2):
+    for thresh in (50000, 70000, 85000, 100000, 120000):
+        for helpers in (256, 128):
+            print("chain  (its own order) thresh %6d helpers %3d: %.3f ms" % (thresh, helpers, run(1, thresh, helpers, reps=9)[0]))

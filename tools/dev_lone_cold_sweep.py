@@ -30,7 +30,7 @@ def run(heavy, icp=20, reps=6, opts=()):
     reg.close()
     return np.array([np.median(t[2:]) for t in ts]) * 1e3
 
-for heavy in (32, 32):
+for heavy in (32, 32, 32):
     a = run(heavy)
     b = run(heavy, icp=0)
     print("give-up at %2d chunks: per query %s  mean %.3f ms;  without ICP (cold pass + RANSAC) %s mean %.3f" % (heavy, np.round(a, 2), a.mean(), np.round(b, 2), b.mean()))

@@ -57,7 +57,7 @@ struct gloc_reg {
   size_t trace_waves = 0;
   int nn_src_per_lane = 2;  // culled kernel: source points per lane (1, 2, 4)
   int nn_job_group = 24;    // culled kernel: jobs interleaved in the launch order (a multiple of 8: see nn_compact.hpp)
-  bool nn_job_group_set = false;  // by the caller (else the chained launch takes its own: chain_order)
+  bool nn_job_group_set = false;  // by the caller (else a small batch takes its own: launch_order)
   int nn_sub_jobs = 0;      // culled kernel: interleaved shares of a job's work-groups that get their own slot (0: by batch size)
   bool temp_target_index = false;  // kd-ordered target index for the temporary scans of the host-buffer calls
   // heavy source groups over several waves (nn_compact.hpp, NnSplit): helper waves per job (-1: by batch size, 0: off)
@@ -229,6 +229,22 @@ int ensure_sub_streams(gloc_reg* h, uint32_t G) {
   return GLOC_OK;
 }
 
+// The launch order of a batch's 1-NN passes (nn_compact.hpp): slots per group and interleaved shares of a job.  A batch of
+// 48 jobs or more: groups of 24 slots, a job per slot (the headline's launches: tuned in rounds 2-6).  A SMALL batch left
+// alone (no GLOC_REG_OPT_NN_JOB_GROUP / NN_SUB_JOBS): rows of 8 slots -- one per XCD -- and as few shares of a job as
+// spread the batch evenly over the 8 XCDs (20 jobs: 2 shares, 40 slots, five rows; an odd number of jobs: 8): an XCD then
+// works on ONE job's share at a time and its L2 holds that job's target instead of three.  Round 5 chose 24 slots x 8 shares on
+// rigid copies; on the distinct casts, one query alone, registration of 20 jobs, slots x shares 24 x 8 / 24 x 4 / 24 x 2 /
+// 8 x 4 / 8 x 2: launch by launch 3.24 / 3.21 / 3.10 / 3.21 / 3.08 ms, chained 2.69 / 2.66 / 2.72 / 2.68 / 2.62
+// (profiles/r06_chain_split_sweep.txt).
+void launch_order(const gloc_reg* h, uint32_t n_jobs, uint32_t& jg, uint32_t& subs) {
+  subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (n_jobs < 48 ? 8u : 1u);
+  jg = (uint32_t)h->nn_job_group;
+  if (h->nn_sub_jobs > 0 || h->nn_job_group_set || n_jobs >= 48) return;
+  jg = 8u;
+  subs = n_jobs % 4u == 0u ? 2u : (n_jobs % 2u == 0u ? 4u : 8u);
+}
+
 // S1 for every job of the batch.  warm: corr holds the previous pass's result.  want_pairs: write the (moved
 // source, matched target) pairs INSTEAD of the moments (the RANSAC stage refits from the pairs: accum_kernel<1>).  The culled search leaves the wave partials of the
 // fp64 moments in h->partials (per source group); the exhaustive one needs accum_kernel<0> afterwards.
@@ -256,11 +272,11 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, const WsView& v, bool warm, bool
     // slots of the launch order (nn_compact.hpp): a job each, or -- few jobs -- `subs` interleaved shares of a job, so
     // that the 8 XCDs get equal numbers of slots
     // (8 shares -- one per XCD -- since round 5: one query alone 105.4 -> 104.1 / 104.4 us per pass against 4)
-    const uint32_t subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (v.n_jobs < 48 ? 8u : 1u);
+    uint32_t jg, subs;
+    launch_order(h, v.n_jobs, jg, subs);
     // (one group of all the slots of a small batch, so that every job's helpers start at the head of the launch, was
     // tried: one query alone 0.115 ms per pass against 0.108 with groups of 24)
     const uint32_t n_slots = v.n_jobs * subs;
-    const uint32_t jg = (uint32_t)h->nn_job_group;
     const uint32_t n_wg = (n_wg_job + subs - 1) / subs;
     const unsigned grid = n_wg * jg * ((n_slots + jg - 1) / jg);
     // (launched as (slots of a group, work-groups of a slot, groups): the same linear order without the divisions)
@@ -329,27 +345,13 @@ int launch_nn(gloc_reg* h, const BatchDims& bd, const WsView& v, bool warm, bool
 // The remaining warm moments passes of a small batch -- search, reduce, solve, plan, `n_pass` times -- in ONE launch
 // (NnChain, reg_kernels.hpp; nn_chain_kernel, nn_compact.hpp).  0 passes: the batch does not qualify (the caller goes on
 // launch by launch).
-// The launch order of the chained passes: slots per group and interleaved shares of a job.  Left alone (no
-// GLOC_REG_OPT_NN_JOB_GROUP / NN_SUB_JOBS), rows of 8 slots -- one per XCD -- and as few shares of a job as spread the batch
-// evenly over the 8 XCDs (20 jobs: 2 shares, 40 slots, five rows; an odd number of jobs: 8): an XCD then works on ONE job's share at a
-// time and its L2 holds that job's target instead of three (one query alone, registration of 20 jobs, slots x shares
-// 24 x 8 / 24 x 4 / 8 x 4 / 8 x 2 / 8 x 1: 2.69 / 2.66 / 2.68 / 2.62 / 2.83 ms -- profiles/r06_chain_split_sweep.txt).  Without a
-// launch boundary between the passes the XCDs need not finish a pass together, which is what 8 shares of every job bought.
-void chain_order(const gloc_reg* h, uint32_t n_jobs, uint32_t& jg, uint32_t& subs) {
-  subs = h->nn_sub_jobs > 0 ? (uint32_t)h->nn_sub_jobs : (n_jobs < 48 ? 8u : 1u);
-  jg = (uint32_t)h->nn_job_group;
-  if (h->nn_sub_jobs > 0 || h->nn_job_group_set || n_jobs >= 48) return;
-  jg = 8u;
-  subs = n_jobs % 4u == 0u ? 2u : (n_jobs % 2u == 0u ? 4u : 8u);
-}
-
 uint32_t chain_passes(const gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t remaining) {
   static const bool off = getenv("GLOC3D_NN_NO_CHAIN") != nullptr;  // developer switch
   static const bool force = getenv("GLOC3D_NN_CHAIN_FORCE") != nullptr;  // developer switch: any batch size, with or without the plan, under the per-kernel events
   if (off || !h->nn_chain || h->chain_broken || h->nn_mode == 1 || h->nn_src_per_lane != 2 || h->trace_on || remaining < 2 || NN_WPB != 1) return 0;
   if (!force && (!v.split.hx || h->prof.enabled)) return 0;
   uint32_t jg, subs;
-  chain_order(h, v.n_jobs, jg, subs);
+  launch_order(h, v.n_jobs, jg, subs);
   if ((!force && v.n_jobs >= 48) || (jg & 7u) || jg % subs) return 0;  // (small batches; a group of slots holds whole jobs)
   if ((bd.n_part & 31u) || (v.split.hx & 31u)) return 0;  // (a job's rows of the per-pass tables are whole cache lines)
   const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
@@ -361,7 +363,7 @@ uint32_t chain_passes(const gloc_reg* h, const BatchDims& bd, const WsView& v, u
 
 int launch_nn_chain(gloc_reg* h, const BatchDims& bd, const WsView& v, uint32_t n_pass, float gate2) {
   uint32_t jg, subs;
-  chain_order(h, v.n_jobs, jg, subs);
+  launch_order(h, v.n_jobs, jg, subs);
   const uint32_t n_wg = ((bd.max_groups + v.split.hx + NN_WPB - 1) / NN_WPB + subs - 1) / subs;
   const uint32_t groups = (v.n_jobs * subs + jg - 1) / jg;
   NnChain ch{};

@@ -241,8 +241,10 @@ enum {
   GLOC_REG_OPT_NN_MODE = 2, /* how S1 (exact 1-NN) is searched; the result is identical */
   GLOC_REG_OPT_NN_SRC_PER_LANE = 3, /* culled search tuning: source points per lane (1, 2 or 4) */
   GLOC_REG_OPT_NN_JOB_GROUP = 4,    /* culled search tuning: jobs whose work-groups are interleaved in the
-                                       launch order (their scans share the caches); default 24.  A multiple of
-                                       8 keeps each job's work-groups on one XCD, i.e. its scans in one L2 */
+                                       launch order (their scans share the caches); default 24 -- 8 in a batch under
+                                       48 jobs, with 2 / 4 / 8 shares of a job per slot (NN_SUB_JOBS below), unless either
+                                       option is set.  A multiple of 8 keeps each slot's work-groups on one XCD, i.e. its
+                                       scans in one L2 */
   GLOC_REG_OPT_TEMP_TARGET_INDEX = 5, /* 1: the host-buffer calls (gloc_reg_batch, gloc_reg_nn) build the kd-ordered
                                        target index for their temporary candidate scans too (default 0: a
                                        millisecond per candidate is more than one registration saves) */
@@ -254,8 +256,9 @@ enum {
   GLOC_REG_OPT_NN_SPLIT_THRESH = 7,  /* the estimate (cycles of one wave) above which a group is split; default
                                        60000 (85000 for the batches whose passes are chained: GLOC_REG_OPT_NN_CHAIN); 0: off */
   GLOC_REG_OPT_NN_SUB_JOBS = 8,      /* culled search tuning: interleaved shares of a job's work-groups that take a
-                                       slot of the launch order each (a slot stays on one XCD); 0 (default): 8 for
-                                       batches under 48 jobs, which 8 XCDs cannot balance job by job, else 1 */
+                                       slot of the launch order each (a slot stays on one XCD); 0 (default): in a
+                                       batch under 48 jobs, which 8 XCDs cannot balance job by job, the fewest of 2 / 4 /
+                                       8 that make the slots a multiple of 8 (20 jobs: 2), else 1 */
   GLOC_REG_OPT_NN_HEAVY_THRESH = 9,  /* culled search, first (cold) pass of a batch: a wave that has processed this many
                                        target chunks hands its source group to a second launch, which searches it with
                                        8 waves (identical results); default 32; 0: off */

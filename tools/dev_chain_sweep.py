@@ -35,8 +35,6 @@ def run(chain, thresh, helpers, sub=0, reps=7, jg=0):
     reg.close()
     return float(np.median(ts[3:])) * 1e3, n
 
-print("plain  (8 shares, groups of 24 slots): %.3f ms" % run(0, 60000, 256)[0])
 for rep in range(2):
-    for thresh in (50000, 70000, 85000, 100000, 120000):
-        for helpers in (256, 128):
-            print("chain  (its own order) thresh %6d helpers %3d: %.3f ms" % (thresh, helpers, run(1, thresh, helpers, reps=9)[0]))
+    for jg, sub in ((24, 8), (24, 4), (24, 2), (8, 2), (8, 4), (16, 2), (16, 4)):
+        print("plain  slots per group %2d, shares of a job %d: %.3f ms" % (jg, sub, run(0, 60000, 256, sub, jg=jg, reps=9)[0]))

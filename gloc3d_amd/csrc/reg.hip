@@ -90,6 +90,11 @@ struct gloc_reg {
   DevBuf chain_buf;               // [ready | done | sdone | err] then the reducers' sub-sums
   uint32_t* h_chain_err = nullptr; // pinned: the batch's err word, copied behind the states
   bool chain_in_batch = false;    // the batch enqueued last ran a chained launch
+  // ... and what it takes to run that batch again launch by launch should the chain's waits run out (collect_jobs):
+  // the jobs as enqueue_jobs saw them (JobHost, kept as bytes: the type is this file's) with their initial poses, the parameters
+  std::vector<unsigned char> retry_jobs;
+  std::vector<float> retry_T;
+  gloc_reg_params retry_prm{};
   std::atomic<uint64_t> chain_launches{0}, chain_timeouts{0};
   size_t last_ld = 0;      // shape of the last batch (gloc_reg_debug_corr)
   uint32_t last_jobs = 0;
@@ -690,6 +695,14 @@ int enqueue_jobs(gloc_reg* h, const std::vector<JobHost>& jh, const gloc_reg_par
   GLOC_TRY(rc);
   GLOC_HIP(hipMemcpyAsync(h->h_states, h->states.p, sizeof(CandState) * n_jobs, hipMemcpyDeviceToHost, s));
   GLOC_HIP(hipEventRecord(h->done_ev, s));
+  if (h->chain_in_batch) {  // (a small batch: a few KB)
+    h->retry_jobs.resize(sizeof(JobHost) * n_jobs);
+    memcpy(h->retry_jobs.data(), jh.data(), sizeof(JobHost) * n_jobs);
+    h->retry_T.assign((size_t)16 * n_jobs, 0.f);
+    for (uint32_t c = 0; c < n_jobs; ++c)
+      if (jh[c].init_T) memcpy(&h->retry_T[(size_t)16 * c], jh[c].init_T, sizeof(float) * 16);
+    h->retry_prm = *prm;
+  }
   return GLOC_OK;
 }
 
@@ -701,13 +714,25 @@ int collect_jobs(gloc_reg* h, uint32_t n_jobs, const size_t* n_src_of, float max
   if (n_jobs == 0) return GLOC_OK;
   GLOC_HIP(hipEventSynchronize(h->done_ev));
   if (h->chain_in_batch && *h->h_chain_err) {
-    // a wait inside the chained launch ran out (NN_CHAIN_WAIT_TICKS): its waves left without finishing the passes -- the
-    // poses are not results.  Reported, and the handle goes back to one launch per pass for good.
+    // A wait inside the chained launch ran out (NN_CHAIN_WAIT_TICKS): its waves left without finishing the passes -- the
+    // poses are not results.  The handle goes back to one launch per pass for good, and THIS batch is run again that
+    // way, here (its scans are still pinned: the batch has not been collected): the caller gets the launch-by-launch bits,
+    // late.  Counted (gloc_reg_debug_chain) and said on stderr once per handle.
+    const bool first = !h->chain_broken;
     h->chain_broken = true;
     h->chain_timeouts++;
-    set_err("the chained ICP passes of a batch of %u jobs timed out on the device (a wait for a job's solve ran out); "
-            "this handle now launches pass by pass -- run the batch again", n_jobs);
-    return GLOC_ERR_HIP;
+    if (first)
+      fprintf(stderr, "[gloc3d] the chained ICP passes of a batch of %u jobs timed out on the device (a wait for a job's solve ran out): "
+                      "the batch is run again launch by launch, and this handle launches pass by pass from now on\n", n_jobs);
+    GLOC_REQUIRE(h->retry_jobs.size() == sizeof(JobHost) * n_jobs, GLOC_ERR_HIP,
+                 "the chained ICP passes of a batch of %u jobs timed out on the device and the batch cannot be run again", n_jobs);
+    std::vector<JobHost> jh(n_jobs);
+    memcpy(jh.data(), h->retry_jobs.data(), sizeof(JobHost) * n_jobs);
+    for (uint32_t c = 0; c < n_jobs; ++c)
+      if (jh[c].init_T) jh[c].init_T = &h->retry_T[(size_t)16 * c];
+    const gloc_reg_params prm = h->retry_prm;
+    GLOC_TRY(enqueue_jobs(h, jh, &prm));
+    GLOC_HIP(hipEventSynchronize(h->done_ev));
   }
   static const bool heavy_dbg = getenv("GLOC3D_NN_HEAVY_DEBUG") != nullptr;  // developer switch: the length of the last cold pass's list
   if (heavy_dbg && h->heavy_of[0].cap) {

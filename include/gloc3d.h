@@ -273,8 +273,9 @@ enum {
                                        plans laid end to end, a wave of pass p + 1 waiting on the device for its own
                                        job's solve of pass p -- instead of 2 launches per pass with the chip draining
                                        in between; 0: launch by launch.  Identical results.  Every device-side wait is
-                                       bounded (3 s): a batch whose chain runs out fails with GLOC_ERR_HIP and the
-                                       handle stops chaining */
+                                       bounded (3 s): a batch whose chain runs out is run again launch by launch before
+                                       the call returns (said once on stderr) and the handle stops chaining until this
+                                       option is set again */
 };
 enum {
   GLOC_REG_NN_CULLED = 0,    /* default: Hilbert-sorted scans, box hierarchy, skip what cannot win */

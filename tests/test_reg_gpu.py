@@ -838,33 +838,44 @@ def test_chained_batches_of_unequal_jobs_and_two_chains_at_once(capi, scans):
 
 def test_a_chained_launch_that_stalls_ends_by_itself(capi, scans):
     """Every wait inside the chained launch is bounded: with solvers made to wait for a wave that never comes
-    (gloc_reg_debug_chain_stall) the launch ends by itself within its time limit, the batch FAILS (no pose of it is a result),
-    and the handle goes on launch by launch -- the next batch on it gives the unchained bits."""
+    (gloc_reg_debug_chain_stall) the launch ends by itself within its time limit, no pose of it is used -- the library runs the
+    SAME batch again launch by launch before it returns (the caller gets the unchained bits, late) -- and the handle goes on
+    launch by launch until the option is set again.  Through batch_ids, through begin / end, and with initial poses."""
     import time
     store = capi.ScanStore()
     A, B = scans["A"], scans["B"]
     qid = store.add(np.ascontiguousarray(B[::4]))
     cids = [store.add(np.ascontiguousarray(x)) for x in (A[::4], A[1::5], A[2::6])]
     prm = capi.default_reg_params(ransac_iters=100, icp_iters=4)
+    from gloc3d_amd import synth
+    init = np.stack([synth.se3(1.5 * i, (0.2 * i, -0.1, 0.0)) for i in range(3)]).astype(np.float32)
     r0 = capi.Registrar(store=store)
     r0.set_option(capi.REG_OPT_NN_CHAIN, 0)
     ref = r0.batch_ids(qid, cids, params=prm)
+    ref_init = r0.batch_ids(qid, cids, init_T=init, params=prm)
     r0.close()
+
+    def same(out, want):
+        assert (bits(out["T"]) == bits(want["T"])).all() and (bits(out["rmse"]) == bits(want["rmse"])).all()
+        assert (out["inliers"] == want["inliers"]).all() and (out["ok"] == want["ok"]).all()
+
     r = capi.Registrar(store=store)
     r.debug_chain_stall(True)
     t0 = time.time()
-    with pytest.raises(capi.GlocError, match="timed out"):
-        r.batch_ids(qid, cids, params=prm)
-    assert time.time() - t0 < 10.0
+    same(r.batch_ids(qid, cids, init_T=init, params=prm), ref_init)  # (stalls, times out, is run again launch by launch)
+    assert 1.0 < time.time() - t0 < 15.0
     assert r.debug_chain() == (1, 1)
-    out = r.batch_ids(qid, cids, params=prm)  # (the handle has stopped chaining)
+    same(r.batch_ids(qid, cids, params=prm), ref)  # (the handle has stopped chaining)
     assert r.debug_chain() == (1, 1)
-    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
+    r.set_option(capi.REG_OPT_NN_CHAIN, 1)  # (switched on again by hand, still stalling: through begin / end this time)
+    r.batch_multi_begin([qid], np.array([cids], np.uint32), params=prm)
+    o = r.batch_multi_end()
+    same({k: v[0] for k, v in o.items()}, ref)
+    assert r.debug_chain() == (2, 2)
     r.debug_chain_stall(False)
-    r.set_option(capi.REG_OPT_NN_CHAIN, 1)  # (switched on again by hand)
-    out = r.batch_ids(qid, cids, params=prm)
-    assert r.debug_chain() == (2, 1)
-    assert (bits(out["T"]) == bits(ref["T"])).all() and (bits(out["rmse"]) == bits(ref["rmse"])).all()
+    r.set_option(capi.REG_OPT_NN_CHAIN, 1)
+    same(r.batch_ids(qid, cids, params=prm), ref)
+    assert r.debug_chain() == (3, 2)
     r.close()
     store.close()
 

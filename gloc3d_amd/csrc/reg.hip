@@ -1462,7 +1462,7 @@ int gloc_reg_debug_needed_iters(gloc_reg* h, const uint32_t* inl, const uint32_t
 }
 
 // Test aid (not part of include/gloc3d.h): the next chained launches wait for a wave that never comes -- every wait runs
-// out, the launch ends by itself, the batch fails (tests/test_reg_gpu.py: the bounded waits).
+// out, the launch ends by itself, the batch is run again launch by launch (tests/test_reg_gpu.py: the bounded waits).
 int gloc_reg_debug_chain_stall(gloc_reg* h, int on) {
   GLOC_REQUIRE(h, GLOC_ERR_INVALID, "null handle");
   h->chain_stall = on != 0;

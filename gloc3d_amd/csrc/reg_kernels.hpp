@@ -104,7 +104,7 @@ constexpr uint32_t NN_HEAVY_PARTS = GLOC_NN_HEAVY_PARTS;
 // through so that no XCD keeps a stale dirty line for the end of the launch) -- never a cache write-back.  A warm wave
 // that reads an OLDER pass's correspondence for its bound (a line its XCD still holds) searches from a looser, still valid,
 // bound: same bits.  Every wait is bounded (NN_CHAIN_WAIT_TICKS of the 100 MHz clock): a wave that runs out sets `err`,
-// every waiting wave leaves when it sees it, and the host reports the batch as failed and stops chaining on the handle.
+// every waiting wave leaves when it sees it, and the host runs the batch again launch by launch and stops chaining on the handle.
 // Hot spots (measured, the first version: 21 ms for one query where launch by launch takes 3.2): 1 225 waves per job and
 // pass reading the SAME pose / plan / flag words past the caches are served one after the other where the line lives
 // (~50 ns each: 1 ms per pass), and counters of different jobs in one line serialise the jobs.  Hence: whatever a pass's

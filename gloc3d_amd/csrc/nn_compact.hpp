@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(64 * NN_WPB) __attribute__((amdgpu_waves_per_eu(6, 
   const uint32_t vjob = grp * job_group + vin;
   if (vjob >= n_jobs * subs) return;
   const uint32_t job = vjob / subs;
-  const bool first_wave = wgv == 0u && (slot & 7u) == 0u;  // (dev stamps: one wave of the job's first row)
+  const bool first_wave = wgv == 0u && vjob % subs == 0u;  // (dev stamps: the first wave of the job's first share)
   if (first_wave) chain_stamp(ch, pass, job, n_jobs, 0, 0);  // a first search wave of the job's pass here
   const size_t cell = ((size_t)pass * n_jobs + job) * NN_CHAIN_PAD;
   NnSplit spp = sp;  // the pass's own plan and helpers' table (pass 0: the batch's, written by the launch before)

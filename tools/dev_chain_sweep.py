@@ -35,6 +35,21 @@ def run(chain, thresh, helpers, sub=0, reps=7, jg=0):
     reg.close()
     return float(np.median(ts[3:])) * 1e3, n
 
+# 16 jobs (the first 16 candidates): whole jobs per XCD against halves, both balanced over the 8 XCDs
+rows16 = [r[:16] for r in rows]
+def run16(sub, jg, reps=9):
+    reg = capi.Registrar(store=store)
+    reg.set_option(capi.REG_OPT_NN_SPLIT_THRESH, 85000)
+    reg.set_option(capi.REG_OPT_NN_SUB_JOBS, sub)
+    reg.set_option(capi.REG_OPT_NN_JOB_GROUP, jg)
+    ts = []
+    for _ in range(reps):
+        for qid, row in zip(qids, rows16):
+            t0 = time.time()
+            reg.batch_multi([qid], [row], params=prm)
+            ts.append(time.time() - t0)
+    reg.close()
+    return float(np.median(ts[3:])) * 1e3
 for rep in range(2):
-    for jg, sub in ((24, 8), (24, 4), (24, 2), (8, 2), (8, 4), (16, 2), (16, 4)):
-        print("plain  slots per group %2d, shares of a job %d: %.3f ms" % (jg, sub, run(0, 60000, 256, sub, jg=jg, reps=9)[0]))
+    for jg, sub in ((8, 1), (8, 2), (8, 4), (16, 2), (24, 8)):
+        print("chain, 16 jobs: slots per group %2d, shares of a job %d: %.3f ms" % (jg, sub, run16(sub, jg)))
